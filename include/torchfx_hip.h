@@ -1,0 +1,168 @@
+/*
+ * torchfx_hip.h -- C ABI of libtorchfx_hip.so: the MI355X (gfx950) backend for
+ * the torchfx.filter hot path.
+ *
+ * This is the drop-in boundary.  Every entry point takes plain device pointers,
+ * sizes and a hipStream_t (as void*); no torch types.  Each one cites the
+ * reference interface it replaces (paths relative to the reference repo,
+ * matteospanio/torchfx v0.5.3).  The Python host side (torchfx_amd/torchfx_ext.py)
+ * binds these with ctypes and re-exposes the reference's own names and
+ * signatures (torchfx_ext.biquad_forward / sos_forward / delay_line_forward,
+ * FIR.forward, fft_conv1d); INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - all signal buffers are DEVICE memory, row-major [C, T], time-minor,
+ *     contiguous (row stride == T);
+ *   - coefficient arrays marked HOST are read on the host during the call
+ *     (they are O(K), like the reference's `sos_cpu` argument);
+ *   - state buffers are DEVICE float64, layout identical to the reference
+ *     ([K, C, 2] = {v[n-1], v[n-2]} per section and channel);
+ *   - calls are asynchronous on `stream` (no host sync inside), outputs never
+ *     alias inputs, inputs are never written;
+ *   - return value: 0 = ok, non-zero = error; tfx_last_error() gives the text
+ *     (thread-local).  The Python layer turns it into RuntimeError, as
+ *     TORCH_CHECK does in the reference (binding.cpp:47,63,78).
+ */
+#ifndef TORCHFX_HIP_H
+#define TORCHFX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *tfx_stream_t; /* hipStream_t */
+
+enum tfx_dtype { TFX_F32 = 0, TFX_F64 = 1 };
+
+/* Arithmetic used INSIDE the IIR kernel (I/O dtypes are independent of it).
+ *   TFX_PREC_F64  : float64 recurrences -- what the reference does
+ *                   (_ops.py:95,149; iir_cpu.cpp is all double).  Default.
+ *   TFX_PREC_F32  : float32 recurrences, float64 only on the host tables.
+ *   TFX_PREC_AUTO : F32 when a host-side worst-case error bound derived from
+ *                   the SOS is below `TFX_AUTO_F32_BOUND`, else F64.
+ */
+enum tfx_precision { TFX_PREC_AUTO = 0, TFX_PREC_F32 = 1, TFX_PREC_F64 = 2 };
+
+int tfx_version(void);
+const char *tfx_last_error(void);
+
+/* Device / build facts for reports: fills name[len] with the gfx arch string,
+ * returns #CUs in *cus (either pointer may be NULL). */
+int tfx_device_info(char *name, int len, int *cus);
+
+/* ---------------------------------------------------------------------------
+ * tfx_sos_forward -- fused K-section DF1 SOS cascade.
+ *
+ * Replaces  torchfx_ext.sos_forward(x, sos, sos_cpu, state_x, state_y)
+ *           src/torchfx/_csrc/binding.cpp:52-66,88-91
+ *           -> sos_forward_cpu  src/torchfx/_csrc/cpu/iir_cpu.cpp:64-159
+ *           -> sos_forward_cuda src/torchfx/_csrc/cuda/biquad_forward.cu:49-92
+ * and, with in/out dtype f32, also the casts around it
+ *           x.to(float64)       src/torchfx/_ops.py:149
+ *           out.to(x.dtype)     src/torchfx/filter/iir.py:176
+ *
+ *   x        DEVICE [C,T] of x_dtype
+ *   y        DEVICE [C,T] of y_dtype (written)
+ *   sos_host HOST   [K,6] float64 rows [b0,b1,b2,a0,a1,a2]; a0 ignored
+ *            (iir_cpu.cpp:86) -- this is the reference's `sos_cpu` argument
+ *   state_x_in / state_y_in   DEVICE [K,C,2] float64, or NULL for zeros
+ *            (_ops.py:144-147)
+ *   state_x_out / state_y_out DEVICE [K,C,2] float64 (written), may be NULL
+ *   y_sections  optional DEVICE [K,C,T] of y_dtype: output of every section
+ *            (section-by-section parity checks); NULL in production
+ *   precision  enum tfx_precision
+ * ------------------------------------------------------------------------- */
+int tfx_sos_forward(const void *x, int x_dtype, void *y, int y_dtype,
+                    int64_t C, int64_t T,
+                    const double *sos_host, int64_t K,
+                    const double *state_x_in, const double *state_y_in,
+                    double *state_x_out, double *state_y_out,
+                    void *y_sections, int precision, tfx_stream_t stream);
+
+/* What AUTO would pick for this SOS, and the plan facts (for DESIGN/bench
+ * reporting and tests): *precision (TFX_PREC_F32/F64), *warmup (samples of
+ * warm-up halo per time segment; -1 = filter memory too long, sequential
+ * segments), *err_bound (worst-case |error| of the f32 path for |x|<=1). */
+int tfx_sos_plan_info(const double *sos_host, int64_t K,
+                      int *precision, int64_t *warmup, double *err_bound);
+
+/* ---------------------------------------------------------------------------
+ * tfx_biquad_forward -- single DF1 biquad.
+ * Replaces  torchfx_ext.biquad_forward(x, b, a1, a2, state_x, state_y)
+ *           binding.cpp:30-50,84-87 -> biquad_forward_cpu iir_cpu.cpp:10-62 /
+ *           biquad_forward_cuda cuda/biquad_forward.cu:7-47.
+ * b_host = HOST [3]; states DEVICE [C,2] float64 (NULL = zeros).
+ * ------------------------------------------------------------------------- */
+int tfx_biquad_forward(const void *x, int x_dtype, void *y, int y_dtype,
+                       int64_t C, int64_t T,
+                       const double *b_host, double a1, double a2,
+                       const double *state_x_in, const double *state_y_in,
+                       double *state_x_out, double *state_y_out,
+                       int precision, tfx_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * tfx_fir_direct_forward -- causal depthwise FIR, direct form.
+ * Replaces the conv_mode="direct" branch of FIR.forward
+ *           src/torchfx/filter/fir.py:556-568  (F.pad + F.conv1d(groups=C)):
+ *   y[c,n] = sum_{j<K} kernel[j] * xpad[c,n+j],  xpad = x left-padded by K-1,
+ * with `kernel` the FLIPPED taps exactly as FIR stores them (fir.py:516-518).
+ * kernel_host: HOST [K] of `dtype`.  x, y: DEVICE [C,T] of `dtype`.
+ * ------------------------------------------------------------------------- */
+int tfx_fir_direct_forward(const void *x, void *y, int dtype,
+                           int64_t C, int64_t T,
+                           const void *kernel_host, int64_t K,
+                           tfx_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * tfx_fft_conv_forward -- overlap-save FFT convolution (rocFFT + HIP kernels).
+ * Replaces  fft_conv1d(x, kernel, padding=(l,r))
+ *           src/torchfx/filter/_fftconv.py:70-141
+ * and through it the default conv_mode="fft" branch of FIR.forward
+ *           src/torchfx/filter/fir.py:552-555.
+ *   x  DEVICE [C,T];  kernel_host HOST [K] FLIPPED taps (the reference's
+ *   [1,1,K] buffer);  y DEVICE [C, T+pad_left+pad_right-K+1] (written).
+ * Errors like the reference: rc != 0 with "kernel size" in the message when
+ * T+l+r < K (_fftconv.py:111-115).
+ * The FFT block size is chosen for MI355X (power of two), not the
+ * reference's int(5*K); results agree to float rounding.
+ * ------------------------------------------------------------------------- */
+int tfx_fft_conv_forward(const void *x, void *y, int dtype,
+                         int64_t C, int64_t T,
+                         const void *kernel_host, int64_t K,
+                         int64_t pad_left, int64_t pad_right,
+                         tfx_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * tfx_delay_line_forward -- kept because the reference extension exports it
+ * (binding.cpp:68-81,92-95; tests/test_ops_dispatch.py:29-35); out of the
+ * hot-path scope.  y = x + (mix*decay) * x[n-delay]  (delay_cpu.cpp:17-41).
+ * ------------------------------------------------------------------------- */
+int tfx_delay_line_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
+                           int64_t delay, double decay, double mix, tfx_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * tfx_sum_forward -- y = sum_i xs[i]  (the accumulate of
+ * ParallelFilterCombination.forward, src/torchfx/filter/__base.py:1019-1026).
+ * xs_host: HOST array of n DEVICE pointers, each [numel] of dtype.
+ * ------------------------------------------------------------------------- */
+int tfx_sum_forward(const void *const *xs_host, int n, void *y, int dtype,
+                    int64_t numel, tfx_stream_t stream);
+
+/* Timing hooks for bench.py: HIP events recorded on the SAME stream the
+ * kernels are launched on (torch.cuda.Event only sees torch's current stream).
+ * tfx_prof_enable(1) makes every kernel launch inside the library bracket
+ * itself with events; tfx_prof_collect() synchronises and returns, per kernel
+ * name, call count and total milliseconds as a JSON string (static buffer). */
+int tfx_prof_enable(int on);
+const char *tfx_prof_collect(void);
+
+/* Drop all cached plans / device workspaces (tests, memory pressure). */
+int tfx_clear_caches(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TORCHFX_HIP_H */

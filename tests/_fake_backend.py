@@ -1,0 +1,54 @@
+"""TEST-ONLY stand-in for torchfx_amd.torchfx_ext built on the CPU oracle (see the
+``oracle_backend`` fixture).  Lets the host-side logic run on a machine without a GPU."""
+import numpy as np
+import torch
+
+from oracle import oracle as O
+
+calls = []
+
+
+def _np(t):
+    return None if t is None else t.detach().cpu().numpy()
+
+
+def sos_forward(x, sos, sos_cpu, state_x, state_y, *, out_dtype=None, precision=None, return_sections=False):
+    calls.append(("sos_forward", tuple(x.shape), int((sos_cpu if sos_cpu is not None else sos).shape[0])))
+    s = _np(sos_cpu if sos_cpu is not None else sos)
+    y, sx, sy, sec = O.sos_forward(_np(x), s, _np(state_x), _np(state_y), sections=True)
+    odt = x.dtype if out_dtype is None else out_dtype
+    out = (torch.from_numpy(y).to(odt), torch.from_numpy(sx), torch.from_numpy(sy))
+    return out + (torch.from_numpy(sec).to(odt),) if return_sections else out
+
+
+def biquad_forward(x, b, a1, a2, state_x, state_y, *, out_dtype=None, precision=None):
+    calls.append(("biquad_forward", tuple(x.shape)))
+    y, sx, sy = O.biquad_forward(_np(x), _np(b), a1, a2, _np(state_x), _np(state_y))
+    odt = x.dtype if out_dtype is None else out_dtype
+    return torch.from_numpy(y).to(odt), torch.from_numpy(sx), torch.from_numpy(sy)
+
+
+def fir_direct_forward(x, kernel):
+    calls.append(("fir_direct_forward", tuple(x.shape), int(kernel.numel())))
+    k = _np(kernel).reshape(-1).astype(_np(x).dtype)
+    return torch.from_numpy(O.fir_direct(_np(x), k))
+
+
+def fft_conv_forward(x, kernel, padding=(0, 0)):
+    calls.append(("fft_conv_forward", tuple(x.shape), int(kernel.numel())))
+    k = _np(kernel).reshape(-1).astype(_np(x).dtype)
+    return torch.from_numpy(np.ascontiguousarray(O.fft_conv1d(_np(x), k, padding)))
+
+
+def sum_forward(tensors):
+    calls.append(("sum_forward", len(tensors)))
+    out = torch.zeros_like(tensors[0])
+    for t in tensors:
+        out += t
+    return out
+
+
+def delay_line_forward(x, delay_samples, decay, mix):
+    if x.shape[-1] <= delay_samples:
+        return x
+    return torch.from_numpy(O.delay_line(_np(x).reshape(-1, x.shape[-1]), delay_samples, decay, mix)).reshape(x.shape)

@@ -1,0 +1,56 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # a gpu test started without a device is a setup error, not a silent pass
+    try:
+        import torch
+        has = torch.cuda.is_available()
+    except Exception:
+        has = False
+    if has:
+        return
+    skip = pytest.mark.skip(reason="no ROCm device")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+        return cache[name]
+
+    return load
+
+
+@pytest.fixture()
+def oracle_backend(monkeypatch):
+    """Route torchfx_amd.torchfx_ext to the CPU oracle so HOST logic (planner, shapes, state
+    rules, error behaviour, sharding) can be tested without a GPU.  Test-only: the product has
+    no such path."""
+    from tests import _fake_backend
+    from torchfx_amd import torchfx_ext
+
+    for name in ("sos_forward", "biquad_forward", "fir_direct_forward", "fft_conv_forward",
+                 "sum_forward", "delay_line_forward"):
+        monkeypatch.setattr(torchfx_ext, name, getattr(_fake_backend, name))
+    return _fake_backend

@@ -1,0 +1,351 @@
+"""GPU parity: the HIP path (through torchfx_ext -> C ABI of libtorchfx_hip.so) against the CPU
+oracle and the golden vectors generated from the real reference.
+
+Stated tolerances (signals are scaled to max|x| <= 1; `scale` = max(1, max|expected|)):
+  IIR, float64 arithmetic (default, what the reference does):
+      float32 output : 1.5e-7 * scale   (one float32 ulp of the downcast; float64 sums may be
+                                          associated differently than iir_cpu.cpp's -ffast-math build)
+      float64 output : 2e-11 * scale ; states 2e-10 * scale
+  IIR, float32 arithmetic (opt-in, TFX_PREC_F32): 5e-6 * scale on well-conditioned filters
+  FIR direct / FFT convolution (float32): 1e-5 * scale   (reference's own bar is 1e-4:
+      tests/test_fir.py:90, tests/test_fftconv.py:77) ; float64: 1e-11 * scale
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_IIR_F32OUT = 1.5e-7
+TOL_IIR_F64OUT = 2e-11
+TOL_STATE = 2e-10
+TOL_IIR_F32MATH = 5e-6
+TOL_CONV_F32 = 1e-5
+TOL_CONV_F64 = 1e-11
+
+DEV = "cuda:0"
+
+
+def ext():
+    from torchfx_amd import torchfx_ext
+    return torchfx_ext
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def close(got, exp, tol, what=""):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    exp = np.asarray(exp)
+    assert got.shape == exp.shape, f"{what}: shape {got.shape} != {exp.shape}"
+    if exp.size == 0:
+        return
+    scale = max(1.0, float(np.abs(exp).max()))
+    err = float(np.abs(got.astype(np.float64) - exp.astype(np.float64)).max())
+    assert np.isfinite(err) and err <= tol * scale, f"{what}: max err {err:.3e} > {tol * scale:.3e}"
+
+
+def rnd(shape, seed, dtype=np.float32):
+    g = np.random.default_rng(seed)
+    x = g.standard_normal(shape)
+    return (x / np.abs(x).max()).astype(dtype)
+
+
+@pytest.fixture(params=[0, 1, 2, 3], ids=["lc32", "lc16", "lc32pf", "lc16pf"])
+def sos_variant(request, monkeypatch):
+    monkeypatch.setenv("TFX_SOS_VARIANT", str(request.param))
+    return request.param
+
+
+# ------------------------------------------------------------------------------------- IIR
+def test_library_loaded_and_device():
+    from torchfx_amd import _lib
+    lib = _lib.load()
+    assert lib.tfx_version() >= 100
+    import ctypes
+    name = ctypes.create_string_buffer(64)
+    cus = ctypes.c_int(0)
+    assert lib.tfx_device_info(name, 64, ctypes.byref(cus)) == 0
+    assert name.value.decode().startswith("gfx950"), name.value
+    assert cus.value >= 200
+
+
+def test_cfg1_golden(golden, sos_variant):
+    g = golden("iir_cfg1")
+    y, sx, sy = ext().sos_forward(dev(g["x"]), None, torch.from_numpy(g["sos"]), None, None)
+    assert y.dtype == torch.float32
+    close(y, g["y"], TOL_IIR_F32OUT, "y")
+    close(sx, g["state_x"], TOL_STATE, "sx")
+    close(sy, g["state_y"], TOL_STATE, "sy")
+
+
+def test_cfg2_section_by_section_golden(golden, sos_variant):
+    """IIR compared after EVERY section (north_star), against the reference's own
+    section-by-section float64 outputs."""
+    g = golden("iir_cfg2_sections")
+    sos = torch.from_numpy(g["sos"])
+    # (a) fused kernel with its per-section taps, float64 in/out
+    y, sx, sy, sec = ext().sos_forward(dev(g["x"].astype(np.float64)), None, sos, None, None,
+                                       return_sections=True)
+    for k in range(g["sos"].shape[0]):
+        close(sec[k], g["y_sections"][k], TOL_IIR_F64OUT, f"section {k} (fused taps)")
+    close(y, g["y_sections"][-1], TOL_IIR_F64OUT, "final")
+    close(sx, g["state_x"], TOL_STATE, "sx")
+    close(sy, g["state_y"], TOL_STATE, "sy")
+    # (b) one launch per section through the public op, like the fixture was generated
+    cur = dev(g["x"].astype(np.float64))
+    for k in range(g["sos"].shape[0]):
+        cur, _, _ = ext().sos_forward(cur, None, sos[k:k + 1], None, None)
+        close(cur, g["y_sections"][k], TOL_IIR_F64OUT, f"section {k} (staged)")
+    # (c) production path: float32 in / float32 out
+    y32, _, _ = ext().sos_forward(dev(g["x"]), None, sos, None, None)
+    close(y32, g["y"], TOL_IIR_F32OUT, "f32 out")
+
+
+def test_chunked_state_carry_golden(golden, sos_variant):
+    g = golden("iir_chunked")
+    sos = torch.from_numpy(g["sos"])
+    x = dev(g["x"])
+    y1, sx, sy = ext().sos_forward(x[:, :1024].contiguous(), None, sos, None, None)
+    close(y1, g["y1"], TOL_IIR_F64OUT, "y1")
+    close(sx, g["mid_state_x"], TOL_STATE, "mid sx")
+    close(sy, g["mid_state_y"], TOL_STATE, "mid sy")
+    y2, sx, sy = ext().sos_forward(x[:, 1024:].contiguous(), None, sos, sx, sy)
+    close(y2, g["y2"], TOL_IIR_F64OUT, "y2")
+    close(sx, g["state_x"], TOL_STATE, "sx")
+    close(sy, g["state_y"], TOL_STATE, "sy")
+
+
+@pytest.mark.parametrize("name", ["hicheby1_20", "hibutter_20_o5", "lobutter_40_o8", "ellip_o12",
+                                  "notch_q30", "butter_o20"])
+def test_ill_conditioned_golden(golden, name, sos_variant):
+    g = golden("iir_hard")
+    y, sx, sy = ext().sos_forward(dev(g["x"]), None, torch.from_numpy(g[name + "_sos"]), None, None)
+    close(y, g[name + "_y"], 2.5e-7, name)      # pole radius ~0.999: allow 2 ulp
+    close(sy, g[name + "_sy"], 1e-8, name + " sy")
+
+
+def test_states_edges_golden(golden, sos_variant):
+    g = golden("iir_shapes")
+    sos = torch.from_numpy(g["s_sos"])
+    isx, isy = dev(g["isx"]), dev(g["isy"])
+    y, sx, sy = ext().sos_forward(dev(g["xs"]), None, sos, isx, isy)
+    close(y, g["ys"], TOL_IIR_F64OUT, "y")
+    close(sx, g["nsx"], TOL_STATE, "sx")
+    close(sy, g["nsy"], TOL_STATE, "sy")
+    assert torch.equal(isx.cpu(), torch.from_numpy(g["isx"]))      # inputs never modified
+    for t in (1, 2, 3):
+        y, sx, sy = ext().sos_forward(dev(g["xs"][:, :t]), None, sos, isx, isy)
+        close(y, g[f"t{t}_y"], TOL_IIR_F64OUT, f"T={t} y")
+        close(sx, g[f"t{t}_sx"], TOL_STATE, f"T={t} sx")
+        close(sy, g[f"t{t}_sy"], TOL_STATE, f"T={t} sy")
+
+
+def test_biquad_entry_point(golden):
+    g = golden("iir_shapes")
+    s = g["bq_sos"][0]
+    x = dev(g["x1d"][None])
+    y, sx, sy = ext().biquad_forward(x, torch.tensor(s[:3]), float(s[4]), float(s[5]), None, None)
+    close(y[0], g["y1d"], TOL_IIR_F32OUT, "biquad y")
+    assert sx.shape == (1, 2) and sy.shape == (1, 2)
+    close(sx, g["bq_sx"][0], TOL_STATE)
+    close(sy, g["bq_sy"][0], TOL_STATE)
+
+
+@pytest.mark.parametrize("C,T,K", [(1, 1, 1), (3, 7, 2), (5, 63, 3), (2, 2049, 4), (7, 4097, 1),
+                                   (1, 100003, 5), (64, 8192, 4), (3, 200000, 16)])
+def test_random_shapes_vs_oracle(C, T, K, sos_variant):
+    """Odd lengths (unaligned rows -> dword path), tiny inputs, many sections, random states."""
+    rng = np.random.default_rng(C * 1000 + T + K)
+    from scipy.signal import butter
+    sos = np.vstack([butter(2, rng.uniform(0.02, 0.6), output="sos") for _ in range(K)])
+    x = rnd((C, T), T)
+    sx0, sy0 = rng.standard_normal((K, C, 2)), rng.standard_normal((K, C, 2))
+    ey, esx, esy = O.sos_forward(x, sos, sx0, sy0)
+    y, sx, sy = ext().sos_forward(dev(x), None, torch.from_numpy(sos), dev(sx0), dev(sy0))
+    close(y, ey.astype(np.float32), 2.5e-7, "y")
+    close(sx, esx, TOL_STATE, "sx")
+    close(sy, esy, TOL_STATE, "sy")
+
+
+def test_time_segmentation_is_exact(monkeypatch):
+    """Segments with a warm-up halo (parallel over time) == one sequential segment per row."""
+    from scipy.signal import butter
+    sos = np.vstack([butter(6, 2000 / 24000, output="sos"), butter(2, 300 / 24000, "highpass", output="sos")])
+    x = dev(rnd((4, 1_500_000), 3).astype(np.float64))
+    monkeypatch.setenv("TFX_SOS_NSEG", "1")
+    y1, sx1, sy1 = ext().sos_forward(x, None, torch.from_numpy(sos), None, None)
+    for nseg in ("0", "7", "64", "300"):
+        monkeypatch.setenv("TFX_SOS_NSEG", nseg)
+        y2, sx2, sy2 = ext().sos_forward(x, None, torch.from_numpy(sos), None, None)
+        close(y2, y1.cpu().numpy(), 1e-13, f"nseg={nseg}")
+        close(sy2, sy1.cpu().numpy(), 1e-13, f"nseg={nseg} state")
+
+
+def test_long_memory_filter_falls_back_to_sequential():
+    """A pole pair at radius 0.999999 never decays within 2^26 samples -> nseg = 1, still exact."""
+    r, th = 0.999999, 0.01
+    sos = np.array([[1e-6, 0, 0, 1, -2 * r * np.cos(th), r * r]])
+    from torchfx_amd import torchfx_ext as E
+    info = E.sos_plan_info(sos)
+    x = rnd((2, 300_000), 5)
+    ey, _, esy = O.sos_forward(x, sos)
+    y, _, sy = ext().sos_forward(dev(x), None, torch.from_numpy(sos), None, None, out_dtype=torch.float64)
+    close(y, ey, 1e-9, f"y (warmup={info['warmup']})")
+    close(sy, esy, 1e-9, "sy")
+
+
+def test_f32_arithmetic_mode(golden):
+    g = golden("iir_cfg2_sections")
+    y, _, _ = ext().sos_forward(dev(g["x"]), None, torch.from_numpy(g["sos"]), None, None, precision="f32")
+    close(y, g["y"], TOL_IIR_F32MATH, "f32 math")
+
+
+def test_mixed_io_dtypes(golden):
+    g = golden("iir_cfg2_sections")
+    sos = torch.from_numpy(g["sos"])
+    y, _, _ = ext().sos_forward(dev(g["x"]), None, sos, None, None, out_dtype=torch.float64)
+    assert y.dtype == torch.float64
+    close(y, g["y_sections"][-1], TOL_IIR_F64OUT, "f32 in / f64 out")
+    y, _, _ = ext().sos_forward(dev(g["x"].astype(np.float64)), None, sos, None, None, out_dtype=torch.float32)
+    close(y, g["y"], TOL_IIR_F32OUT, "f64 in / f32 out")
+
+
+def test_errors_are_runtime_errors():
+    x = torch.zeros(2, 16)
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        ext().sos_forward(x, None, torch.eye(6)[:1].double(), None, None)
+    xd = x.to(DEV)
+    with pytest.raises(RuntimeError, match="state_x"):
+        ext().sos_forward(xd, None, torch.tensor([[1., 0, 0, 1, 0, 0]]).double(), torch.zeros(3, 2, 2).to(DEV), None)
+    with pytest.raises(RuntimeError, match="non-finite"):
+        ext().sos_forward(xd, None, torch.tensor([[float("nan"), 0, 0, 1, 0, 0]]).double(), None, None)
+    with pytest.raises(RuntimeError, match="kernel size"):
+        ext().fft_conv_forward(xd, torch.ones(64))
+
+
+# ------------------------------------------------------------------------------------- FIR
+@pytest.mark.parametrize("K", [5, 32, 1024])
+def test_fir_golden(golden, K):
+    g = golden("fir")
+    x = dev(g["x"])
+    close(ext().fir_direct_forward(x, g[f"k{K}"]), g[f"direct{K}"], TOL_CONV_F32, "direct")
+    close(ext().fft_conv_forward(x, g[f"k{K}"], (K - 1, 0)), g[f"fft{K}"], TOL_CONV_F32, "fft")
+
+
+def test_fir_short_and_f64_golden(golden):
+    g = golden("fir")
+    close(ext().fir_direct_forward(dev(g["xs"]), g["ks"]), g["ys_direct"], TOL_CONV_F32)
+    close(ext().fft_conv_forward(dev(g["xs"]), g["ks"], (31, 0)), g["ys_fft"], TOL_CONV_F32)
+    close(ext().fir_direct_forward(dev(g["xt"]), g["kt"]), g["yt_direct"], TOL_CONV_F64)     # T < K, f64
+    close(ext().fft_conv_forward(dev(g["xt"]), g["kt"], (63, 0)), g["yt_fft"], TOL_CONV_F64)
+
+
+@pytest.mark.parametrize("C,T,K", [(1, 1, 1), (2, 100, 3), (3, 5000, 1025), (1, 40000, 2500), (5, 16385, 64)])
+def test_fir_direct_shapes_vs_f64(C, T, K):
+    from scipy.signal import lfilter
+    rng = np.random.default_rng(K)
+    b = (rng.standard_normal(K) / K).astype(np.float32)
+    x = rnd((C, T), T + K)
+    exp = lfilter(b.astype(np.float64), [1.0], x.astype(np.float64), axis=-1)
+    y = ext().fir_direct_forward(dev(x), b[::-1].copy())
+    close(y, exp.astype(np.float32), TOL_CONV_F32, "direct vs lfilter f64")
+    y2 = ext().fft_conv_forward(dev(x), b[::-1].copy(), (K - 1, 0))
+    close(y2, exp.astype(np.float32), TOL_CONV_F32, "fft vs lfilter f64")
+
+
+def test_fftconv_golden(golden):
+    g = golden("fftconv")
+    x = dev(g["x"])
+    for K in (64, 4097):
+        close(ext().fft_conv_forward(x, g[f"k{K}"], (K - 1, 0)), g[f"y{K}"], TOL_CONV_F32, f"K={K}")
+    close(ext().fft_conv_forward(x, g["k16"], (8, 7)), g["y16_pad87"], TOL_CONV_F32, "pad (8,7)")
+
+
+def reverb_ir(K=65536):
+    ir = np.random.default_rng(0).standard_normal(K) * np.exp(-np.arange(K) / 8000.0)
+    return (ir / np.abs(ir).sum()).astype(np.float32)
+
+
+def test_fftconv_65536_golden(golden, monkeypatch):
+    g = golden("fftconv")
+    kf = reverb_ir()[::-1].copy()
+    for lg in ("0", "17", "19"):
+        monkeypatch.setenv("TFX_FFT_LOG2N", lg)
+        y = ext().fft_conv_forward(dev(g["x_long"]), kf, (65535, 0))
+        close(y, g["y_long"], TOL_CONV_F32, f"log2N={lg}")
+
+
+def test_fftconv_slabbing(monkeypatch):
+    """Channel slabs (bounded workspace) give the same result as one slab."""
+    x = dev(rnd((6, 70000), 1))
+    k = rnd((300,), 2)
+    monkeypatch.setenv("TFX_FFT_WS_MB", "4096")
+    y1 = ext().fft_conv_forward(x, k, (299, 0))
+    monkeypatch.setenv("TFX_FFT_WS_MB", "1")
+    y2 = ext().fft_conv_forward(x, k, (299, 0))
+    assert torch.equal(y1, y2)
+
+
+# ------------------------------------------------------------------------ modules / planner
+def test_wave_chain_golden(golden):
+    from torchfx_amd import Wave
+    from torchfx_amd import filter as F
+    g = golden("chain")
+    f1, f2 = F.HiButterworth(100, order=2), F.LoButterworth(8000, order=4)
+    f3 = F.ParametricEQ(2000, 1.0, -3.0)
+    fir = F.DesignableFIR(cutoff=6000, num_taps=127, fs=48000)
+    w = Wave(g["x"], 48000, device=DEV) | f1 | f2 | fir | f3
+    close(w.ys, g["y_chain"], TOL_CONV_F32, "wave chain")
+    p1, p2 = F.LoButterworth(1000, order=2, fs=48000), F.HiButterworth(4000, order=2, fs=48000)
+    close((p1 + p2)(dev(g["x"])), g["y_par"], 3e-7, "parallel sum")
+
+
+def test_cfg5_small_chain_golden_staged_and_fused(golden):
+    from scipy.signal import firwin
+    from torchfx_amd import Wave
+    from torchfx_amd import filter as F
+    g = golden("chain")
+    irs = np.random.default_rng(1).standard_normal(4097) * np.exp(-np.arange(4097) / 500.0)
+    irs = irs / np.abs(irs).sum()
+
+    def pipe(fuse):
+        w = Wave(g["xc"], 48000, device=DEV)
+        w.fuse_fir = fuse
+        return (w | F.LoButterworth(2000, order=6) | F.ParametricEQ(frequency=1000, q=2.0, gain=3.0)
+                | F.FIR(firwin(1024, 5000, fs=48000)) | F.FIR(irs))
+    close(pipe(False).ys, g["yc"], TOL_CONV_F32, "staged chain")
+    wf = pipe(True)
+    assert len(wf.plan()) == 2          # one SOS cascade + one merged FIR
+    close(wf.ys, g["yc"], TOL_CONV_F32, "fused chain (merged FIR)")
+
+
+def test_module_shapes_dtype_and_state_rules(golden):
+    from torchfx_amd import filter as F
+    g = golden("iir_shapes")
+    bq = F.BiquadLPF(cutoff=1500, q=0.9, fs=48000)
+    y = bq(dev(g["x1d"]))
+    assert y.shape == g["y1d"].shape and y.dtype == torch.float32
+    close(y, g["y1d"], TOL_IIR_F32OUT, "1-D")
+    close(bq._state_y, g["bq_sy"], TOL_STATE)
+    lr = F.LoLinkwitzRiley(1200, order=4, fs=44100)
+    y = lr(dev(g["x3d"]))
+    assert y.dtype == torch.float64
+    close(y, g["y3d"], TOL_IIR_F64OUT, "3-D")
+    assert lr._state_x.shape == (2, 6, 2)
+    close(lr._state_y, g["lr_sy"], TOL_STATE)
+    lr(dev(g["x3d"][0]))                    # channel count changes: state silently re-zeroed
+    assert lr._state_x.shape == (2, 3, 2)
+
+
+def test_delay_and_passthrough(golden):
+    g = golden("delay")
+    close(ext().delay_line_forward(dev(g["x"]), 100, 0.5, 0.3), g["y"], 1e-7)
+    x = dev(g["x"])
+    assert ext().delay_line_forward(x, 5000, 0.5, 0.3) is x
+    y, sx, sy = ext().sos_forward(x, None, torch.tensor([[1., 0, 0, 1, 0, 0]]).double(), None, None)
+    assert torch.equal(y, x)                # pass-through section is exact (test_ops_dispatch.py:45-52)
+    assert sx.shape == (1, 2, 2)

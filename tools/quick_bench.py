@@ -1,0 +1,85 @@
+"""Developer micro-benchmark (not the driver's bench.py): times individual ops with the
+library's own HIP-event profiler, sweeping the tuning knobs exposed as env vars."""
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from torchfx_amd import _lib, torchfx_ext as E  # noqa: E402
+
+lib = _lib.load()
+
+
+def timed(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    lib.tfx_prof_enable(1)
+    lib.tfx_prof_collect()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps * 1e3
+    prof = json.loads(lib.tfx_prof_collect().decode())
+    lib.tfx_prof_enable(0)
+    return wall, {k: v["total_ms"] / reps for k, v in prof.items()}
+
+
+def main():
+    which = sys.argv[1:] or ["sos", "fir", "fft"]
+    dev = "cuda:0"
+    from scipy.signal import butter, firwin
+    if "sos" in which:
+        C, T = 64, 2_880_000
+        x = torch.randn(C, T, device=dev)
+        sos = np.vstack([butter(6, 2000 / 24000, output="sos"),
+                         np.array([[1.0089, -1.9636, 0.9695, 1, -1.9636, 0.9784]])])
+        sos_t = torch.from_numpy(sos)
+        print("plan", E.sos_plan_info(sos))
+        for prec in ("f64", "f32"):
+            for var in (0, 1, 2, 3):
+                for wpc in (8, 12, 16, 24, 32):
+                    os.environ["TFX_SOS_VARIANT"] = str(var)
+                    os.environ["TFX_SOS_WAVES_PER_CU"] = str(wpc)
+                    wall, prof = timed(lambda: E.sos_forward(x, None, sos_t, None, None, precision=prec))
+                    ms = list(prof.values())[0]
+                    print(f"sos {prec} var={var} waves/cu={wpc:2d}: kernel {ms:7.3f} ms  wall {wall:7.3f} ms  "
+                          f"{C * T / ms / 1e3:9.1f} Msamp/s  {8 * C * T / ms / 1e9:6.2f} TB/s ({8 * C * T / ms / 1e9 / 8 * 100:5.1f}% of 8 TB/s)",
+                          flush=True)
+        del x
+    if "fir" in which:
+        C, T = 64, 2_880_000
+        x = torch.randn(C, T, device=dev)
+        k = firwin(1024, 5000, fs=48000).astype(np.float32)[::-1].copy()
+        wall, prof = timed(lambda: E.fir_direct_forward(x, k), reps=3, warm=1)
+        ms = list(prof.values())[0]
+        print(f"fir direct 1024: kernel {ms:.3f} ms wall {wall:.3f}  {C * T / ms / 1e3:.1f} Msamp/s  "
+              f"{2 * 1024 * C * T / ms / 1e9:.1f} TFLOP/s ({2 * 1024 * C * T / ms / 1e9 / 157.3 * 100:.1f}% of 157.3)", flush=True)
+        wall, prof = timed(lambda: E.fft_conv_forward(x, k, (1023, 0)), reps=3, warm=1)
+        print(f"fir fft 1024: wall {wall:.3f} ms  {C * T / wall / 1e3:.1f} Msamp/s", prof, flush=True)
+        del x
+    if "fft" in which:
+        C, T = 64, 2_880_000 * (10 if "big" in which else 1)
+        x = torch.randn(C, T, device=dev)
+        K = 65536
+        ir = np.random.default_rng(0).standard_normal(K) * np.exp(-np.arange(K) / 8000.0)
+        k = (ir / np.abs(ir).sum()).astype(np.float32)[::-1].copy()
+        for lg in (17, 18, 19, 20):
+            for ws in (256, 2048, 16384):
+                os.environ["TFX_FFT_LOG2N"] = str(lg)
+                os.environ["TFX_FFT_WS_MB"] = str(ws)
+                wall, prof = timed(lambda: E.fft_conv_forward(x, k, (K - 1, 0)), reps=2, warm=1)
+                tot = sum(prof.values())
+                print(f"fftconv 65536 log2N={lg} ws={ws:5d}MB: wall {wall:8.3f} ms kernels {tot:8.3f} ms  "
+                      f"{C * T / wall / 1e3:9.1f} Msamp/s  {8 * C * T / wall / 1e9:5.2f} TB/s  "
+                      + " ".join(f"{n.replace('_kernel', '')}={v:.2f}" for n, v in prof.items()), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,289 @@
+// capi.hip -- extern "C" surface of libtorchfx_hip.so (see include/torchfx_hip.h) plus the
+// small shared services: thread-local error text, per-kernel HIP-event timing, device scratch,
+// and the two elementwise kernels (delay line, branch sum).
+#include "common.h"
+#include "../../include/torchfx_hip.h"
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace tfx {
+
+// implemented in sos.hip / fir.hip / fftconv.hip
+void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C, int64_t T,
+                 const double *sos_host, int64_t K, const double *sx_in, const double *sy_in,
+                 double *sx_out, double *sy_out, void *y_sections, int precision, hipStream_t stream);
+void sos_plan_info(const double *sos_host, int64_t K, int *precision, int64_t *warmup, double *err_bound);
+void sos_clear_plans();
+void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
+                        const void *kernel_host, int64_t K, hipStream_t stream);
+void fir_clear();
+void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, const void *kernel_host,
+                      int64_t K, int64_t pad_left, int64_t pad_right, hipStream_t stream);
+void fftconv_clear();
+
+// ---- errors ------------------------------------------------------------------------------------
+static thread_local std::string t_last_error;
+void set_last_error(const std::string &msg) { t_last_error = msg; }
+
+// ---- profiling -----------------------------------------------------------------------------------
+struct ProfRec {
+    std::string name;
+    hipEvent_t a, b;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<ProfRec> g_open;
+
+bool prof_on() { return g_prof_on; }
+void prof_begin(const char *name, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r;
+    r.name = name;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, s);
+    g_open.push_back(r);
+}
+void prof_end(hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_open.empty()) return;
+    ProfRec r = g_open.back();
+    g_open.pop_back();
+    (void)hipEventRecord(r.b, s);
+    g_prof.push_back(r);
+}
+
+// ---- scratch -------------------------------------------------------------------------------------
+struct Scratch {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+static std::mutex g_scr_mu;
+static std::map<std::string, Scratch> g_scr;
+void *scratch(const char *tag, size_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g_scr_mu);
+    Scratch &s = g_scr[tag];
+    if (s.bytes < bytes) {
+        if (s.p) {
+            // the old buffer may still be in use by queued work: drain before freeing
+            (void)hipDeviceSynchronize();
+            (void)hipFree(s.p);
+            s.p = nullptr;
+            s.bytes = 0;
+        }
+        TFX_HIP(hipMalloc(&s.p, bytes));
+        s.bytes = bytes;
+    }
+    return s.p;
+}
+void scratch_clear()
+{
+    std::lock_guard<std::mutex> lk(g_scr_mu);
+    (void)hipDeviceSynchronize();
+    for (auto &kv : g_scr)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    g_scr.clear();
+}
+
+// ---- elementwise kernels ----------------------------------------------------------------------------
+// y = x + coeff * x[n - D]   (src/torchfx/_csrc/cpu/delay_cpu.cpp:17-41)
+template <typename T>
+__global__ void __launch_bounds__(256)
+delay_line_kernel(const T *__restrict__ x, T *__restrict__ y, int64_t Tn, int64_t total, int64_t D, T coeff)
+{
+    int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; g < total; g += stride) {
+        const int64_t n = g % Tn;
+        T v = x[g];
+        if (n >= D) v += coeff * x[g - D];
+        y[g] = v;
+    }
+}
+
+constexpr int SUM_MAX = 16;
+struct SumArgs {
+    const void *p[SUM_MAX];
+    int n;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) sum_kernel(SumArgs a, T *__restrict__ y, int64_t total)
+{
+    int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; g < total; g += stride) {
+        T acc = (T)0;                    // zeros_like + in-place adds, in branch order (__base.py:1022-1026)
+        for (int i = 0; i < a.n; ++i) acc += ((const T *)a.p[i])[g];
+        y[g] = acc;
+    }
+}
+
+}  // namespace tfx
+
+using namespace tfx;
+
+#define TFX_API_BEGIN try {
+#define TFX_API_END                                                                           \
+    return 0;                                                                                 \
+    }                                                                                         \
+    catch (const std::exception &e) { set_last_error(e.what()); return 1; }                   \
+    catch (...) { set_last_error("unknown error"); return 2; }
+
+extern "C" {
+
+int tfx_version(void) { return 100; }
+const char *tfx_last_error(void) { return t_last_error.c_str(); }
+
+int tfx_device_info(char *name, int len, int *cus)
+{
+    TFX_API_BEGIN
+    int dev = 0;
+    TFX_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t pr;
+    TFX_HIP(hipGetDeviceProperties(&pr, dev));
+    if (name && len > 0) snprintf(name, (size_t)len, "%s", pr.gcnArchName);
+    if (cus) *cus = pr.multiProcessorCount;
+    TFX_API_END
+}
+
+int tfx_sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C, int64_t T,
+                    const double *sos_host, int64_t K, const double *state_x_in, const double *state_y_in,
+                    double *state_x_out, double *state_y_out, void *y_sections, int precision,
+                    tfx_stream_t stream)
+{
+    TFX_API_BEGIN
+    sos_forward(x, x_dtype, y, y_dtype, C, T, sos_host, K, state_x_in, state_y_in, state_x_out, state_y_out,
+                y_sections, precision, (hipStream_t)stream);
+    TFX_API_END
+}
+
+int tfx_sos_plan_info(const double *sos_host, int64_t K, int *precision, int64_t *warmup, double *err_bound)
+{
+    TFX_API_BEGIN
+    sos_plan_info(sos_host, K, precision, warmup, err_bound);
+    TFX_API_END
+}
+
+int tfx_biquad_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C, int64_t T,
+                       const double *b_host, double a1, double a2, const double *state_x_in,
+                       const double *state_y_in, double *state_x_out, double *state_y_out, int precision,
+                       tfx_stream_t stream)
+{
+    TFX_API_BEGIN
+    // a biquad is the K = 1 cascade; [C,2] states are the [1,C,2] layout
+    const double sos[6] = {b_host[0], b_host[1], b_host[2], 1.0, a1, a2};
+    sos_forward(x, x_dtype, y, y_dtype, C, T, sos, 1, state_x_in, state_y_in, state_x_out, state_y_out, nullptr,
+                precision, (hipStream_t)stream);
+    TFX_API_END
+}
+
+int tfx_fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, const void *kernel_host,
+                           int64_t K, tfx_stream_t stream)
+{
+    TFX_API_BEGIN
+    fir_direct_forward(x, y, dtype, C, T, kernel_host, K, (hipStream_t)stream);
+    TFX_API_END
+}
+
+int tfx_fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, const void *kernel_host,
+                         int64_t K, int64_t pad_left, int64_t pad_right, tfx_stream_t stream)
+{
+    TFX_API_BEGIN
+    fft_conv_forward(x, y, dtype, C, T, kernel_host, K, pad_left, pad_right, (hipStream_t)stream);
+    TFX_API_END
+}
+
+int tfx_delay_line_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, int64_t delay, double decay,
+                           double mix, tfx_stream_t stream)
+{
+    TFX_API_BEGIN
+    TFX_CHECK(dtype == TFX_F32 || dtype == TFX_F64, "delay_line_forward: bad dtype");
+    TFX_CHECK(delay >= 0, "delay_line_forward: negative delay");
+    const int64_t total = C * T;
+    if (total == 0) return 0;
+    const unsigned grid = (unsigned)(ceil_div(total, 256) < 8192 ? ceil_div(total, 256) : 8192);
+    ProfScope ps("delay_line_kernel", (hipStream_t)stream);
+    if (dtype == TFX_F32)
+        hipLaunchKernelGGL(delay_line_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float *)x,
+                           (float *)y, T, total, delay, (float)(mix * decay));
+    else
+        hipLaunchKernelGGL(delay_line_kernel<double>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           (const double *)x, (double *)y, T, total, delay, mix * decay);
+    TFX_HIP(hipGetLastError());
+    TFX_API_END
+}
+
+int tfx_sum_forward(const void *const *xs_host, int n, void *y, int dtype, int64_t numel, tfx_stream_t stream)
+{
+    TFX_API_BEGIN
+    TFX_CHECK(n >= 1 && n <= SUM_MAX, "sum_forward: between 1 and %d inputs", SUM_MAX);
+    TFX_CHECK(dtype == TFX_F32 || dtype == TFX_F64, "sum_forward: bad dtype");
+    if (numel == 0) return 0;
+    SumArgs a;
+    a.n = n;
+    for (int i = 0; i < n; ++i) a.p[i] = xs_host[i];
+    const unsigned grid = (unsigned)(ceil_div(numel, 256) < 8192 ? ceil_div(numel, 256) : 8192);
+    ProfScope ps("sum_kernel", (hipStream_t)stream);
+    if (dtype == TFX_F32)
+        hipLaunchKernelGGL(sum_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, (float *)y, numel);
+    else
+        hipLaunchKernelGGL(sum_kernel<double>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, (double *)y, numel);
+    TFX_HIP(hipGetLastError());
+    TFX_API_END
+}
+
+int tfx_prof_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return 0;
+}
+
+const char *tfx_prof_collect(void)
+{
+    static std::string out;
+    (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    std::map<std::string, std::pair<int, double>> agg;
+    std::vector<std::string> order;
+    for (auto &r : g_prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            if (!agg.count(r.name)) order.push_back(r.name);
+            agg[r.name].first += 1;
+            agg[r.name].second += ms;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    out = "{";
+    bool first = true;
+    for (auto &n : order) {
+        char b[256];
+        snprintf(b, sizeof(b), "%s\"%s\": {\"calls\": %d, \"total_ms\": %.6f}", first ? "" : ", ", n.c_str(),
+                 agg[n].first, agg[n].second);
+        out += b;
+        first = false;
+    }
+    out += "}";
+    return out.c_str();
+}
+
+int tfx_clear_caches(void)
+{
+    TFX_API_BEGIN
+    sos_clear_plans();
+    fir_clear();
+    fftconv_clear();
+    scratch_clear();
+    TFX_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// common.h -- shared host-side plumbing for libtorchfx_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+namespace tfx {
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+void set_last_error(const std::string &msg);
+
+#define TFX_CHECK(cond, ...)                                                        \
+    do {                                                                            \
+        if (!(cond)) {                                                              \
+            char _b[512];                                                           \
+            snprintf(_b, sizeof(_b), __VA_ARGS__);                                  \
+            throw ::tfx::Error(_b);                                                 \
+        }                                                                           \
+    } while (0)
+
+#define TFX_HIP(expr)                                                               \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) {                                                     \
+            char _b[512];                                                           \
+            snprintf(_b, sizeof(_b), "HIP error %s at %s:%d (%s)",                  \
+                     hipGetErrorString(_e), __FILE__, __LINE__, #expr);             \
+            throw ::tfx::Error(_b);                                                 \
+        }                                                                           \
+    } while (0)
+
+// ---- per-kernel timing (bench.py's roofline leg) --------------------------------
+// When enabled, prof_begin/prof_end bracket a launch with hipEvents on the launch
+// stream; collect() synchronises and aggregates by name.
+bool prof_on();
+void prof_begin(const char *name, hipStream_t s);
+void prof_end(hipStream_t s);
+
+struct ProfScope {
+    hipStream_t s;
+    bool on;
+    ProfScope(const char *name, hipStream_t st) : s(st), on(prof_on()) {
+        if (on) prof_begin(name, s);
+    }
+    ~ProfScope() {
+        if (on) prof_end(s);
+    }
+};
+
+// ---- stream-ordered device scratch ------------------------------------------------
+// A tiny cache of device buffers keyed by (tag); grown on demand, reused across calls
+// on the same stream order (callers use them only inside one call's stream work).
+void *scratch(const char *tag, size_t bytes);
+void scratch_clear();
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace tfx

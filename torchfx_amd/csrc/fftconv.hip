@@ -1,0 +1,301 @@
+// fftconv.hip -- overlap-save FFT convolution: rocFFT transforms + hand-written HIP
+// frame / spectrum / un-frame kernels.
+//
+// Replaces fft_conv1d (src/torchfx/filter/_fftconv.py:70-141) -- F.pad, unfold (as_strided),
+// torch.fft.rfft, `* kernel_z.conj()`, torch.fft.irfft, slice [:S], reshape, trim -- which in
+// the reference materialises four full-size temporaries and recomputes the kernel spectrum on
+// every call.  Same semantics (causal correlation with the stored flipped kernel, output length
+// T+l+r-K+1); different framing: the block is a power of two chosen for rocFFT on MI355X instead
+// of int(5*K), the kernel spectrum (pre-conjugated, pre-scaled by 1/N) is cached per filter, and
+// the frames are processed in channel slabs so the workspace stays bounded.
+//
+//   frame f of row c :  fr[i] = xp[c, f*S + i],  xp = x padded (l, r),   i < N,  S = N-K+1
+//   Z = rfft(fr) ;  Z *= conj(rfft(kf_pad)) / N ;  o = irfft(Z) ;  y[c, f*S + i] = o[i], i < S
+#include "common.h"
+#include "../../include/torchfx_hip.h"
+
+#include <rocfft/rocfft.h>
+
+#include <cstring>
+
+#include <map>
+#include <mutex>
+#include <vector>
+
+namespace tfx {
+
+#define TFX_ROCFFT(expr)                                                                     \
+    do {                                                                                     \
+        rocfft_status _s = (expr);                                                           \
+        TFX_CHECK(_s == rocfft_status_success, "rocFFT error %d at %s:%d (%s)", (int)_s,     \
+                  __FILE__, __LINE__, #expr);                                                \
+    } while (0)
+
+// ---- frame: zero-padded gather of overlapping blocks ---------------------------------------
+// one thread = 4 consecutive samples of one frame; N % 4 == 0
+template <typename T>
+__global__ void __launch_bounds__(256)
+ols_frame_kernel(const T *__restrict__ x, T *__restrict__ fr, int64_t Tn, int64_t c0, int64_t F,
+                 int64_t N, int64_t S, int64_t pad_left, int64_t total4)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total4) return;
+    const int64_t n4 = N / 4;
+    const int64_t b = g / n4;            // frame index within the slab
+    const int64_t i = (g - b * n4) * 4;
+    const int64_t c = c0 + b / F, f = b % F;
+    const int64_t m = f * S + i - pad_left;     // index into x[c, :]
+    const T *xr = x + c * Tn;
+    T v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int64_t mm = m + e;
+        v[e] = (mm >= 0 && mm < Tn) ? xr[mm] : (T)0;
+    }
+    T *dst = fr + b * N + i;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dst[e] = v[e];
+}
+
+// ---- spectrum multiply: Z[b,k] *= H[k]  (H already conjugated and scaled) -------------------
+template <typename T2>
+__global__ void __launch_bounds__(256)
+ols_cmul_kernel(T2 *__restrict__ z, const T2 *__restrict__ h, int64_t bins, int64_t total)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    const int64_t k = g % bins;
+    const T2 a = z[g], w = h[k];
+    T2 o;
+    o.x = a.x * w.x - a.y * w.y;
+    o.y = a.x * w.y + a.y * w.x;
+    z[g] = o;
+}
+
+// ---- un-frame: keep the first S samples of every block ---------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+ols_unframe_kernel(const T *__restrict__ fr, T *__restrict__ y, int64_t Tout, int64_t c0, int64_t F,
+                   int64_t N, int64_t S, int64_t total)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;                      // total = nb * S
+    const int64_t b = g / S, i = g - b * S;
+    const int64_t c = c0 + b / F, f = b % F;
+    const int64_t n = f * S + i;
+    if (n < Tout) y[c * Tout + n] = fr[b * N + i];
+}
+
+// ---- plans -------------------------------------------------------------------------------------
+struct FftKey {
+    int dtype;
+    int64_t N, batch;
+    bool operator<(const FftKey &o) const
+    {
+        if (dtype != o.dtype) return dtype < o.dtype;
+        if (N != o.N) return N < o.N;
+        return batch < o.batch;
+    }
+};
+struct FftPlan {
+    rocfft_plan fwd = nullptr, inv = nullptr;
+    size_t work_bytes = 0;
+};
+struct SpecKey {
+    int dtype;
+    int64_t N;
+    std::vector<char> taps;
+    bool operator<(const SpecKey &o) const
+    {
+        if (dtype != o.dtype) return dtype < o.dtype;
+        if (N != o.N) return N < o.N;
+        return taps < o.taps;
+    }
+};
+
+static std::mutex g_fft_mu;
+static bool g_rocfft_up = false;
+static std::map<FftKey, FftPlan> g_fft_plans;
+static std::map<SpecKey, void *> g_specs;
+
+static FftPlan &get_fft_plan(int dtype, int64_t N, int64_t batch)
+{
+    if (!g_rocfft_up) {
+        TFX_ROCFFT(rocfft_setup());
+        g_rocfft_up = true;
+    }
+    FftKey key{dtype, N, batch};
+    auto it = g_fft_plans.find(key);
+    if (it != g_fft_plans.end()) return it->second;
+    FftPlan pl;
+    const size_t len[1] = {(size_t)N};
+    const rocfft_precision pr = dtype == TFX_F32 ? rocfft_precision_single : rocfft_precision_double;
+    TFX_ROCFFT(rocfft_plan_create(&pl.fwd, rocfft_placement_notinplace, rocfft_transform_type_real_forward,
+                                  pr, 1, len, (size_t)batch, nullptr));
+    TFX_ROCFFT(rocfft_plan_create(&pl.inv, rocfft_placement_notinplace, rocfft_transform_type_real_inverse,
+                                  pr, 1, len, (size_t)batch, nullptr));
+    size_t w1 = 0, w2 = 0;
+    TFX_ROCFFT(rocfft_plan_get_work_buffer_size(pl.fwd, &w1));
+    TFX_ROCFFT(rocfft_plan_get_work_buffer_size(pl.inv, &w2));
+    pl.work_bytes = w1 > w2 ? w1 : w2;
+    return g_fft_plans.emplace(key, pl).first->second;
+}
+
+static void exec_fft(rocfft_plan plan, void *in, void *out, void *work, size_t work_bytes, hipStream_t stream)
+{
+    rocfft_execution_info info = nullptr;
+    TFX_ROCFFT(rocfft_execution_info_create(&info));
+    TFX_ROCFFT(rocfft_execution_info_set_stream(info, stream));
+    if (work_bytes) TFX_ROCFFT(rocfft_execution_info_set_work_buffer(info, work, work_bytes));
+    void *ib[1] = {in}, *ob[1] = {out};
+    rocfft_status st = rocfft_execute(plan, ib, ob, info);
+    rocfft_execution_info_destroy(info);
+    TFX_CHECK(st == rocfft_status_success, "rocfft_execute failed (%d)", (int)st);
+}
+
+template <typename T, typename T2>
+static void *get_spectrum(int dtype, const void *kernel_host, int64_t K, int64_t N, hipStream_t stream)
+{
+    SpecKey key{dtype, N, std::vector<char>((const char *)kernel_host, (const char *)kernel_host + K * sizeof(T))};
+    auto it = g_specs.find(key);
+    if (it != g_specs.end()) return it->second;
+    if (g_specs.size() > 64) {
+        for (auto &kv : g_specs) (void)hipFree(kv.second);
+        g_specs.clear();
+    }
+    // one-time per (filter, N): pad taps, forward transform, conjugate + scale.  Blocking.
+    const int64_t bins = N / 2 + 1;
+    std::vector<T> hp((size_t)N, (T)0);
+    memcpy(hp.data(), kernel_host, (size_t)K * sizeof(T));
+    T *dpad = nullptr;
+    T2 *dspec = nullptr;
+    TFX_HIP(hipMalloc((void **)&dpad, (size_t)N * sizeof(T)));
+    TFX_HIP(hipMalloc((void **)&dspec, (size_t)bins * sizeof(T2)));
+    TFX_HIP(hipMemcpy(dpad, hp.data(), (size_t)N * sizeof(T), hipMemcpyHostToDevice));
+    FftPlan &p1 = get_fft_plan(dtype, N, 1);
+    void *work = nullptr;
+    if (p1.work_bytes) TFX_HIP(hipMalloc(&work, p1.work_bytes));
+    exec_fft(p1.fwd, dpad, dspec, work, p1.work_bytes, stream);
+    TFX_HIP(hipStreamSynchronize(stream));
+    std::vector<T2> hs((size_t)bins);
+    TFX_HIP(hipMemcpy(hs.data(), dspec, (size_t)bins * sizeof(T2), hipMemcpyDeviceToHost));
+    const T sc = (T)1 / (T)N;
+    for (auto &v : hs) { v.x = v.x * sc; v.y = -v.y * sc; }        // conj(.)/N  (_fftconv.py:131)
+    TFX_HIP(hipMemcpy(dspec, hs.data(), (size_t)bins * sizeof(T2), hipMemcpyHostToDevice));
+    (void)hipFree(dpad);
+    if (work) (void)hipFree(work);
+    g_specs[key] = dspec;
+    return dspec;
+}
+
+void fftconv_clear()
+{
+    std::lock_guard<std::mutex> lk(g_fft_mu);
+    for (auto &kv : g_specs) (void)hipFree(kv.second);
+    g_specs.clear();
+    for (auto &kv : g_fft_plans) {
+        if (kv.second.fwd) rocfft_plan_destroy(kv.second.fwd);
+        if (kv.second.inv) rocfft_plan_destroy(kv.second.inv);
+    }
+    g_fft_plans.clear();
+}
+
+static int64_t env_i64(const char *name, int64_t dflt)
+{
+    const char *e = getenv(name);
+    return (e && *e) ? atoll(e) : dflt;
+}
+
+int64_t fftconv_block_size(int64_t K, int64_t L)
+{
+    // power of two >= 4K (>= 75 % of each block is valid output), at least 4096, but no larger
+    // than needed for the whole (padded) signal in one block
+    int64_t n = 4096;
+    while (n < 4 * K) n <<= 1;
+    const int64_t lg = env_i64("TFX_FFT_LOG2N", 0);
+    if (lg > 0) { n = (int64_t)1 << lg; while (n < 2 * K) n <<= 1; }
+    int64_t cap = 8;
+    while (cap < L) cap <<= 1;            // one block covers everything
+    if (n > cap) n = cap;
+    while (n < K) n <<= 1;
+    return n;
+}
+
+template <typename T, typename T2>
+static void fft_conv_typed(const T *x, T *y, int dtype, int64_t C, int64_t Tn, const void *kernel_host,
+                           int64_t K, int64_t pl, int64_t pr, hipStream_t stream)
+{
+    const int64_t L = Tn + pl + pr;
+    const int64_t Tout = L - K + 1;
+    const int64_t N = fftconv_block_size(K, L);
+    const int64_t S = N - K + 1;
+    const int64_t F = ceil_div(Tout, S);
+    const int64_t bins = N / 2 + 1;
+
+    std::lock_guard<std::mutex> lk(g_fft_mu);
+    const T2 *H = (const T2 *)get_spectrum<T, T2>(dtype, kernel_host, K, N, stream);
+
+    // channel slab so that frames + spectra stay within the workspace budget
+    const int64_t ws_mb = env_i64("TFX_FFT_WS_MB", 2048);
+    const int64_t per_ch = F * (N * (int64_t)sizeof(T) + bins * (int64_t)sizeof(T2));
+    int64_t cps = (ws_mb << 20) / per_ch;
+    if (cps < 1) cps = 1;
+    if (cps > C) cps = C;
+
+    T *fr = (T *)scratch(dtype == TFX_F32 ? "ols_frames32" : "ols_frames64", (size_t)(cps * F * N) * sizeof(T));
+    T2 *zs = (T2 *)scratch(dtype == TFX_F32 ? "ols_spec32" : "ols_spec64", (size_t)(cps * F * bins) * sizeof(T2));
+
+    for (int64_t c0 = 0; c0 < C; c0 += cps) {
+        const int64_t nc = (C - c0 < cps) ? (C - c0) : cps;
+        const int64_t nb = nc * F;
+        FftPlan &plan = get_fft_plan(dtype, N, nb);
+        void *work = plan.work_bytes ? scratch("ols_work", plan.work_bytes) : nullptr;
+        {
+            const int64_t total4 = nb * (N / 4);
+            ProfScope ps("ols_frame_kernel", stream);
+            hipLaunchKernelGGL(ols_frame_kernel<T>, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, stream,
+                               x, fr, Tn, c0, F, N, S, pl, total4);
+            TFX_HIP(hipGetLastError());
+        }
+        {
+            ProfScope ps("rocfft_r2c", stream);
+            exec_fft(plan.fwd, fr, zs, work, plan.work_bytes, stream);
+        }
+        {
+            const int64_t total = nb * bins;
+            ProfScope ps("ols_cmul_kernel", stream);
+            hipLaunchKernelGGL(ols_cmul_kernel<T2>, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream,
+                               zs, H, bins, total);
+            TFX_HIP(hipGetLastError());
+        }
+        {
+            ProfScope ps("rocfft_c2r", stream);
+            exec_fft(plan.inv, zs, fr, work, plan.work_bytes, stream);
+        }
+        {
+            const int64_t total = nb * S;
+            ProfScope ps("ols_unframe_kernel", stream);
+            hipLaunchKernelGGL(ols_unframe_kernel<T>, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream,
+                               fr, y, Tout, c0, F, N, S, total);
+            TFX_HIP(hipGetLastError());
+        }
+    }
+}
+
+void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, const void *kernel_host,
+                      int64_t K, int64_t pad_left, int64_t pad_right, hipStream_t stream)
+{
+    TFX_CHECK(dtype == TFX_F32 || dtype == TFX_F64, "fft_conv_forward: bad dtype %d", dtype);
+    TFX_CHECK(K >= 1 && pad_left >= 0 && pad_right >= 0, "fft_conv_forward: bad sizes");
+    const int64_t L = T + pad_left + pad_right;
+    // same condition and wording as _fftconv.py:111-115
+    TFX_CHECK(L >= K, "Input should be at least as large as the kernel size %lld, but it is only %lld samples long.",
+              (long long)K, (long long)L);
+    if (C == 0) return;
+    if (dtype == TFX_F32)
+        fft_conv_typed<float, float2>((const float *)x, (float *)y, dtype, C, T, kernel_host, K, pad_left, pad_right, stream);
+    else
+        fft_conv_typed<double, double2>((const double *)x, (double *)y, dtype, C, T, kernel_host, K, pad_left, pad_right, stream);
+}
+
+}  // namespace tfx

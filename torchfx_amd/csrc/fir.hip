@@ -1,0 +1,215 @@
+// fir.hip -- direct-form causal depthwise FIR for gfx950.
+//
+// Replaces the conv_mode="direct" branch of FIR.forward (src/torchfx/filter/fir.py:556-568:
+// F.pad(x,(K-1,0)) + F.conv1d(groups=C) with one shared flipped kernel):
+//     y[c,n] = sum_{t<K} kf[t] * xp[c, n+t],   xp[m] = x[m-(K-1)]  (zero for m < K-1)
+//
+// float32: 2K flop/sample (2048 at K=1024) makes this FP32-rate bound, not HBM bound.  gfx950 has
+// an exact-f32 matrix instruction, v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain, same peak as
+// the vector ALU but one instruction per 4096 flop), so the convolution is phrased as a
+// Toeplitz product on the matrix pipe -- NOT to "reach MFMA" with reduced precision, the
+// arithmetic is plain f32 FMA:
+//     out(i,j) = y[nb + 32 i + j] = sum_s  A[i][s] * B[s][j]
+//     A[i][s] = xw[32 i + s]          (signal window, LDS, rows padded 32->33 floats)
+//     B[s][j] = kpad[s - j + 31]      (taps, Toeplitz, LDS, 31 zeros in front)
+// Each wave owns NJ = 4 output tiles of 32x32 = 1024 consecutive samples and re-uses every B
+// fragment across them; a workgroup (4 waves) covers 16384 outputs of one channel per pass and
+// walks the taps in chunks of <= 1024 so the LDS window stays bounded for any K.
+//
+// float64 signals (the reference computes conv1d in the input dtype) use a plain LDS-tiled
+// vector kernel: rare path, correctness first.
+#include "common.h"
+#include "../../include/torchfx_hip.h"
+
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+namespace tfx {
+
+// device copies of tap vectors, keyed by content: uploaded (blocking) the first time a filter
+// is seen, then reused -- no host sync on the steady-state path.
+static std::mutex g_taps_mu;
+static std::map<std::vector<char>, void *> g_taps;
+static const void *cached_taps(const void *host, size_t bytes, size_t padded)
+{
+    std::vector<char> key((const char *)host, (const char *)host + bytes);
+    key.push_back((char)(padded & 0xff));
+    std::lock_guard<std::mutex> lk(g_taps_mu);
+    auto it = g_taps.find(key);
+    if (it != g_taps.end()) return it->second;
+    if (g_taps.size() > 128) {
+        (void)hipDeviceSynchronize();
+        for (auto &kv : g_taps) (void)hipFree(kv.second);
+        g_taps.clear();
+    }
+    std::vector<char> h(padded, 0);
+    memcpy(h.data(), host, bytes);
+    void *d = nullptr;
+    TFX_HIP(hipMalloc(&d, padded));
+    TFX_HIP(hipMemcpy(d, h.data(), padded, hipMemcpyHostToDevice));
+    g_taps[key] = d;
+    return d;
+}
+void fir_clear()
+{
+    std::lock_guard<std::mutex> lk(g_taps_mu);
+    (void)hipDeviceSynchronize();
+    for (auto &kv : g_taps) (void)hipFree(kv.second);
+    g_taps.clear();
+}
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int FIR_NJ = 4;                       // 32x32 tiles per wave
+constexpr int FIR_WOUT = FIR_NJ * 1024;         // outputs per wave
+constexpr int FIR_NOUT = 4 * FIR_WOUT;          // outputs per workgroup
+constexpr int FIR_KC = 1024;                    // tap chunk
+
+__device__ __forceinline__ int xpad33(int m) { return m + (m >> 5); }
+
+// kf_dev: [Kpad] flipped taps on device, zero-padded to a multiple of FIR_KC
+__global__ void __launch_bounds__(256, 2)
+fir_direct_mfma_kernel(const float *__restrict__ x, float *__restrict__ y,
+                       const float *__restrict__ kf_dev, int64_t C, int64_t T, int K, int nchunks,
+                       int64_t tiles_per_row)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int XW = FIR_NOUT + FIR_KC + 32;              // window length (floats)
+    constexpr int XW_PAD = XW + (XW >> 5) + 1;
+    float *xw = (float *)smem;                              // [XW_PAD]
+    float *kp = xw + ((XW_PAD + 3) & ~3);                   // [31 + FIR_KC + 33]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t c = blockIdx.x / tiles_per_row;
+    const int64_t n0 = (blockIdx.x % tiles_per_row) * (int64_t)FIR_NOUT;
+    const float *xrow = x + c * T;
+    float *yrow = y + c * T;
+
+    floatx16 acc[FIR_NJ];
+#pragma unroll
+    for (int t = 0; t < FIR_NJ; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    const int li = lane & 31, kk = lane >> 5;
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int t0 = ch * FIR_KC;
+        __syncthreads();    // previous chunk's readers are done
+        // window: xw[m] = xp[n0 + t0 + m] = x[n0 + t0 + m - (K-1)]
+        const int64_t base = n0 + t0 - (int64_t)(K - 1);
+        for (int m = tid; m < XW; m += 256) {
+            const int64_t g = base + m;
+            xw[xpad33(m)] = (g >= 0 && g < T) ? xrow[g] : 0.0f;
+        }
+        // taps: kp[u + 31] = kf[t0 + u] for u in [0,KC), zeros elsewhere
+        for (int u = tid; u < 31 + FIR_KC + 33; u += 256) {
+            const int v = u - 31;
+            kp[u] = (v >= 0 && v < FIR_KC) ? kf_dev[t0 + v] : 0.0f;   // kf_dev is zero-padded
+        }
+        __syncthreads();
+
+        // contraction over s in [0, KC+32): step q covers s = 2q + kk
+        const int xb = wave * FIR_WOUT;
+#pragma unroll 4
+        for (int q = 0; q < (FIR_KC + 32) / 2; ++q) {
+            const int s = 2 * q + kk;
+            const float b = kp[s - li + 31];
+#pragma unroll
+            for (int t = 0; t < FIR_NJ; ++t) {
+                const float a = xw[xpad33(xb + t * 1024 + 32 * li + s)];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // D layout: lane holds column j = lane&31, rows i = 8*(r/4) + 4*(lane>>5) + (r&3)
+#pragma unroll
+    for (int t = 0; t < FIR_NJ; ++t) {
+        const int64_t nb = n0 + wave * FIR_WOUT + t * 1024;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = 8 * (r >> 2) + 4 * kk + (r & 3);
+            const int64_t n = nb + 32 * i + li;
+            if (n < T) yrow[n] = acc[t][r];
+        }
+    }
+}
+
+// generic (float64, or any dtype) LDS-tiled vector kernel: 256 threads x 4 outputs
+template <typename T>
+__global__ void __launch_bounds__(256)
+fir_direct_simple_kernel(const T *__restrict__ x, T *__restrict__ y, const T *__restrict__ kf_dev,
+                         int64_t C, int64_t Tn, int K, int64_t tiles_per_row)
+{
+    constexpr int NO = 1024, KC = 512;
+    __shared__ T xw[NO + KC];
+    __shared__ T kp[KC];
+    const int tid = threadIdx.x;
+    const int64_t c = blockIdx.x / tiles_per_row;
+    const int64_t n0 = (blockIdx.x % tiles_per_row) * (int64_t)NO;
+    const T *xrow = x + c * Tn;
+    T acc[4] = {0, 0, 0, 0};
+    for (int t0 = 0; t0 < K; t0 += KC) {
+        __syncthreads();
+        const int64_t base = n0 + t0 - (int64_t)(K - 1);
+        for (int m = tid; m < NO + KC; m += 256) {
+            const int64_t g = base + m;
+            xw[m] = (g >= 0 && g < Tn) ? xrow[g] : (T)0;
+        }
+        for (int u = tid; u < KC; u += 256) kp[u] = (t0 + u < K) ? kf_dev[t0 + u] : (T)0;
+        __syncthreads();
+        const int kc = (K - t0 < KC) ? (K - t0) : KC;
+        for (int u = 0; u < kc; ++u) {
+            const T k = kp[u];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = fma(k, xw[tid + 256 * r + u], acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t n = n0 + tid + 256 * r;
+        if (n < Tn) y[c * Tn + n] = acc[r];
+    }
+}
+
+void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
+                        const void *kernel_host, int64_t K, hipStream_t stream)
+{
+    TFX_CHECK(dtype == TFX_F32 || dtype == TFX_F64, "fir_direct_forward: bad dtype %d", dtype);
+    TFX_CHECK(K >= 1, "fir_direct_forward: empty kernel");
+    TFX_CHECK(K < (1 << 30), "fir_direct_forward: kernel too long");
+    if (C == 0 || T == 0) return;
+    const size_t esz = dtype == TFX_F32 ? 4 : 8;
+    const int64_t Kpad = ceil_div(K, FIR_KC) * FIR_KC;
+    const void *kdev = cached_taps(kernel_host, (size_t)K * esz, (size_t)Kpad * esz);
+    if (dtype == TFX_F32) {
+        const int64_t tiles = ceil_div(T, FIR_NOUT);
+        TFX_CHECK(C * tiles < (1ll << 31), "fir_direct_forward: grid too large");
+        constexpr int XW = FIR_NOUT + FIR_KC + 32;
+        constexpr int XW_PAD = XW + (XW >> 5) + 1;
+        const size_t shmem = (((XW_PAD + 3) & ~3) + 31 + FIR_KC + 33) * sizeof(float);
+        static bool attr_done = false;
+        if (!attr_done) {
+            TFX_HIP(hipFuncSetAttribute((const void *)fir_direct_mfma_kernel,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            attr_done = true;
+        }
+        ProfScope ps("fir_direct_mfma_kernel", stream);
+        hipLaunchKernelGGL(fir_direct_mfma_kernel, dim3((unsigned)(C * tiles)), dim3(256), shmem, stream,
+                           (const float *)x, (float *)y, (const float *)kdev, C, T, (int)K,
+                           (int)(Kpad / FIR_KC), tiles);
+        TFX_HIP(hipGetLastError());
+    } else {
+        const int64_t tiles = ceil_div(T, 1024);
+        TFX_CHECK(C * tiles < (1ll << 31), "fir_direct_forward: grid too large");
+        ProfScope ps("fir_direct_simple_kernel<f64>", stream);
+        hipLaunchKernelGGL(fir_direct_simple_kernel<double>, dim3((unsigned)(C * tiles)), dim3(256), 0, stream,
+                           (const double *)x, (double *)y, (const double *)kdev, C, T, (int)K, tiles);
+        TFX_HIP(hipGetLastError());
+    }
+}
+
+}  // namespace tfx

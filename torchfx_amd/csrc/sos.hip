@@ -1,0 +1,736 @@
+// sos.hip -- fused K-section DF1 SOS cascade for gfx950 (MI355X).
+//
+// Replaces the reference's CPU loop (src/torchfx/_csrc/cpu/iir_cpu.cpp:64-159) and its
+// CUDA path (cuda/biquad_forward.cu:49-92 + cuda/parallel_scan.cu: one forcing kernel and a
+// 3-phase Blelloch scan PER SECTION, ~40 B/sample/section of HBM traffic) with ONE launch that
+// reads x once and writes y once (8 B/sample for f32 I/O).  Not a port of either.
+//
+// Decomposition (DESIGN.md "IIR kernel"):
+//   * a STREAM = (channel, time segment) is owned by one 64-lane wavefront; a workgroup is four
+//     independent streams (no __syncthreads anywhere).  Segments other than the first start
+//     `warm` samples early from zero state; `warm` is chosen on the host so that the cascade's
+//     zero-input transition matrix A^warm is below 2^-60, i.e. the halo reproduces the true
+//     state to float64 round-off.  Filters whose memory is too long get nseg = 1 (exact,
+//     sequential tiles per channel).
+//   * a TILE = 64 lanes x LC consecutive samples.  Coalesced 16-byte global loads are
+//     transposed through a padded (bank-conflict-free) LDS stage so that lane j owns samples
+//     [j*LC, (j+1)*LC) in registers.  The next tile's loads are issued before computing.
+//   * per section, entirely in registers:  (1) each lane runs the DF1 recurrence over its LC
+//     samples from zero state (lane 0: from the carried true state);  (2) the 2-vector end
+//     states are combined across lanes by a Kogge-Stone scan with the constant 2x2 matrices
+//     C^(LC*2^k) (host-computed in long double);  (3) each lane adds the homogeneous response
+//     g[n] * (state at its chunk start).  Section s+1 then consumes the exact output of s.
+//   * arithmetic type TC is float64 by default -- the reference computes in float64
+//     (_ops.py:149) -- or float32 (TFX_PREC_F32).
+#include "common.h"
+#include "../../include/torchfx_hip.h"
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+namespace tfx {
+
+// ------------------------------------------------------------------------------------------
+// Table layout per section (TC elements):
+//   [0..4]  b0 b1 b2 -a1 -a2      [5..7] pad
+//   [8 + 4k + {0..3}]             Cmp^(LC * 2^k) row-major, k < 6   (Cmp = [[-a1,-a2],[1,0]])
+// ------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int tab_stride(int) { return 8 + 24; }
+
+struct SosParams {
+    const void *x;
+    void *y;
+    void *taps;          // optional [K,C,T] of TOut
+    const void *tab;     // device table, TC
+    const double *sx_in, *sy_in;
+    double *sx_out, *sy_out;
+    int64_t C, T;
+    int64_t seg_len;     // multiple of 4 (VEC alignment)
+    int64_t warm;        // multiple of 4
+    int K, nseg, nsteps;
+};
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename T> struct U16 {               // 16 bytes of T
+    static constexpr int N = 16 / sizeof(T);
+    union { uint4 u; T e[N]; };
+};
+
+// LC   samples per lane per tile          VEC  16-byte global accesses (aligned rows)
+// TAPS also store every section's output  PF   keep the next tile's loads in flight in registers
+// MINW waves per SIMD the register allocator must leave room for
+template <typename TIn, typename TOut, typename TC, int LC, bool VEC, bool TAPS, bool PF, int MINW>
+__global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int IOB = sizeof(TIn) > sizeof(TOut) ? sizeof(TIn) : sizeof(TOut);
+    constexpr int CHUNK_B = LC * IOB + 16;   // per-lane chunk, padded: conflict-free b128 access
+    constexpr int STAGE_B = 64 * CHUNK_B;
+    constexpr int TILE = 64 * LC;
+    constexpr int TS = tab_stride(LC);
+#ifndef TFX_SB
+#define TFX_SB 4
+#endif
+    constexpr int SB = TFX_SB;          // scheduling-barrier period (samples)
+    constexpr int EI = 16 / sizeof(TIn), NUI = LC / EI;   // elems per 16 B, units per lane (in)
+    constexpr int EO = 16 / sizeof(TOut), NUO = LC / EO;  // (out)
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int K = p.K;
+    const int64_t sid = (int64_t)blockIdx.x * 4 + wave;
+    if (sid >= p.C * p.nseg) return;                       // wave-uniform
+    const int64_t c = sid / p.nseg;
+    const int g = (int)(sid - c * p.nseg);
+    const int carry_b = (((K * 4 + 2 * LC) * (int)sizeof(TC)) + 15) & ~15;
+    char *stage = smem + wave * (STAGE_B + carry_b);
+    TC *carry = (TC *)(stage + STAGE_B);                   // [K][4] = vin1 vin2 y1 y2
+    TC *cap = carry + K * 4;                               // [2][LC] final-state capture scratch
+
+    const int64_t T = p.T;
+    const TIn *__restrict__ xrow = (const TIn *)p.x + c * T;
+    TOut *__restrict__ yrow = (TOut *)p.y + c * T;
+    // Coefficient tables live in the CONSTANT address space: wave-uniform indices then lower to
+    // s_load (scalar cache, SGPR operands) instead of per-lane vector loads.
+    typedef const TC __attribute__((address_space(4))) *ctab_t;
+    const ctab_t tab = (ctab_t)(uintptr_t)p.tab;
+
+    const int64_t out_begin = (int64_t)g * p.seg_len;
+    if (out_begin >= T) return;
+    int64_t out_end = out_begin + p.seg_len;
+    if (out_end > T) out_end = T;
+    int64_t start = out_begin - p.warm;
+    if (start < 0) start = 0;
+    const bool last_seg = (out_end == T);
+
+    // ---- initial carry: the caller's state for the stream that starts at n = 0, zeros for a
+    //      warm-up start.  Layout of state tensors: [K, C, 2] (iir_cpu.cpp:125-130).
+    for (int i = lane; i < K * 4; i += 64) {
+        const int s = i >> 2, f = i & 3;
+        TC v = (TC)0;
+        if (start == 0) {
+            const double *src = (f < 2) ? p.sx_in : p.sy_in;
+            if (src) v = (TC)src[((int64_t)s * p.C + c) * 2 + (f & 1)];
+        }
+        carry[i] = v;
+    }
+    wave_sync();
+
+    // ---- global -> registers (coalesced).  Per-lane pointer + immediate offsets; the common
+    //      full-tile case is branch-free, a partial tile (signal tail) is predicated.
+    uint4 rawv[VEC ? NUI : 1];
+    TIn raws[VEC ? 1 : LC];
+    auto load_tile = [&](int64_t ts) {
+        const int64_t left = T - ts;
+        if constexpr (VEC) {
+            const uint4 *__restrict__ xl = (const uint4 *)(xrow + ts) + lane;
+            if (left >= TILE) {
+#pragma unroll
+                for (int i = 0; i < NUI; ++i) rawv[i] = xl[i * 64];
+            } else {
+                const int nv = (int)(left / EI);   // valid 16-byte units
+#pragma unroll
+                for (int i = 0; i < NUI; ++i)
+                    rawv[i] = (i * 64 + lane < nv) ? xl[i * 64] : make_uint4(0, 0, 0, 0);
+            }
+        } else {
+            const TIn *__restrict__ xl = xrow + ts + lane;
+            if (left >= TILE) {
+#pragma unroll
+                for (int i = 0; i < LC; ++i) raws[i] = xl[i * 64];
+            } else {
+                const int nv = (int)left;
+#pragma unroll
+                for (int i = 0; i < LC; ++i) raws[i] = (i * 64 + lane < nv) ? xl[i * 64] : (TIn)0;
+            }
+        }
+    };
+    // LDS stage addresses: unit q = i*64 + lane lives at chunk q/NU, slot q%NU; 64 % NU == 0
+    char *const st_in_v = stage + (lane / NUI) * CHUNK_B + (lane % NUI) * 16;
+    char *const st_out_v = stage + (lane / NUO) * CHUNK_B + (lane % NUO) * 16;
+    char *const st_in_s = stage + (lane / LC) * CHUNK_B + (lane % LC) * (int)sizeof(TIn);     // LC | 64
+    char *const st_out_s = stage + (lane / LC) * CHUNK_B + (lane % LC) * (int)sizeof(TOut);
+    char *const st_own = stage + lane * CHUNK_B;
+
+    if constexpr (PF) load_tile(start);
+
+    for (int64_t ts = start; ts < out_end; ts += TILE) {
+        TC d[LC];
+        if constexpr (!PF) load_tile(ts);
+        // ---- stage: coalesced order -> LDS -> blocked (lane j owns [j*LC,(j+1)*LC))
+        if constexpr (VEC) {
+#pragma unroll
+            for (int i = 0; i < NUI; ++i) *(uint4 *)(st_in_v + i * (64 / NUI) * CHUNK_B) = rawv[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < LC; ++i) *(TIn *)(st_in_s + i * (64 / LC) * CHUNK_B) = raws[i];
+        }
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < NUI; ++i) {
+            U16<TIn> v;
+            v.u = *(const uint4 *)(st_own + i * 16);
+#pragma unroll
+            for (int e = 0; e < EI; ++e) d[i * EI + e] = (TC)v.e[e];
+        }
+        wave_sync();
+
+        // ---- prefetch the next tile while this one is computed
+        if constexpr (PF) { if (ts + TILE < out_end) load_tile(ts + TILE); }
+
+        const bool final_tile = last_seg && (ts + TILE >= T);
+        const int r = (int)(T - ts);   // valid samples in the final tile (1..TILE)
+
+        for (int s = 0; s < K; ++s) {
+            const ctab_t tb = tab + s * TS;
+            const TC b0 = tb[0], b1 = tb[1], b2 = tb[2], na1 = tb[3], na2 = tb[4];
+            const TC cv1 = carry[s * 4 + 0], cv2 = carry[s * 4 + 1];
+            const TC cy1 = carry[s * 4 + 2], cy2 = carry[s * 4 + 3];
+
+            // final tile only: read the section's sequence at tile-local index idx (-1/-2 = the
+            // carried history) through a 2 x LC scratch in LDS
+            auto capture2 = [&](int i1, int i2, TC h1, TC h2, TC &o1, TC &o2) {
+                const int w1 = i1 >= 0 ? i1 / LC : -1, w2 = i2 >= 0 ? i2 / LC : -1;
+                if (lane == w1) {
+#pragma unroll
+                    for (int n = 0; n < LC; ++n) cap[n] = d[n];
+                }
+                if (lane == w2) {
+#pragma unroll
+                    for (int n = 0; n < LC; ++n) cap[LC + n] = d[n];
+                }
+                wave_sync();
+                o1 = i1 >= 0 ? cap[i1 - w1 * LC] : (i1 == -1 ? h1 : h2);
+                o2 = i2 >= 0 ? cap[LC + i2 - w2 * LC] : (i2 == -1 ? h1 : h2);
+                wave_sync();
+            };
+
+            // input history of this lane's chunk: previous lane's last two inputs
+            TC pv1 = __shfl_up(d[LC - 1], 1);
+            TC pv2 = __shfl_up(d[LC - 2], 1);
+            if (lane == 0) { pv1 = cv1; pv2 = cv2; }
+            TC sx1 = (TC)0, sx2 = (TC)0;
+            if (final_tile) capture2(r - 1, r - 2, cv1, cv2, sx1, sx2);
+            if (lane == 63) { carry[s * 4 + 0] = d[LC - 1]; carry[s * 4 + 1] = d[LC - 2]; }
+
+            // (1) zero-state response of this chunk (lane 0 starts from the true state)
+            TC u1 = (lane == 0) ? cy1 : (TC)0;
+            TC u2 = (lane == 0) ? cy2 : (TC)0;
+#pragma unroll
+            for (int n = 0; n < LC; ++n) {
+                const TC v = d[n];
+                TC f = b0 * v;
+                f = fma(b1, pv1, f);
+                f = fma(b2, pv2, f);
+                const TC t = fma(na2, u2, f);
+                const TC u = fma(na1, u1, t);
+                d[n] = u;
+                pv2 = pv1; pv1 = v;
+                u2 = u1;   u1 = u;
+                // keep the update in place: stop the scheduler hoisting all LC feed-forward parts
+                // ahead of the recurrence (that doubles the live registers)
+                if ((n & (SB - 1)) == SB - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+
+            // (2) inclusive scan of chunk end-states over lanes:  S_j = sum_i P^(j-i) z_i
+            TC s0 = u1, s1 = u2;
+            const ctab_t pm = tb + 8;
+            for (int k = 0; k < p.nsteps; ++k) {
+                const int dd = 1 << k;
+                const TC t0 = __shfl_up(s0, dd);
+                const TC t1 = __shfl_up(s1, dd);
+                const TC a0 = fma(pm[4 * k + 0], t0, pm[4 * k + 1] * t1);
+                const TC a1 = fma(pm[4 * k + 2], t0, pm[4 * k + 3] * t1);
+                if (lane >= dd) { s0 += a0; s1 += a1; }
+            }
+            TC h1 = __shfl_up(s0, 1), h2 = __shfl_up(s1, 1);
+            if (lane == 0) { h1 = (TC)0; h2 = (TC)0; }
+
+            // (3) add the homogeneous response of the true chunk-start state (h1,h2) =
+            //     (y[-1], y[-2]): h[n] = -a1 h[n-1] - a2 h[n-2], run as a recurrence (no table)
+#pragma unroll
+            for (int n = 0; n < LC; ++n) {
+                const TC h = fma(na1, h1, na2 * h2);
+                d[n] += h;
+                h2 = h1; h1 = h;
+                if ((n & (SB - 1)) == SB - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+
+            if (lane == 63) { carry[s * 4 + 2] = d[LC - 1]; carry[s * 4 + 3] = d[LC - 2]; }
+
+            if (final_tile) {
+                TC sy1, sy2;
+                capture2(r - 1, r - 2, cy1, cy2, sy1, sy2);
+                if (lane == 0) {
+                    const int64_t o = ((int64_t)s * p.C + c) * 2;
+                    if (p.sx_out) { p.sx_out[o] = (double)sx1; p.sx_out[o + 1] = (double)sx2; }
+                    if (p.sy_out) { p.sy_out[o] = (double)sy1; p.sy_out[o + 1] = (double)sy2; }
+                }
+            }
+            if constexpr (TAPS) {   // debug / section-by-section parity only
+                TOut *trow = (TOut *)p.taps + ((int64_t)s * p.C + c) * T + ts;
+                const int64_t lo64 = out_begin - ts, hi64 = out_end - ts;
+                const int lo = lo64 > 0 ? (int)lo64 : 0, hi = hi64 < TILE ? (int)hi64 : TILE;
+#pragma unroll
+                for (int n = 0; n < LC; ++n) {
+                    const int rel = lane * LC + n;
+                    if (rel >= lo && rel < hi) trow[rel] = (TOut)d[n];
+                }
+            }
+            wave_sync();   // carry[] written by lane 63 is read by all lanes next tile/section
+        }
+
+        // ---- store (skipped entirely while still inside the warm-up halo)
+        if (ts + TILE > out_begin) {
+#pragma unroll
+            for (int i = 0; i < NUO; ++i) {
+                U16<TOut> v;
+#pragma unroll
+                for (int e = 0; e < EO; ++e) v.e[e] = (TOut)d[i * EO + e];
+                *(uint4 *)(st_own + i * 16) = v.u;
+            }
+            wave_sync();
+            const int64_t lo64 = out_begin - ts, hi64 = out_end - ts;
+            const bool full = (lo64 <= 0) && (hi64 >= TILE);
+            if constexpr (VEC) {
+                uint4 *__restrict__ yl = (uint4 *)(yrow + ts) + lane;
+                if (full) {
+#pragma unroll
+                    for (int i = 0; i < NUO; ++i)
+                        yl[i * 64] = *(const uint4 *)(st_out_v + i * (64 / NUO) * CHUNK_B);
+                } else {
+                    const int lo = lo64 > 0 ? (int)(lo64 / EO) : 0;
+                    const int hi = hi64 < TILE ? (int)(hi64 / EO) : TILE / EO;
+#pragma unroll
+                    for (int i = 0; i < NUO; ++i) {
+                        const int q = i * 64 + lane;
+                        const uint4 v = *(const uint4 *)(st_out_v + i * (64 / NUO) * CHUNK_B);
+                        if (q >= lo && q < hi) yl[i * 64] = v;
+                    }
+                }
+            } else {
+                TOut *__restrict__ yl = yrow + ts + lane;
+                const int lo = lo64 > 0 ? (int)lo64 : 0;
+                const int hi = hi64 < TILE ? (int)hi64 : TILE;
+#pragma unroll
+                for (int i = 0; i < LC; ++i) {
+                    const int e = i * 64 + lane;
+                    const TOut v = *(const TOut *)(st_out_s + i * (64 / LC) * CHUNK_B);
+                    if (e >= lo && e < hi) yl[i * 64] = v;
+                }
+            }
+            wave_sync();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Host side: tables and plan cache
+// ------------------------------------------------------------------------------------------
+typedef long double ld;
+
+struct SosPlan {
+    int K = 0;
+    int nsteps32 = 6, nsteps16 = 6;
+    int64_t warm = -1;            // samples; -1 = too long / not decaying
+    double err_bound_f32 = -1.0;  // worst-case |err| of f32 arithmetic for |x| <= 1 (lazy)
+    void *tab_f64_lc32 = nullptr; // device
+    void *tab_f32_lc32 = nullptr;
+    void *tab_f64_lc16 = nullptr;
+    void *tab_f32_lc16 = nullptr;
+    std::vector<double> sos;
+};
+
+static std::mutex g_plan_mu;
+static std::map<std::vector<double>, SosPlan *> g_plans;
+
+// one zero-input step of the whole cascade on state w = [x1,x2, y1_1,y1_2, ..., yK_1,yK_2]
+static void cascade_step(const std::vector<double> &sos, int K, std::vector<ld> &w)
+{
+    std::vector<ld> nw(w.size());
+    ld v = 0.0L;                     // current input sample = 0
+    ld p1 = w[0], p2 = w[1];         // input history of section 0
+    nw[0] = 0.0L; nw[1] = w[0];
+    for (int s = 0; s < K; ++s) {
+        const double *co = &sos[s * 6];
+        const ld y1 = w[2 + 2 * s], y2 = w[3 + 2 * s];
+        const ld yn = (ld)co[0] * v + (ld)co[1] * p1 + (ld)co[2] * p2 - (ld)co[4] * y1 - (ld)co[5] * y2;
+        nw[2 + 2 * s] = yn; nw[3 + 2 * s] = y1;
+        p1 = y1; p2 = y2;            // next section's input history = this section's old outputs
+        v = yn;
+    }
+    w.swap(nw);
+}
+
+static std::vector<ld> matmul(const std::vector<ld> &a, const std::vector<ld> &b, int D)
+{
+    std::vector<ld> c((size_t)D * D, 0.0L);
+    for (int i = 0; i < D; ++i)
+        for (int k = 0; k < D; ++k) {
+            const ld aik = a[(size_t)i * D + k];
+            if (aik == 0.0L) continue;
+            for (int j = 0; j < D; ++j) c[(size_t)i * D + j] += aik * b[(size_t)k * D + j];
+        }
+    return c;
+}
+static ld maxabs(const std::vector<ld> &a)
+{
+    ld m = 0;
+    for (ld v : a) { ld t = fabsl(v); if (!(t <= m)) m = t; }   // NaN-propagating
+    return m;
+}
+
+// smallest W (with margin) such that max|A^W| < tol; -1 if not reached within 2^26 samples
+static int64_t warmup_length(const std::vector<double> &sos, int K)
+{
+    const int D = 2 * K + 2;
+    std::vector<ld> A((size_t)D * D, 0.0L);
+    for (int j = 0; j < D; ++j) {
+        std::vector<ld> w(D, 0.0L);
+        w[j] = 1.0L;
+        cascade_step(sos, K, w);
+        for (int i = 0; i < D; ++i) A[(size_t)i * D + j] = w[i];
+    }
+    const ld tol = ldexpl(1.0L, -60);
+    std::vector<std::vector<ld>> pw;   // A^(2^i)
+    pw.push_back(A);
+    int m = 0;
+    for (; m < 26; ++m) {
+        ld nrm = maxabs(pw.back());
+        if (!(nrm == nrm) || nrm > 1e300L) return -1;
+        if (nrm < tol) break;
+        pw.push_back(matmul(pw.back(), pw.back(), D));
+    }
+    if (m == 26) return -1;
+    // greedy: largest n with max|A^n| >= tol
+    std::vector<ld> cur;
+    int64_t n = 0;
+    for (int i = m - 1; i >= 0; --i) {
+        std::vector<ld> cand = cur.empty() ? pw[i] : matmul(cur, pw[i], D);
+        if (maxabs(cand) >= tol) { cur.swap(cand); n += (int64_t)1 << i; }
+    }
+    int64_t W = n + 1;
+    W += W / 8 + 8;                    // margin: the norm is not strictly monotone
+    return W;
+}
+
+template <typename TC>
+static void fill_tables(const std::vector<double> &sos, int K, int LC, std::vector<TC> &out, int &nsteps)
+{
+    const int TS = tab_stride(LC);
+    out.assign((size_t)K * TS, (TC)0);
+    nsteps = 0;
+    for (int s = 0; s < K; ++s) {
+        const double *co = &sos[s * 6];
+        TC *tb = &out[(size_t)s * TS];
+        tb[0] = (TC)co[0]; tb[1] = (TC)co[1]; tb[2] = (TC)co[2];
+        tb[3] = (TC)(-co[4]); tb[4] = (TC)(-co[5]);
+        const ld a1 = co[4], a2 = co[5];
+        // alpha: response to state (1,0); beta: to (0,1)
+        ld al1 = 1, al2 = 0, be1 = 0, be2 = 1;
+        ld P[4] = {1, 0, 0, 1};
+        for (int n = 0; n < LC; ++n) {
+            const ld al = -a1 * al1 - a2 * al2, be = -a1 * be1 - a2 * be2;
+            al2 = al1; al1 = al; be2 = be1; be1 = be;
+        }
+        P[0] = al1; P[1] = be1; P[2] = al2; P[3] = be2;          // Cmp^LC
+        int need = 0;
+        for (int k = 0; k < 6; ++k) {
+            for (int i = 0; i < 4; ++i) tb[8 + 4 * k + i] = (TC)P[i];
+            ld m = 0;
+            for (int i = 0; i < 4; ++i) m = fmaxl(m, fabsl(P[i]));
+            if (!(m < 1e-22L)) need = k + 1;    // this step still contributes (or is NaN/inf)
+            const ld q0 = P[0] * P[0] + P[1] * P[2], q1 = P[0] * P[1] + P[1] * P[3];
+            const ld q2 = P[2] * P[0] + P[3] * P[2], q3 = P[2] * P[1] + P[3] * P[3];
+            P[0] = q0; P[1] = q1; P[2] = q2; P[3] = q3;
+        }
+        if (need > nsteps) nsteps = need;
+    }
+}
+
+// Worst-case f32 error bound for |x| <= 1: sum over sections of (rounding noise injected at the
+// section's recursion, ~2.5 ulp of the local signal magnitude) x (L1 gain from that point to
+// the output).  Impulse responses are run until they decay (cap 2^18 samples).
+static double f32_error_bound(const std::vector<double> &sos, int K)
+{
+    const int64_t NMAX = 1 << 18;
+    const double eps = 5.96e-8;
+    double total = 0.0;
+    // magnitude bound of the signal at the output of section s: L1 norm of H_0..s
+    std::vector<double> mag(K, 0.0);
+    {
+        std::vector<double> sx0(K, 0), sx1(K, 0), sy0(K, 0), sy1(K, 0);
+        std::vector<double> l1(K, 0.0);
+        for (int64_t n = 0; n < NMAX; ++n) {
+            double v = (n == 0) ? 1.0 : 0.0, tail = 0.0;
+            for (int s = 0; s < K; ++s) {
+                const double *co = &sos[s * 6];
+                double yn = co[0] * v + co[1] * sx0[s] + co[2] * sx1[s] - co[4] * sy0[s] - co[5] * sy1[s];
+                sx1[s] = sx0[s]; sx0[s] = v; sy1[s] = sy0[s]; sy0[s] = yn; v = yn;
+                l1[s] += fabs(yn); tail += fabs(yn);
+            }
+            if (n > 64 && tail < 1e-14) break;
+            if (!(tail == tail) || tail > 1e30) return INFINITY;
+        }
+        for (int s = 0; s < K; ++s) mag[s] = fmax(1.0, l1[s]);
+    }
+    for (int s0 = 0; s0 < K; ++s0) {
+        // noise injected into y of section s0 passes 1/A_s0 then sections s0+1..K-1
+        std::vector<double> sx0(K, 0), sx1(K, 0), sy0(K, 0), sy1(K, 0);
+        double l1 = 0.0;
+        for (int64_t n = 0; n < NMAX; ++n) {
+            const double *c0 = &sos[s0 * 6];
+            double e = (n == 0) ? 1.0 : 0.0;
+            double yn = e - c0[4] * sy0[s0] - c0[5] * sy1[s0];
+            sy1[s0] = sy0[s0]; sy0[s0] = yn;
+            double v = yn;
+            for (int s = s0 + 1; s < K; ++s) {
+                const double *co = &sos[s * 6];
+                double y2 = co[0] * v + co[1] * sx0[s] + co[2] * sx1[s] - co[4] * sy0[s] - co[5] * sy1[s];
+                sx1[s] = sx0[s]; sx0[s] = v; sy1[s] = sy0[s]; sy0[s] = y2; v = y2;
+            }
+            l1 += fabs(v);
+            if (n > 64 && fabs(v) < 1e-14 && fabs(yn) < 1e-14) break;
+            if (!(v == v) || fabs(v) > 1e30) return INFINITY;
+        }
+        const double in_mag = (s0 == 0) ? 1.0 : mag[s0 - 1];
+        const double *c0 = &sos[s0 * 6];
+        const double local = (fabs(c0[0]) + fabs(c0[1]) + fabs(c0[2])) * in_mag +
+                             (fabs(c0[4]) + fabs(c0[5])) * mag[s0];
+        total += 2.5 * eps * local * l1;
+    }
+    return total;
+}
+
+static void free_plan(SosPlan *pl)
+{
+    void *t[4] = {pl->tab_f64_lc32, pl->tab_f32_lc32, pl->tab_f64_lc16, pl->tab_f32_lc16};
+    for (void *q : t) if (q) (void)hipFree(q);
+    delete pl;
+}
+static double plan_err_bound(SosPlan *pl)
+{
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    if (pl->err_bound_f32 < 0) pl->err_bound_f32 = f32_error_bound(pl->sos, pl->K);
+    return pl->err_bound_f32;
+}
+static double auto_bound()
+{
+    const char *e = getenv("TFX_AUTO_F32_BOUND");
+    return (e && *e) ? atof(e) : 2e-6;
+}
+
+static SosPlan *get_plan(const double *sos_host, int64_t K, hipStream_t stream)
+{
+    std::vector<double> key(sos_host, sos_host + K * 6);
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) return it->second;
+    if (g_plans.size() > 256) {   // bound the cache
+        for (auto &kv : g_plans) {
+            free_plan(kv.second);
+        }
+        g_plans.clear();
+    }
+    SosPlan *pl = new SosPlan();
+    pl->K = (int)K;
+    pl->sos = key;
+    pl->warm = warmup_length(key, (int)K);
+    g_plans[key] = pl;
+    return pl;
+}
+
+template <typename TC>
+static void *ensure_table(SosPlan *pl, void **slot, int LC, int *nsteps, hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    if (!*slot) {
+        std::vector<TC> h;
+        fill_tables<TC>(pl->sos, pl->K, LC, h, *nsteps);
+        void *d = nullptr;
+        TFX_HIP(hipMalloc(&d, h.size() * sizeof(TC)));
+        // synchronous copy from a temporary: happens once per distinct filter
+        TFX_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(TC), hipMemcpyHostToDevice));
+        *slot = d;
+    }
+    return *slot;
+}
+
+void sos_clear_plans()
+{
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    for (auto &kv : g_plans) {
+        free_plan(kv.second);
+    }
+    g_plans.clear();
+}
+
+static int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+
+static int g_cus = 0;
+static int device_cus()
+{
+    if (!g_cus) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess)
+            g_cus = pr.multiProcessorCount;
+        if (g_cus <= 0) g_cus = 256;
+    }
+    return g_cus;
+}
+
+template <typename TIn, typename TOut, typename TC, int LC, bool VEC, bool TAPS, bool PF, int MINW>
+static void launch_one(const SosParams &p, int64_t nstreams, hipStream_t stream)
+{
+    constexpr int IOB = sizeof(TIn) > sizeof(TOut) ? sizeof(TIn) : sizeof(TOut);
+    constexpr int STAGE_B = 64 * (LC * IOB + 16);
+    const int carry_b = (((p.K * 4 + 2 * LC) * (int)sizeof(TC)) + 15) & ~15;
+    const size_t shmem = 4 * (size_t)(STAGE_B + carry_b);
+    TFX_CHECK(shmem <= 160 * 1024, "sos_forward: K=%d needs %zu B of LDS (max 163840)", p.K, shmem);
+    const unsigned grid = (unsigned)ceil_div(nstreams, 4);
+    auto kern = sos_stream_kernel<TIn, TOut, TC, LC, VEC, TAPS, PF, MINW>;
+    if (shmem > 64 * 1024)
+        TFX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    ProfScope ps(sizeof(TC) == 8 ? "sos_stream_kernel<f64>" : "sos_stream_kernel<f32>", stream);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, stream, p);
+    TFX_HIP(hipGetLastError());
+}
+
+// Variants (TFX_SOS_VARIANT): 0 = LC32, 1 = LC16, 2 = LC32 + register prefetch, 3 = LC16 + prefetch.
+// Register budgets (waves/SIMD) were chosen from -Rpass-analysis so that nothing spills.
+template <typename TIn, typename TOut, typename TC>
+static void launch_main(const SosParams &p, bool vec, int variant, int64_t nstreams, hipStream_t stream)
+{
+    constexpr bool F32 = sizeof(TC) == 4;
+    if (p.taps || !vec) {     // debug taps / unaligned rows: plain dword path
+        if (variant & 1) {
+            if (p.taps) launch_one<TIn, TOut, TC, 16, false, true, false, F32 ? 5 : 3>(p, nstreams, stream);
+            else launch_one<TIn, TOut, TC, 16, false, false, false, F32 ? 5 : 3>(p, nstreams, stream);
+        } else {
+            if (p.taps) launch_one<TIn, TOut, TC, 32, false, true, false, F32 ? 3 : 2>(p, nstreams, stream);
+            else launch_one<TIn, TOut, TC, 32, false, false, false, F32 ? 3 : 2>(p, nstreams, stream);
+        }
+        return;
+    }
+    switch (variant) {
+    case 1: launch_one<TIn, TOut, TC, 16, true, false, false, F32 ? 6 : 4>(p, nstreams, stream); break;
+    case 2: launch_one<TIn, TOut, TC, 32, true, false, true, F32 ? 3 : 2>(p, nstreams, stream); break;
+    case 3: launch_one<TIn, TOut, TC, 16, true, false, true, F32 ? 5 : 3>(p, nstreams, stream); break;
+    default: launch_one<TIn, TOut, TC, 32, true, false, false, F32 ? 4 : 3>(p, nstreams, stream); break;
+    }
+}
+// rarely used dtype mixes: one configuration only
+template <typename TIn, typename TOut, typename TC>
+static void launch_rare(const SosParams &p, bool vec, int64_t nstreams, hipStream_t stream)
+{
+    if (p.taps) launch_one<TIn, TOut, TC, 16, false, true, false, 3>(p, nstreams, stream);
+    else if (vec) launch_one<TIn, TOut, TC, 16, true, false, false, 4>(p, nstreams, stream);
+    else launch_one<TIn, TOut, TC, 16, false, false, false, 3>(p, nstreams, stream);
+}
+
+void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C, int64_t T,
+                 const double *sos_host, int64_t K,
+                 const double *sx_in, const double *sy_in, double *sx_out, double *sy_out,
+                 void *y_sections, int precision, hipStream_t stream)
+{
+    TFX_CHECK(C >= 0 && T >= 0 && K >= 0, "sos_forward: negative size");
+    TFX_CHECK(x_dtype == TFX_F32 || x_dtype == TFX_F64, "sos_forward: bad x dtype %d", x_dtype);
+    TFX_CHECK(y_dtype == TFX_F32 || y_dtype == TFX_F64, "sos_forward: bad y dtype %d", y_dtype);
+    if (C == 0) return;
+    const size_t st_bytes = (size_t)K * C * 2 * sizeof(double);
+    if (T == 0 || K == 0) {
+        // no samples: state passes through (iir_cpu.cpp writes back what it loaded);
+        // no sections: y = x
+        if (sx_out && K) { if (sx_in) TFX_HIP(hipMemcpyAsync(sx_out, sx_in, st_bytes, hipMemcpyDeviceToDevice, stream));
+                           else TFX_HIP(hipMemsetAsync(sx_out, 0, st_bytes, stream)); }
+        if (sy_out && K) { if (sy_in) TFX_HIP(hipMemcpyAsync(sy_out, sy_in, st_bytes, hipMemcpyDeviceToDevice, stream));
+                           else TFX_HIP(hipMemsetAsync(sy_out, 0, st_bytes, stream)); }
+        if (K == 0 && T > 0) {
+            TFX_CHECK(x_dtype == y_dtype, "sos_forward: K=0 needs equal dtypes");
+            TFX_HIP(hipMemcpyAsync(y, x, (size_t)C * T * (x_dtype == TFX_F32 ? 4 : 8), hipMemcpyDeviceToDevice, stream));
+        }
+        return;
+    }
+    for (int64_t i = 0; i < K * 6; ++i)
+        TFX_CHECK(std::isfinite(sos_host[i]), "sos_forward: non-finite SOS coefficient");
+
+    SosPlan *pl = get_plan(sos_host, K, stream);
+    int prec = precision;
+    if (prec == TFX_PREC_AUTO) prec = (plan_err_bound(pl) <= auto_bound()) ? TFX_PREC_F32 : TFX_PREC_F64;
+    if (x_dtype == TFX_F64 || y_dtype == TFX_F64) prec = TFX_PREC_F64;   // f64 signals: always f64 math
+    const bool rare = !(x_dtype == TFX_F32 && y_dtype == TFX_F32);
+
+    const int variant = rare ? 1 : env_int("TFX_SOS_VARIANT", 0);
+    const int LC = (variant & 1) ? 16 : 32, TILE = 64 * LC;
+    SosParams p{};
+    p.x = x; p.y = y; p.taps = y_sections;
+    p.sx_in = sx_in; p.sy_in = sy_in; p.sx_out = sx_out; p.sy_out = sy_out;
+    p.C = C; p.T = T; p.K = (int)K;
+
+    // ---- time segmentation
+    const int64_t tiles_total = ceil_div(T, TILE);
+    int64_t nseg = 1, seg_len = tiles_total * TILE, warm = 0;
+    const int force_nseg = env_int("TFX_SOS_NSEG", 0);
+    if (pl->warm >= 0) {
+        warm = (pl->warm + 3) & ~(int64_t)3;
+        const int waves_per_cu = env_int("TFX_SOS_WAVES_PER_CU", 16);
+        const int64_t target = (int64_t)device_cus() * waves_per_cu;
+        int64_t nseg_target = force_nseg > 0 ? force_nseg : (target + C - 1) / C;
+        if (nseg_target < 1) nseg_target = 1;
+        int64_t seg_tiles = ceil_div(tiles_total, nseg_target);
+        if (force_nseg <= 0) {
+            const int64_t min_tiles = ceil_div(env_int("TFX_SOS_MIN_SEG_OVER_WARM", 16) * warm, TILE);
+            if (seg_tiles < min_tiles) seg_tiles = min_tiles;
+        }
+        if (seg_tiles < 1) seg_tiles = 1;
+        nseg = ceil_div(tiles_total, seg_tiles);
+        seg_len = seg_tiles * TILE;
+        if (nseg == 1) warm = 0;
+    }
+    p.nseg = (int)nseg; p.seg_len = seg_len; p.warm = warm;
+    const int64_t nstreams = C * nseg;
+
+    const int xsz = x_dtype == TFX_F32 ? 4 : 8, ysz = y_dtype == TFX_F32 ? 4 : 8;
+    const bool vec = (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0) &&
+                     ((T * xsz) % 16 == 0) && ((T * ysz) % 16 == 0);
+
+    if (prec == TFX_PREC_F32) {
+        p.tab = ensure_table<float>(pl, LC == 32 ? &pl->tab_f32_lc32 : &pl->tab_f32_lc16, LC,
+                                    LC == 32 ? &pl->nsteps32 : &pl->nsteps16, stream);
+        p.nsteps = LC == 32 ? pl->nsteps32 : pl->nsteps16;
+        launch_main<float, float, float>(p, vec, variant, nstreams, stream);
+    } else {
+        p.tab = ensure_table<double>(pl, LC == 32 ? &pl->tab_f64_lc32 : &pl->tab_f64_lc16, LC,
+                                     LC == 32 ? &pl->nsteps32 : &pl->nsteps16, stream);
+        p.nsteps = LC == 32 ? pl->nsteps32 : pl->nsteps16;
+        if (x_dtype == TFX_F32 && y_dtype == TFX_F32) launch_main<float, float, double>(p, vec, variant, nstreams, stream);
+        else if (x_dtype == TFX_F32) launch_rare<float, double, double>(p, vec, nstreams, stream);
+        else if (y_dtype == TFX_F32) launch_rare<double, float, double>(p, vec, nstreams, stream);
+        else launch_rare<double, double, double>(p, vec, nstreams, stream);
+    }
+}
+
+void sos_plan_info(const double *sos_host, int64_t K, int *precision, int64_t *warmup, double *err_bound)
+{
+    SosPlan *pl = get_plan(sos_host, K, nullptr);
+    const double eb = plan_err_bound(pl);
+    if (precision) *precision = (eb <= auto_bound()) ? TFX_PREC_F32 : TFX_PREC_F64;
+    if (warmup) *warmup = pl->warm;
+    if (err_bound) *err_bound = eb;
+}
+
+}  // namespace tfx

@@ -1,0 +1,159 @@
+"""``Wave``: the signal container with the lazy ``|`` pipeline and the fusion planner.
+
+Reference: ``src/torchfx/wave.py`` -- only the hot-path part is mirrored: construction
+(:100-140), lazy ``ys`` (:196-205), ``_materialize`` (:207-239: consecutive IIR/Biquad steps
+become one ``FusedSOSCascade``; a *single* IIR step runs the module itself and therefore
+keeps its state across waves), ``_deferred`` (:241-257), ``to`` (:275-332), ``__or__``
+(:578-695: fs propagation + eager coefficient design, ``nn.Sequential`` flattened into
+steps), ``__len__`` / ``channels``.  File I/O (``from_file`` / ``save``) is out of scope
+(SURVEY.md 8f rank 4).
+
+Beyond the reference, the planner can also merge consecutive ``FIR`` steps into one
+overlap-save pass (``fuse_fir=True`` or env ``TORCHFX_AMD_FUSE_FIR=1``): convolution is
+associative, so ``FIR(b1) | FIR(b2)`` == ``FIR(b1 * b2)``; the merged taps are computed on the
+host in float64.  Off by default so the default results follow the reference's staged
+float32 arithmetic; ``bench.py`` turns it on for the chain workload and checks it against the
+staged oracle.
+"""
+from __future__ import annotations
+
+import os
+import typing as tp
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+
+from torchfx_amd.effect import FX
+from torchfx_amd.filter._base import AbstractFilter
+
+
+def _merge_fir_run(run: list) -> nn.Module:
+    """[FIR, FIR, ...] -> one FIR whose taps are the float64 convolution of the members'."""
+    from torchfx_amd.filter.fir import FIR
+
+    taps = None
+    for f in run:
+        b = f.kernel.detach().cpu().reshape(-1).flip(0).to(torch.float64).numpy()
+        taps = b if taps is None else np.convolve(taps, b)
+    merged = FIR.__new__(FIR)
+    nn.Module.__init__(merged)
+    merged._conv_mode = "fft"
+    merged.a = [1.0]
+    # keep float64 taps: the merged filter is rounded once, when the kernel casts to x.dtype
+    merged.register_buffer("kernel", torch.from_numpy(taps[::-1].copy()).reshape(1, 1, -1))
+    return merged
+
+
+class Wave:
+    """Discrete-time signal ``ys [C,T]`` sampled at ``fs`` with a deferred filter pipeline."""
+
+    fs: int
+
+    def __init__(self, ys, fs: int, device="cpu", metadata: dict[str, tp.Any] | None = None) -> None:
+        self.fs = fs
+        self._pipeline: list[nn.Module] = []
+        self._ys = ys if isinstance(ys, Tensor) else Tensor(ys)   # Tensor(ys): float32, as wave.py:137
+        self.metadata = metadata or {}
+        self.fuse_fir = os.environ.get("TORCHFX_AMD_FUSE_FIR", "0") == "1"
+        self.to(device)
+
+    # ------------------------------------------------------------------ lazy data
+    @property
+    def ys(self) -> Tensor:
+        self._materialize()
+        return self._ys
+
+    @ys.setter
+    def ys(self, value: Tensor) -> None:
+        self._ys = value
+        self._pipeline = []
+
+    def plan(self) -> list[nn.Module]:
+        """The fused execution plan of the pending pipeline (``wave.py:216-233``)."""
+        from torchfx_amd.filter.biquad import Biquad
+        from torchfx_amd.filter.fir import FIR
+        from torchfx_amd.filter.fused import FusedSOSCascade
+        from torchfx_amd.filter.iir import IIR
+
+        plan: list[nn.Module] = []
+        run: list = []
+        kind = None
+
+        def flush() -> None:
+            nonlocal run, kind
+            if kind == "iir":
+                plan.append(FusedSOSCascade(*run) if len(run) >= 2 else run[0])
+            elif kind == "fir":
+                plan.append(_merge_fir_run(run) if len(run) >= 2 else run[0])
+            run, kind = [], None
+
+        for m in self._pipeline:
+            k = "iir" if isinstance(m, (IIR, Biquad)) else (
+                "fir" if (self.fuse_fir and isinstance(m, FIR) and m._conv_mode != "direct") else None)
+            if k is None or (kind is not None and k != kind):
+                flush()
+            if k is None:
+                plan.append(m)
+            else:
+                run.append(m)
+                kind = k
+        flush()
+        return plan
+
+    def _materialize(self) -> None:
+        if not self._pipeline:
+            return
+        data = self._ys
+        for step in self.plan():
+            data = step(data)
+        self._ys = data
+        self._pipeline = []
+
+    @classmethod
+    def _deferred(cls, ys: Tensor, fs: int, device, metadata, pipeline: list[nn.Module],
+                  fuse_fir: bool = False) -> "Wave":
+        w = object.__new__(cls)
+        w._ys, w.fs, w._device, w.metadata, w._pipeline, w.fuse_fir = ys, fs, device, metadata, pipeline, fuse_fir
+        return w
+
+    # ------------------------------------------------------------------ device
+    @property
+    def device(self):
+        return self._device
+
+    @device.setter
+    def device(self, device) -> None:
+        self.to(device)
+
+    def to(self, device) -> "Wave":
+        self._device = device
+        self._materialize()
+        self._ys = self._ys.to(device)
+        return self
+
+    # ------------------------------------------------------------------ pipeline
+    def __or__(self, f: nn.Module) -> "Wave":
+        if not isinstance(f, nn.Module):
+            raise TypeError(f"Expected nn.Module, but got {type(f).__name__} instead.")
+        for m in f.modules():                       # includes f itself and nested containers
+            if isinstance(m, FX):
+                if getattr(m, "fs", 0) is None:
+                    m.fs = self.fs
+                if isinstance(m, AbstractFilter) and not m._has_computed_coeff:
+                    m.compute_coefficients()
+        steps = list(f.children()) if isinstance(f, nn.Sequential) else [f]
+        return Wave._deferred(self._ys, self.fs, self._device, self.metadata,
+                              self._pipeline + steps, self.fuse_fir)
+
+    def __len__(self) -> int:
+        return self.ys.shape[1]
+
+    def channels(self) -> int:
+        return self.ys.shape[0]
+
+    def get_channel(self, index: int) -> "Wave":
+        return Wave(self.ys[index], self.fs)
+
+    def duration(self, unit: str) -> float:
+        return len(self) / self.fs * (1000 if unit == "ms" else 1)
