@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- the driver's benchmark contract for the torchfx.filter hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over one batch of synthetic audio already resident in
+HBM.  Default workload = the configuration BASELINE.json's metric is quoted on: the fused pipe
+chain  4-section SOS cascade | FIR-1024 | 65536-tap reverb IR  over 64 channels x 600 s @ 48 kHz
+float32 PER GPU (configs[4] is 512 channels over 8 GPUs = 64 per GPU).  Other workloads
+(`--workload sos|fir|fftconv` = configs[1..3]) are there for profiling; the parity tests cover
+them.  Channels shard across ranks with no data-path collective (weak scaling); `--gather`
+additionally times the final RCCL gather to rank 0 outside the timed region.
+
+Prints ONE JSON line on rank 0.  `roofline` follows SURVEY.md 8(d): algorithmic bytes are
+8 B per sample-channel (4 B read + 4 B written) for every stage and for the fused chain.
+`cpu_baseline` times the oracle (our CPU restatement of the reference path, pinned by golden
+vectors) on a bounded sample of the same workload -- a reported baseline, never a target.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FS = 48000
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_PEAK_TF = 157.3
+
+
+def reverb_ir(K: int = 65536) -> np.ndarray:
+    """SURVEY.md 8(d) cfg 4: seeded exponentially-decaying noise tail, L1-normalised, float32."""
+    ir = np.random.default_rng(0).standard_normal(K) * np.exp(-np.arange(K) / 8000.0)
+    return (ir / np.abs(ir).sum()).astype(np.float32)
+
+
+def build_filters():
+    from scipy.signal import firwin
+    from torchfx_amd import filter as F
+
+    f1 = F.LoButterworth(2000, order=6, fs=FS)                       # 3 sections
+    f2 = F.ParametricEQ(frequency=1000, q=2.0, gain=3.0, fs=FS)      # 1 section  (examples/quick_start.py chain)
+    fir = F.FIR(firwin(1024, 5000, fs=FS))                           # cfg 3 taps
+    rev = F.FIR(reverb_ir())                                         # cfg 4 IR
+    for f in (f1, f2):
+        f.compute_coefficients()
+    return f1, f2, fir, rev
+
+
+def make_step(workload: str, x: torch.Tensor):
+    """Returns (step_fn, description, n_stages_reference)."""
+    from torchfx_amd import filter as F
+    from torchfx_amd import torchfx_ext as E
+    from torchfx_amd.wave import _merge_fir_run
+
+    f1, f2, fir, rev = build_filters()
+    sos = torch.cat([f1._sos, f2._sos]).contiguous()
+    if workload == "sos":
+        return (lambda: E.sos_forward(x, None, sos, None, None)[0]), "cfg2: fused 4-section SOS cascade", 1
+    if workload == "fir":
+        k = fir.kernel.reshape(-1)
+        return (lambda: E.fir_direct_forward(x, k)), "cfg3: direct FIR, 1024 taps", 1
+    if workload == "fftconv":
+        k = rev.kernel.reshape(-1)
+        return (lambda: E.fft_conv_forward(x, k, (k.numel() - 1, 0))), "cfg4: overlap-save FFT conv, 65536 taps", 1
+    if workload == "chain":
+        merged = _merge_fir_run([fir, rev])          # conv associativity: one 66559-tap overlap-save pass
+        k = merged.kernel.reshape(-1).to(torch.float32)
+        pad = (k.numel() - 1, 0)
+
+        def step():
+            y = E.sos_forward(x, None, sos, None, None)[0]
+            return E.fft_conv_forward(y, k, pad)
+        return step, "cfg5/GPU: fused chain 4xbiquad | FIR-1024 | FFT-conv-65536 (FIRs merged)", 3
+    raise SystemExit(f"unknown workload {workload}")
+
+
+def cpu_baseline(workload: str, seconds: float, channels: int) -> dict:
+    """Oracle on the host, single thread, bounded sample of the same workload."""
+    os.environ["OMP_NUM_THREADS"] = "1"
+    from oracle import oracle as O
+
+    f1, f2, fir, rev = build_filters()
+    sos = np.vstack([f1._sos.numpy(), f2._sos.numpy()])
+    g = np.random.default_rng(7)
+    T = int(seconds * FS)
+    x = g.standard_normal((channels, T)).astype(np.float32)
+    x /= np.abs(x).max()
+    kf, kr = fir.kernel.numpy().reshape(-1), rev.kernel.numpy().reshape(-1)
+    fn = {
+        "sos": lambda: O.iir_module_forward(x, sos)[0],
+        "fir": lambda: O.fir_direct(x, kf),
+        "fftconv": lambda: O.fir_forward(x, kr, "fft"),
+        "chain": lambda: O.chain_forward(x, sos, [kf, kr]),
+    }[workload]
+    t0 = time.perf_counter()
+    fn()
+    dt = time.perf_counter() - t0
+    return {"value": round(channels * T / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": f"{channels} ch x {seconds:g} s @ 48 kHz float32, oracle (C float64 DF1 + numpy overlap-save, "
+                      f"reference framing N=int(5K)), 1 thread, {dt:.2f} s"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="chain", choices=["chain", "sos", "fir", "fftconv"])
+    ap.add_argument("--channels", type=int, default=64, help="channels PER GPU")
+    ap.add_argument("--seconds", type=float, default=None, help="signal length (default: 600 chain/fftconv, 60 sos/fir)")
+    ap.add_argument("--gather", action="store_true", help="also time the final RCCL gather to rank 0")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from torchfx_amd import _lib
+    lib = _lib.load()                      # fails loudly if the HIP extension is missing
+
+    seconds = args.seconds if args.seconds is not None else (600.0 if args.workload in ("chain", "fftconv") else 60.0)
+    C, T = args.channels, int(seconds * FS)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.randn(C, T, device=dev, generator=gen, dtype=torch.float32)
+    x.mul_(1.0 / float(x.abs().max()))     # max|x| <= 1 (benchmarks/conftest.py:70-82 of the reference)
+
+    step, desc, _ = make_step(args.workload, x)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        out = step()
+    sync()
+    lib.tfx_prof_enable(1)
+    lib.tfx_prof_collect()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = json.loads(lib.tfx_prof_collect().decode())
+    lib.tfx_prof_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    gather_ms = None
+    if args.gather and world > 1:
+        bufs = [torch.empty_like(out) for _ in range(world)] if rank == 0 else None
+        sync()
+        g0 = time.perf_counter()
+        dist.gather(out, bufs, dst=0)
+        sync()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        samples = C * T
+        value = world * samples / (elapsed / args.steps) / 1e6            # whole-job Msamples/s
+        kernels = {}
+        for name, v in prof.items():
+            calls_per_step = v["calls"] / args.steps
+            kernels[name] = {"launches_per_step": round(calls_per_step, 2),
+                             "avg_ms_per_launch": round(v["total_ms"] / v["calls"], 4),
+                             "ms_per_step": round(v["total_ms"] / args.steps, 4)}
+        dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"]) if kernels else None
+        gpu_ms = sum(k["ms_per_step"] for k in kernels.values())
+        # per-GPU algorithmic bytes of one step: 8 B per sample-channel
+        alg_gb = 8.0 * samples / 1e9
+        if args.workload == "fir":
+            ach = 2.0 * 1024 * samples / (ms_step * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": round(ach / FP32_PEAK_TF, 4), "traffic": None,
+                    "note": "2*1024 flop/sample on exact-f32 MFMA (v_mfma_f32_32x32x2_f32); HBM roof unreachable (SURVEY 7.3-3)"}
+        else:
+            ach = alg_gb / (ms_step * 1e-3)
+            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                    "note": "algorithmic 8 B/sample-channel x samples of one step / step time (all launches of the step)"}
+        roof["dominant_kernel"] = dom
+        if dom:
+            roof["dominant_kernel_avg_ms"] = kernels[dom]["avg_ms_per_launch"]
+            roof["dominant_kernel_ms_per_step"] = kernels[dom]["ms_per_step"]
+        if "sos_stream_kernel<f64>" in kernels or "sos_stream_kernel<f32>" in kernels:
+            kn = "sos_stream_kernel<f64>" if "sos_stream_kernel<f64>" in kernels else "sos_stream_kernel<f32>"
+            a = alg_gb / (kernels[kn]["ms_per_step"] * 1e-3)
+            roof["iir_kernel"] = {"name": kn, "achieved": round(a, 1), "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4)}
+        line = {
+            "metric": "Msamples/s (64-ch fused biquad->FIR->FFT-conv chain per GPU); % HBM roofline"
+                      if args.workload == "chain" else f"Msamples/s ({args.workload})",
+            "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 I/O; f64 IIR recurrences, f32 FFT",
+            "data": "synthetic", "per_gpu_value": round(value / world, 1),
+            "config": {"workload": desc, "channels_per_gpu": C, "seconds": seconds, "fs": FS,
+                       "samples_per_gpu": samples, "parallelism": f"channel-shard x{world}, no data-path collective",
+                       "iir_precision": os.environ.get("TORCHFX_AMD_IIR_PRECISION", "f64")},
+            "roofline": roof,
+            "kernels": kernels, "gpu_ms_per_step_sum_of_kernels": round(gpu_ms, 4),
+        }
+        if gather_ms is not None:
+            line["gather_ms"] = round(gather_ms, 2)
+        if not args.no_cpu_baseline:
+            try:
+                sec, ch = {"chain": (300.0, 8), "sos": (600.0, 16), "fir": (240.0, 8), "fftconv": (600.0, 8)}[args.workload]
+                line["cpu_baseline"] = cpu_baseline(args.workload, sec, ch)     # ~10-20 s of CPU work
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                line["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

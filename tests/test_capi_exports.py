@@ -1,0 +1,67 @@
+"""The C-ABI library loads on a machine without a GPU and exports exactly what
+include/torchfx_hip.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+from tests.conftest import ROOT
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "torchfx_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tfx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_hot_path():
+    syms = declared_symbols()
+    for need in ("tfx_sos_forward", "tfx_biquad_forward", "tfx_fir_direct_forward",
+                 "tfx_fft_conv_forward", "tfx_delay_line_forward", "tfx_sum_forward"):
+        assert need in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from torchfx_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for s in declared_symbols():
+        assert hasattr(lib, s), f"{s} declared in the header but not exported"
+    assert lib.tfx_version() >= 100
+
+
+def test_python_binding_table_matches_header():
+    from torchfx_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+    _lib.load()     # sets restype/argtypes for all of them; raises on any mismatch
+
+
+def test_only_extern_c_tfx_symbols_are_public_entry_points():
+    from torchfx_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported_c = sorted({ln.split()[-1] for ln in out.splitlines() if " T tfx_" in ln})
+    assert exported_c == declared_symbols()
+
+
+def test_plan_info_runs_without_gpu():
+    import numpy as np
+    from scipy.signal import butter
+    from torchfx_amd import torchfx_ext as E
+    info = E.sos_plan_info(butter(4, 0.1, output="sos"))
+    assert 100 < info["warmup"] < 2000 and info["f32_error_bound"] > 0
+    # pure delay-free FIR section: memory of exactly two samples
+    assert E.sos_plan_info(np.array([[1.0, 0.5, 0.25, 1, 0, 0]]))["warmup"] < 32
+    # marginally stable integrator never decays
+    assert E.sos_plan_info(np.array([[1.0, 0, 0, 1, -1.0, 0]]))["warmup"] == -1
+
+
+def test_errors_without_device_are_loud():
+    import pytest
+    import torch
+    from torchfx_amd import torchfx_ext as E
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        E.sos_forward(torch.zeros(1, 8), None, torch.tensor([[1., 0, 0, 1, 0, 0]]), None, None)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        E.fir_direct_forward(torch.zeros(1, 8), torch.ones(3))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        E.fft_conv_forward(torch.zeros(1, 8), torch.ones(3), (2, 0))

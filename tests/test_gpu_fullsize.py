@@ -1,0 +1,143 @@
+"""BASELINE.json's full sizes on the GPU, checked through size-independent properties plus the
+oracle on a channel subset (SURVEY.md 8d "parity at scale").  Tolerances as in
+test_gpu_parity.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+FS = 48000
+
+
+def ext():
+    from torchfx_amd import torchfx_ext
+    return torchfx_ext
+
+
+def maxerr(a, b):
+    return float((a.double() - b.double()).abs().max())
+
+
+def cfg2_sos():
+    from torchfx_amd import filter as F
+    f1, f2 = F.LoButterworth(2000, order=6, fs=FS), F.ParametricEQ(frequency=1000, q=2.0, gain=3.0, fs=FS)
+    f1.compute_coefficients(), f2.compute_coefficients()
+    return torch.cat([f1._sos, f2._sos])
+
+
+def reverb_ir(K=65536):
+    ir = np.random.default_rng(0).standard_normal(K) * np.exp(-np.arange(K) / 8000.0)
+    return (ir / np.abs(ir).sum()).astype(np.float32)
+
+
+def signal(C, T, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    x = torch.randn(C, T, device=DEV, generator=g)
+    return x / x.abs().max()
+
+
+def test_cfg2_sos_64ch_60s(monkeypatch):
+    C, T = 64, 60 * FS
+    sos = cfg2_sos()
+    x = signal(C, T, 1)
+    y, sx, sy = ext().sos_forward(x, None, sos, None, None)
+    assert torch.isfinite(y).all()
+    # (1) oracle on channels {0, C/2, C-1}, full length, section by section for channel 0
+    for c in (0, C // 2, C - 1):
+        ey, _, esy = O.sos_forward(x[c:c + 1].cpu().numpy(), sos.numpy())
+        assert np.abs(y[c].cpu().numpy() - ey[0].astype(np.float32)).max() <= 1.5e-7 * max(1, np.abs(ey).max())
+        assert np.abs(sy[:, c].cpu().numpy() - esy[:, 0]).max() <= 2e-10
+    _, _, _, esec = O.sos_forward(x[:1, :200_000].cpu().numpy(), sos.numpy(), sections=True)
+    _, _, _, sec = ext().sos_forward(x[:1, :200_000].double().contiguous(), None, sos, None, None, return_sections=True)
+    for k in range(4):
+        assert np.abs(sec[k].cpu().numpy() - esec[k]).max() <= 2e-11, f"section {k}"
+    # (2) chunked == contiguous at full size (state carry), split at an awkward point
+    cut = 1_234_567
+    y1, s1x, s1y = ext().sos_forward(x[:, :cut].contiguous(), None, sos, None, None)
+    y2, s2x, s2y = ext().sos_forward(x[:, cut:].contiguous(), None, sos, s1x, s1y)
+    assert maxerr(torch.cat([y1, y2], 1), y) <= 1.2e-7
+    assert maxerr(s2y, sy) <= 1e-12
+    # (3) time-parallel segmentation == sequential (one stream per channel)
+    monkeypatch.setenv("TFX_SOS_NSEG", "1")
+    ys, _, sys_ = ext().sos_forward(x, None, sos, None, None)
+    assert torch.equal(ys, y) or maxerr(ys, y) <= 6e-8
+    assert maxerr(sys_, sy) <= 1e-12
+    monkeypatch.delenv("TFX_SOS_NSEG")
+    # (4) linearity: f(a*x1 + x2) == a*f(x1) + f(x2)
+    x2 = signal(C, T, 2)
+    ya, _, _ = ext().sos_forward(0.5 * x + x2, None, sos, None, None)
+    yb, _, _ = ext().sos_forward(x2, None, sos, None, None)
+    assert maxerr(ya, 0.5 * y + yb) <= 4e-7
+
+
+def test_cfg3_fir_direct_64ch_60s():
+    from scipy.signal import firwin
+    C, T = 64, 60 * FS
+    kf = firwin(1024, 5000, fs=FS).astype(np.float32)[::-1].copy()
+    x = signal(C, T, 3)
+    y = ext().fir_direct_forward(x, kf)
+    # two different algorithms agree (direct MFMA Toeplitz vs rocFFT overlap-save)
+    yf = ext().fft_conv_forward(x, kf, (1023, 0))
+    assert maxerr(y, yf) <= 1e-5
+    # oracle on three channels, 10 s window at the start and at the end
+    for c in (0, 31, 63):
+        xc = x[c:c + 1].cpu().numpy()
+        e0 = O.fir_direct(xc[:, :10 * FS], kf)
+        assert np.abs(y[c, :10 * FS].cpu().numpy() - e0[0]).max() <= 1e-5
+        e1 = O.fir_direct(xc[:, -10 * FS - 1023:], kf)[:, 1023:]
+        assert np.abs(y[c, -10 * FS:].cpu().numpy() - e1[0]).max() <= 1e-5
+    # impulse response property: FIR of a unit impulse is the taps
+    imp = torch.zeros(2, 5000, device=DEV)
+    imp[:, 7] = 1.0
+    yi = ext().fir_direct_forward(imp, kf)
+    assert torch.equal(yi[0, 7:7 + 1024].cpu(), torch.from_numpy(kf[::-1].copy()))
+
+
+def test_cfg4_fftconv_64ch_600s():
+    C, T, K = 64, 600 * FS, 65536
+    kf = reverb_ir()[::-1].copy()
+    x = signal(C, T, 4)
+    y = ext().fft_conv_forward(x, kf, (K - 1, 0))
+    assert y.shape == x.shape and torch.isfinite(y).all()
+    # oracle (reference framing N = int(5K)) on three channels, first and last 20 s
+    for c in (0, 32, 63):
+        xc = x[c:c + 1].cpu().numpy()
+        n = 20 * FS
+        e0 = O.fft_conv1d(xc[:, :n], kf, (K - 1, 0))
+        assert np.abs(y[c, :n].cpu().numpy() - e0[0]).max() <= 1e-5
+        e1 = O.fft_conv1d(xc[:, -n - (K - 1):], kf, (0, 0))
+        assert np.abs(y[c, -n:].cpu().numpy() - e1[0]).max() <= 1e-5
+    # linearity at full size
+    x2 = signal(C, T, 5)
+    yb = ext().fft_conv_forward(x2, kf, (K - 1, 0))
+    x2.mul_(0.25).add_(x)
+    ya = ext().fft_conv_forward(x2, kf, (K - 1, 0))
+    yb.mul_(0.25).add_(y)
+    assert maxerr(ya, yb) <= 5e-6
+
+
+def test_cfg5_chain_per_gpu_64ch_600s():
+    """The bench workload: fused SOS -> merged (FIR-1024 * IR-65536) overlap-save, 64 ch x 600 s,
+    against the STAGED oracle (sos -> FIR fft -> IR fft, as the reference would run it)."""
+    from scipy.signal import firwin
+    import bench
+    C, T = 64, 600 * FS
+    x = signal(C, T, 6)
+    step, _, _ = bench.make_step("chain", x)
+    y = step()
+    assert y.shape == x.shape and torch.isfinite(y).all()
+    sos = cfg2_sos().numpy()
+    kf = firwin(1024, 5000, fs=FS).astype(np.float32)[::-1].copy()
+    kr = reverb_ir()[::-1].copy()
+    n = 15 * FS
+    for c in (0, 40, 63):
+        e = O.chain_forward(x[c:c + 1, :n].cpu().numpy(), sos, [kf, kr])
+        assert np.abs(y[c, :n].cpu().numpy() - e[0]).max() <= 1e-5
+    # tail: staged GPU ops == fused GPU chain on the last 30 s (needs the whole history -> GPU vs GPU)
+    ys = ext().sos_forward(x[:2].contiguous(), None, torch.from_numpy(sos), None, None)[0]
+    ys = ext().fft_conv_forward(ys, kf, (1023, 0))
+    ys = ext().fft_conv_forward(ys, kr, (65535, 0))
+    assert maxerr(ys[:, -30 * FS:], y[:2, -30 * FS:]) <= 1e-5

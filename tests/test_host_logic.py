@@ -1,0 +1,232 @@
+"""Host-side logic on CPU (kernels replaced by the oracle through the `oracle_backend`
+fixture): coefficient design, the Wave planner / chain fusion, shape / dtype / state rules,
+`+`, error behaviour.  Mirrors the reference's own hot-path tests."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+import torchfx_amd as fx
+from torchfx_amd import filter as F
+
+
+def close(a, b, tol):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    assert np.abs(a.astype(np.float64) - np.asarray(b, dtype=np.float64)).max() <= tol * max(1.0, np.abs(b).max())
+
+
+# ------------------------------------------------------------------ designs (row a8)
+def test_every_design_class_matches_reference_sos(golden):
+    g = golden("designs")
+    specs = [ast.literal_eval(str(s)) for s in g["specs"]]
+    keys = [k for k in g.files if k != "specs"]
+    assert len(specs) == len(keys) == 68
+    per_fs = len(specs) // 2
+    for n, (cls, args, kw, fs) in enumerate(specs):
+        key = f"{n % per_fs:02d}_{cls}_{fs}"
+        f = getattr(F, cls)(*args, fs=fs, **kw)
+        f.compute_coefficients()
+        exp = g[key]
+        assert f._sos.dtype == torch.float64 and tuple(f._sos.shape) == exp.shape, key
+        # same SciPy, same cookbook arithmetic order -> identical rows
+        assert np.array_equal(f._sos.numpy(), exp), key
+
+
+def test_designable_fir_taps(golden):
+    g = golden("fir_designs")
+    for i in range(4):
+        cut, nt, kw = ast.literal_eval(str(g[f"spec{i}"]))
+        f = F.DesignableFIR(cutoff=cut, num_taps=nt, fs=48000, **kw)
+        assert f.kernel.dtype == torch.float32 and tuple(f.kernel.shape) == (1, 1, nt)
+        assert np.array_equal(f.kernel.numpy(), g[f"k{i}"])
+
+
+def test_fir_kernel_is_flipped_float32():
+    f = F.FIR([1.0, 2.0, 3.0])
+    assert f.kernel.dtype == torch.float32
+    assert f.kernel.reshape(-1).tolist() == [3.0, 2.0, 1.0] and f.a == [1.0]
+    assert list(f.state_dict()) == ["kernel"]          # IIR modules have an empty state_dict
+    assert list(F.LoButterworth(100, fs=8000).state_dict()) == []
+    with pytest.raises(ValueError, match="conv_mode"):
+        F.FIR([1.0], conv_mode="nope")
+
+
+def test_biquad_coefficient_views_and_defaults():
+    f = F.BiquadLPF(1000, 0.707, fs=48000)
+    assert f.b is None and f.a is None
+    f.compute_coefficients()
+    assert f.b.shape == (3,) and f.a[0] == 1.0 and f._has_computed_coeff
+    assert F.LoButterworth(100).order == 5 and F.HiButterworth(100).order == 5
+    assert F.Butterworth("lowpass", 100, order=24, order_scale="db").order == 4
+    with pytest.raises(ValueError, match="positive even"):
+        F.LinkwitzRiley("lowpass", 1000, order=3)
+    assert F.Peaking(1000, 1.0, -1.0, "linear").gain_db == 0
+
+
+# ------------------------------------------------------------------ forward rules (a6, a7)
+def test_missing_fs_raises(oracle_backend):
+    with pytest.raises(ValueError, match="Sample rate"):
+        F.LoButterworth(1000)(torch.zeros(1, 8))
+    with pytest.raises(ValueError, match="Sample rate"):
+        F.BiquadHPF(1000, 0.7)(torch.zeros(1, 8))
+
+
+def test_shapes_dtypes_state(oracle_backend, golden):
+    g = golden("iir_shapes")
+    bq = F.BiquadLPF(cutoff=1500, q=0.9, fs=48000)
+    y = bq(torch.from_numpy(g["x1d"]))
+    assert y.shape == g["y1d"].shape and y.dtype == torch.float32
+    close(y, g["y1d"], 1e-7)
+    close(bq._state_x, g["bq_sx"], 1e-12)
+    lr = F.LoLinkwitzRiley(1200, order=4, fs=44100)
+    y = lr(torch.from_numpy(g["x3d"]))
+    assert y.dtype == torch.float64 and tuple(y.shape) == g["y3d"].shape
+    close(y, g["y3d"], 1e-12)
+    assert tuple(lr._state_x.shape) == (2, 6, 2)            # [K, B*C, 2]
+    lr(torch.from_numpy(g["x3d"][0]))                       # C changes -> state re-zeroed
+    assert tuple(lr._state_x.shape) == (2, 3, 2)
+    lr.reset_state()
+    assert lr._sos is None and lr._state_x is None          # IIR.reset_state drops the design too
+    bq.reset_state()
+    assert bq._sos is not None and bq._state_x is None      # Biquad.reset_state keeps it
+
+
+def test_state_carries_across_calls(oracle_backend, golden):
+    g = golden("iir_chunked")
+    fa, fb = F.HiButterworth(300, order=3, fs=44100), F.LoChebyshev1(4000, order=4, ripple=0.5, fs=44100)
+    fz = F.FusedSOSCascade(fa, fb)
+    assert np.array_equal(fz._sos.numpy(), g["sos"])
+    x = torch.from_numpy(g["x"])
+    close(fz(x[:, :1024]), g["y1"], 1e-12)
+    close(fz(x[:, 1024:]), g["y2"], 1e-12)
+    close(fz._state_y, g["state_y"], 1e-12)
+
+
+# ------------------------------------------------------------------ planner / fusion (a9-a11)
+def test_wave_is_lazy_and_fuses_iir_runs(oracle_backend, golden):
+    g = golden("chain")
+    oracle_backend.calls.clear()
+    f1, f2 = F.HiButterworth(100, order=2), F.LoButterworth(8000, order=4)
+    f3 = F.ParametricEQ(2000, 1.0, -3.0)
+    fir = F.DesignableFIR(cutoff=6000, num_taps=127)
+    w = fx.Wave(g["x"], 48000) | f1 | f2 | fir | f3
+    assert f1.fs == 48000 and fir.fs == 48000 and f1._sos is not None      # fs propagated, eager design
+    assert oracle_backend.calls == []                                      # nothing computed yet
+    plan = w.plan()
+    assert [type(p).__name__ for p in plan] == ["FusedSOSCascade", "DesignableFIR", "ParametricEQ"]
+    assert np.array_equal(plan[0]._sos.numpy(), g["sos_run1"])
+    close(w.ys, g["y_chain"], 2e-5)
+    names = [c[0] for c in oracle_backend.calls]
+    assert names == ["sos_forward", "fft_conv_forward", "sos_forward"]
+    assert oracle_backend.calls[0][2] == 3                                 # 1 + 2 sections in one call
+    assert f1._state_x is None                                             # members of a fused run keep no state
+    assert f3._state_x is not None                                         # a lone IIR step does (quirk, wave.py:221-224)
+
+
+def test_chain_forms_are_equivalent(oracle_backend):
+    x = torch.randn(2, 3000, generator=torch.Generator().manual_seed(0), dtype=torch.float64)
+
+    def fs3():
+        return F.LoButterworth(3000, order=2), F.HiChebyshev1(200, order=3), F.Notch(1000, 5.0)
+    a = (fx.Wave(x, 44100) | fs3()[0] | fs3()[1] | fs3()[2]).ys
+    f = fs3()
+    b = (fx.Wave(x, 44100) | (f[0] | f[1] | f[2])).ys
+    c = (fx.Wave(x, 44100) | nn.Sequential(*fs3())).ys
+    seq = x
+    for m in fs3():
+        m.fs = 44100
+        seq = m(seq)
+    for other in (b, c, seq):
+        close(other, a.numpy(), 1e-12)
+    chain = f[0] | f[1] | f[2]
+    assert isinstance(chain, fx.FilterChain) and len(chain) == 3
+    assert len((f[0] | f[1]) | (f[1] | f[2])) == 4                          # flattening
+    assert f[0].__or__(3) is NotImplemented
+    with pytest.raises(TypeError, match="nn.Module"):
+        fx.Wave(x, 44100) | 3
+
+
+def test_fused_cascade_validation():
+    with pytest.raises(ValueError, match="at least one"):
+        F.FusedSOSCascade()
+    with pytest.raises(ValueError, match="different sample rates"):
+        F.FusedSOSCascade(F.LoButterworth(100, fs=8000), F.LoButterworth(100, fs=16000))
+    with pytest.raises(ValueError, match="no sampling frequency"):
+        F.FusedSOSCascade(F.LoButterworth(100))
+    with pytest.raises(TypeError):
+        F.FusedSOSCascade(F.FIR([1.0]))
+    fz = F.FusedSOSCascade.from_chain(nn.Sequential(F.LoButterworth(100, order=2, fs=8000), F.FIR([1.0]),
+                                                    F.BiquadNotch(50, 5, fs=8000)))
+    assert fz._num_sections == 2
+
+
+def test_fir_run_merge_is_opt_in(oracle_backend, golden):
+    g = golden("chain")
+    from scipy.signal import firwin
+    irs = np.random.default_rng(1).standard_normal(4097) * np.exp(-np.arange(4097) / 500.0)
+    irs = irs / np.abs(irs).sum()
+
+    def pipe(fuse):
+        w = fx.Wave(g["xc"], 48000)
+        w.fuse_fir = fuse
+        return (w | F.LoButterworth(2000, order=6) | F.ParametricEQ(frequency=1000, q=2.0, gain=3.0)
+                | F.FIR(firwin(1024, 5000, fs=48000)) | F.FIR(irs))
+    assert len(pipe(False).plan()) == 3
+    close(pipe(False).ys, g["yc"], 2e-5)
+    wf = pipe(True)
+    plan = wf.plan()
+    assert len(plan) == 2 and plan[1].kernel.numel() == 1024 + 4097 - 1
+    close(wf.ys, g["yc"], 2e-5)                   # conv associativity: same result as staged
+
+
+# ------------------------------------------------------------------ parallel sum (a12)
+def test_parallel_combination(oracle_backend, golden):
+    g = golden("chain")
+    p1, p2 = F.LoButterworth(1000, order=2), F.HiButterworth(4000, order=2)
+    comb = p1 + p2
+    assert isinstance(comb, F.ParallelFilterCombination) and not comb._has_computed_coeff
+    w = fx.Wave(g["x"], 48000) | comb
+    assert p1.fs == 48000 and comb._has_computed_coeff
+    close(w.ys, g["y_par"], 1e-6)
+    nested = (F.LoButterworth(1000, order=2, fs=48000) + F.HiButterworth(4000, order=2, fs=48000)) | F.Notch(50, 3, fs=48000)
+    assert isinstance(nested, fx.FilterChain)
+
+
+# ------------------------------------------------------------------ FIR / fft_conv1d (a13, a14)
+def test_fir_forward_modes_and_shapes(oracle_backend, golden):
+    g = golden("fir")
+    x = torch.from_numpy(g["x"])
+    from scipy.signal import firwin
+    b = firwin(32, 5000, fs=48000)
+    for mode, key in (("fft", "fft32"), ("auto", "fft32"), ("direct", "direct32")):
+        y = F.FIR(b, conv_mode=mode)(x)
+        assert y.shape == x.shape and y.dtype == x.dtype
+        close(y, g[key], 2e-5)
+    assert F.FIR(b)(x[0]).shape == x[0].shape
+    assert F.FIR(b)(x[None]).shape == (1, *x.shape)
+    with pytest.raises(ValueError, match="shape"):
+        F.FIR(b)(torch.zeros(1, 1, 1, 8))
+    close(F.FIR(g["kt"][::-1].copy())(torch.from_numpy(g["xt"])), g["yt_fft"], 1e-12)    # f64, T < K
+
+
+def test_fft_conv1d_signature_and_errors(oracle_backend, golden):
+    from torchfx_amd.filter._fftconv import fft_conv1d
+    g = golden("fftconv")
+    x = torch.from_numpy(g["x"])[None]
+    y = fft_conv1d(x, torch.from_numpy(g["k16"])[None, None], padding=(8, 7))
+    assert tuple(y.shape) == (1, 2, 50000)
+    close(y[0], g["y16_pad87"], 2e-5)
+    with pytest.raises(RuntimeError, match="kernel size"):
+        fft_conv1d(x[..., :10], torch.ones(1, 1, 16))
+    with pytest.raises(RuntimeError, match="Block ratio"):
+        fft_conv1d(x, torch.ones(1, 1, 16), block_ratio=0.5)
+
+
+def test_ops_module_surface():
+    from torchfx_amd import _ops, torchfx_ext
+    assert _ops.PARALLEL_SCAN_THRESHOLD == 2048
+    for n in ("biquad_forward", "sos_forward", "delay_line_forward"):
+        assert hasattr(torchfx_ext, n)
+    assert fx.is_native_available() is True

@@ -1,0 +1,42 @@
+"""The oracle is test infrastructure: nothing under torchfx_amd/ (Python or HIP) may import,
+link or call it, and the product must not read /root/reference at run time."""
+import os
+import re
+
+from tests.conftest import ROOT
+
+
+def product_files():
+    for d, _, fs in os.walk(os.path.join(ROOT, "torchfx_amd")):
+        if "build" in d.split(os.sep):
+            continue
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                yield os.path.join(d, f)
+
+
+def test_product_never_touches_the_oracle_or_the_reference():
+    bad = re.compile(r"(^|\W)(import\s+oracle|from\s+oracle|liboracle|oracle/|/root/reference)")
+    for p in product_files():
+        for i, line in enumerate(open(p, encoding="utf-8", errors="replace"), 1):
+            code = line.split("#")[0] if p.endswith(".py") else line
+            assert not bad.search(code), f"{p}:{i}: {line.strip()}"
+
+
+def test_no_cpu_fallback_branches():
+    """torchfx_ext must not be able to compute on the host: no SciPy / torch.nn.functional /
+    torch.fft imports, and every op checks the device first."""
+    import ast
+    src = open(os.path.join(ROOT, "torchfx_amd", "torchfx_ext.py")).read()
+    tree = ast.parse(src)
+    mods = set()
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Import):
+            mods |= {a.name for a in node.names}
+        elif isinstance(node, ast.ImportFrom):
+            mods.add(node.module or "")
+    assert not any(m.startswith(("scipy", "torch.nn", "torch.fft", "oracle")) for m in mods), mods
+    ops = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name.endswith("_forward") and n.name != "sum_forward"]
+    assert len(ops) == 5
+    for fn in ops:
+        assert "require_device" in ast.unparse(fn), fn.name
