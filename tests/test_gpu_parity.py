@@ -349,3 +349,41 @@ def test_delay_and_passthrough(golden):
     y, sx, sy = ext().sos_forward(x, None, torch.tensor([[1., 0, 0, 1, 0, 0]]).double(), None, None)
     assert torch.equal(y, x)                # pass-through section is exact (test_ops_dispatch.py:45-52)
     assert sx.shape == (1, 2, 2)
+
+
+# ------------------------------------------------------------------ native LDS-FFT overlap-save
+@pytest.mark.parametrize("C,T,K", [(1, 70000, 4096), (3, 200001, 9000), (2, 300000, 16384),
+                                   (1, 262144, 65536), (3, 600000, 65536), (2, 700003, 66559),
+                                   (5, 400000, 40000)])
+def test_native_ols_vs_rocfft_and_f64(C, T, K, monkeypatch):
+    """The hand-written four-step pipeline (two frames per complex FFT) against the rocFFT path
+    and against a float64 FFT convolution; odd frame counts leave an unpaired frame."""
+    from scipy.signal import fftconvolve
+    rng = np.random.default_rng(K + T)
+    k = (rng.standard_normal(K) * np.exp(-np.arange(K) / (K / 6))).astype(np.float32)
+    k /= np.abs(k).sum()
+    x = rnd((C, T), T)
+    xd = dev(x)
+    monkeypatch.setenv("TFX_OLS_NATIVE", "1")
+    yn = ext().fft_conv_forward(xd, k[::-1].copy(), (K - 1, 0))
+    monkeypatch.setenv("TFX_OLS_NATIVE", "0")
+    yr = ext().fft_conv_forward(xd, k[::-1].copy(), (K - 1, 0))
+    exp = np.stack([fftconvolve(x[c].astype(np.float64), k.astype(np.float64))[:T] for c in range(C)])
+    close(yn, exp.astype(np.float32), 4e-6, "native vs f64")
+    close(yr, exp.astype(np.float32), 4e-6, "rocfft vs f64")
+    # and the native path is really the one that ran: different rounding than rocFFT
+    monkeypatch.setenv("TFX_OLS_PAIRS_PER_SLAB", "3")
+    monkeypatch.setenv("TFX_OLS_NATIVE", "1")
+    yn2 = ext().fft_conv_forward(xd, k[::-1].copy(), (K - 1, 0))
+    assert torch.equal(yn, yn2)          # slab size does not change results
+
+
+def test_native_ols_padding_variants(monkeypatch):
+    monkeypatch.setenv("TFX_OLS_NATIVE", "1")
+    K = 5000
+    k = rnd((K,), 1)
+    x = rnd((2, 150000), 2)
+    for pad in ((0, 0), (K - 1, 0), (100, 77), (0, K)):
+        y = ext().fft_conv_forward(dev(x), k, pad)
+        e = O.fft_conv1d(x.astype(np.float64), k.astype(np.float64), pad)
+        close(y, e.astype(np.float32), 2e-5, f"pad={pad}")

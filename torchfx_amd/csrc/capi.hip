@@ -23,6 +23,7 @@ void fir_clear();
 void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, const void *kernel_host,
                       int64_t K, int64_t pad_left, int64_t pad_right, hipStream_t stream);
 void fftconv_clear();
+void olsnative_clear();
 
 // ---- errors ------------------------------------------------------------------------------------
 static thread_local std::string t_last_error;
@@ -282,6 +283,7 @@ int tfx_clear_caches(void)
     sos_clear_plans();
     fir_clear();
     fftconv_clear();
+    olsnative_clear();
     scratch_clear();
     TFX_API_END
 }

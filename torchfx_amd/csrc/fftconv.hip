@@ -24,6 +24,11 @@
 
 namespace tfx {
 
+// olsnative.hip: hand-written LDS FFT passes for the long-kernel float32 case
+bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out);
+void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const float *kf_host, int64_t K,
+                       int64_t pl, int64_t pr, int64_t N, hipStream_t stream);
+
 #define TFX_ROCFFT(expr)                                                                     \
     do {                                                                                     \
         rocfft_status _s = (expr);                                                           \
@@ -292,6 +297,11 @@ void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, c
     TFX_CHECK(L >= K, "Input should be at least as large as the kernel size %lld, but it is only %lld samples long.",
               (long long)K, (long long)L);
     if (C == 0) return;
+    int64_t Nn = 0;
+    if (dtype == TFX_F32 && olsnative_supported(K, L, &Nn)) {
+        olsnative_forward((const float *)x, (float *)y, C, T, (const float *)kernel_host, K, pad_left, pad_right, Nn, stream);
+        return;
+    }
     if (dtype == TFX_F32)
         fft_conv_typed<float, float2>((const float *)x, (float *)y, dtype, C, T, kernel_host, K, pad_left, pad_right, stream);
     else

@@ -1,0 +1,465 @@
+// olsnative.hip -- overlap-save convolution with hand-written LDS-resident FFT passes (float32).
+//
+// Why: with rocFFT the 65536-tap case costs 5 launches per slab (frame, r2c, cmul, c2r, un-frame)
+// and ~95 B of HBM traffic per output sample.  Here the whole block pipeline is three kernels and
+// ~31 B/sample, with the framing, zero padding, spectrum multiply, 1/N scaling and the
+// "keep the first S samples" selection all fused into them:
+//
+//   * two real frames ride one complex transform:  z = frame_a + i frame_b.  The taps are real, so
+//     conv(z) = conv(a) + i conv(b): no real-FFT untangling pass, the spectrum multiply stays local.
+//   * N = N1 * N2 (N1 = 256) four-step decomposition, n = n1*N2 + n2, k = k1 + N1*k2:
+//       A  column FFTs over n1 (256-point, 32 adjacent columns per workgroup, data gathered
+//          straight from the signal with zero fill)                          -> T[k1][n2]
+//       B  per row k1: * W_N^(n2 k1), 1024-point FFT over n2, * Hp[k1][k2], inverse FFT,
+//          * conj(W_N^(n2 k1)); one wavefront per row, in place                -> T[k1][n2]
+//       C  column inverse FFTs over k1; real part -> frame_a's output samples, imaginary part ->
+//          frame_b's, only the first S = N-K+1 (valid) samples are stored      -> y
+//     Hp[k1][k2] = conj(FFT(kf_pad))[k1 + N1 k2] / N is precomputed once per filter on the host
+//     in float64.
+//   * every FFT is a radix-4 Stockham autosort in LDS; layouts are chosen so all LDS accesses of
+//     the column passes are conflict-free ([row][col] with the column on the lane index).
+//
+// Semantics = fft_conv1d (src/torchfx/filter/_fftconv.py:70-141): causal correlation with the
+// stored flipped kernel, output length T + l + r - K + 1.
+#include "common.h"
+#include "../../include/torchfx_hip.h"
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+namespace tfx {
+
+typedef float2 cpx;
+
+__device__ __forceinline__ cpx cmul(cpx a, cpx b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cpx cmulc(cpx a, cpx b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a*conj(b)
+__device__ __forceinline__ cpx cadd(cpx a, cpx b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cpx csub(cpx a, cpx b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+template <bool INV>
+__device__ __forceinline__ void dft4(cpx &a0, cpx &a1, cpx &a2, cpx &a3)
+{
+    const cpx s02 = cadd(a0, a2), d02 = csub(a0, a2), s13 = cadd(a1, a3), d13 = csub(a1, a3);
+    const cpx id = INV ? make_float2(-d13.y, d13.x) : make_float2(d13.y, -d13.x);   // (+i or -i) * d13
+    a0 = cadd(s02, s13);
+    a2 = csub(s02, s13);
+    a1 = cadd(d02, id);
+    a3 = csub(d02, id);
+}
+
+__device__ __forceinline__ void wave_sync2()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct OlsGeom {
+    int64_t Tn;        // input row length
+    int64_t Tout;      // output row length
+    int64_t F;         // frames per channel
+    int64_t S;         // hop = valid outputs per frame
+    int64_t pad_left;
+    int64_t nframes;   // C * F
+    int N2;            // row length (N = 256 * N2)
+};
+
+constexpr int OLS_N1 = 256;
+constexpr int OLS_CB = 32;      // columns per workgroup in the column passes
+
+// ---------------------------------------------------------------------------------------------
+// Column pass (A: forward from the signal, C: inverse to the output).  256 threads:
+// col = tid & 31, q = tid >> 5; thread owns butterflies j = q + 8 i (i < 8) of its column.
+// LDS: one [256][32] complex buffer (64 KB); stage inputs are read into registers, barrier,
+// outputs written, barrier.
+// ---------------------------------------------------------------------------------------------
+template <bool INV>
+__device__ __forceinline__ void col_stages(cpx (&v)[8][4], cpx *lds, const cpx *tw256, int col, int q)
+{
+    // stage 0 (Ns = 1): no twiddle
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dft4<INV>(v[i][0], v[i][1], v[i][2], v[i][3]);
+#pragma unroll
+    for (int s = 1; s < 4; ++s) {
+        const int Ns_prev = 1 << (2 * (s - 1));
+        const int Ns = Ns_prev * 4;
+        // write outputs of stage s-1:  rows j0 + r*Ns_prev,  j0 = (j / Ns_prev) * 4 Ns_prev + j % Ns_prev
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = q + 8 * i;
+            const int j0 = (j / Ns_prev) * (4 * Ns_prev) + (j % Ns_prev);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds[(j0 + r * Ns_prev) * OLS_CB + col] = v[i][r];
+        }
+        __syncthreads();
+        // read inputs of stage s: rows j + 64 r, twiddle W_{4Ns}^{r k}, k = j % Ns
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int j = q + 8 * i;
+            const int k = j % Ns;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                cpx x = lds[(j + 64 * r) * OLS_CB + col];
+                if (r > 0) {
+                    const cpx w = tw256[(r * k * (64 / Ns)) & 255];
+                    x = INV ? cmulc(x, w) : cmul(x, w);
+                }
+                v[i][r] = x;
+            }
+            dft4<INV>(v[i][0], v[i][1], v[i][2], v[i][3]);
+        }
+        __syncthreads();
+    }
+    // after the last stage (Ns = 64): thread holds rows j + 64 r in natural order
+}
+
+__global__ void __launch_bounds__(256, 2)
+ols_col_fwd_kernel(const float *__restrict__ x, cpx *__restrict__ T, const cpx *__restrict__ tw256g,
+                   OlsGeom g, int64_t frame0)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cpx *lds = (cpx *)smem;                    // [256][32]
+    cpx *tw256 = lds + OLS_N1 * OLS_CB;        // [256]
+    const int tid = threadIdx.x, col = tid & 31, q = tid >> 5;
+    tw256[tid] = tw256g[tid];
+    const int ncb = g.N2 / OLS_CB;
+    const int64_t pair = blockIdx.x / ncb;
+    const int cb = blockIdx.x % ncb;
+    const int n2 = cb * OLS_CB + col;
+    const int64_t fa = frame0 + 2 * pair, fb = fa + 1;
+    // frame -> (channel, frame-in-channel) -> first sample index in x
+    const int64_t ca = fa / g.F, ia0 = (fa % g.F) * g.S - g.pad_left;
+    const bool has_b = fb < g.nframes;
+    const int64_t cb_ = has_b ? fb / g.F : 0, ib0 = has_b ? (fb % g.F) * g.S - g.pad_left : 0;
+    const float *xa = x + ca * g.Tn, *xb = x + cb_ * g.Tn;
+
+    cpx v[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int j = q + 8 * i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t n = (int64_t)(j + 64 * r) * g.N2 + n2;
+            const int64_t ia = ia0 + n, ib = ib0 + n;
+            const float re = (ia >= 0 && ia < g.Tn) ? xa[ia] : 0.0f;
+            const float im = (has_b && ib >= 0 && ib < g.Tn) ? xb[ib] : 0.0f;
+            v[i][r] = make_float2(re, im);
+        }
+    }
+    __syncthreads();      // tw256 visible
+    col_stages<false>(v, lds, tw256, col, q);
+    cpx *Tp = T + pair * ((int64_t)OLS_N1 * g.N2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int j = q + 8 * i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tp[(int64_t)(j + 64 * r) * g.N2 + n2] = v[i][r];
+    }
+}
+
+__global__ void __launch_bounds__(256, 2)
+ols_col_inv_kernel(const cpx *__restrict__ T, float *__restrict__ y, const cpx *__restrict__ tw256g,
+                   OlsGeom g, int64_t frame0)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cpx *lds = (cpx *)smem;
+    cpx *tw256 = lds + OLS_N1 * OLS_CB;
+    const int tid = threadIdx.x, col = tid & 31, q = tid >> 5;
+    tw256[tid] = tw256g[tid];
+    const int ncb = g.N2 / OLS_CB;
+    const int64_t pair = blockIdx.x / ncb;
+    const int cb = blockIdx.x % ncb;
+    const int n2 = cb * OLS_CB + col;
+    const cpx *Tp = T + pair * ((int64_t)OLS_N1 * g.N2);
+    cpx v[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int j = q + 8 * i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[i][r] = Tp[(int64_t)(j + 64 * r) * g.N2 + n2];
+    }
+    __syncthreads();
+    col_stages<true>(v, lds, tw256, col, q);
+
+    const int64_t fa = frame0 + 2 * pair, fb = fa + 1;
+    const int64_t ca = fa / g.F, oa0 = (fa % g.F) * g.S;
+    const bool has_b = fb < g.nframes;
+    const int64_t cb_ = has_b ? fb / g.F : 0, ob0 = has_b ? (fb % g.F) * g.S : 0;
+    float *ya = y + ca * g.Tout, *yb = y + cb_ * g.Tout;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int j = q + 8 * i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t n = (int64_t)(j + 64 * r) * g.N2 + n2;
+            if (n < g.S) {                                   // valid part of the block
+                if (oa0 + n < g.Tout) ya[oa0 + n] = v[i][r].x;
+                if (has_b && ob0 + n < g.Tout) yb[ob0 + n] = v[i][r].y;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row pass B: one wavefront per row of N2 = 4^L2 points; lane owns butterflies j = lane + 64 i.
+// ---------------------------------------------------------------------------------------------
+template <int L2, bool INV>
+__device__ __forceinline__ void row_stages(cpx (&v)[(1 << (2 * L2)) / 256][4], cpx *lds, const cpx *twr, int lane)
+{
+    constexpr int N2 = 1 << (2 * L2), Q = N2 / 4, NB = Q / 64;     // NB butterflies per lane
+#pragma unroll
+    for (int i = 0; i < NB; ++i) dft4<INV>(v[i][0], v[i][1], v[i][2], v[i][3]);
+#pragma unroll
+    for (int s = 1; s < L2; ++s) {
+        const int Ns_prev = 1 << (2 * (s - 1));
+        const int Ns = Ns_prev * 4;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int j = lane + 64 * i;
+            const int j0 = (j / Ns_prev) * (4 * Ns_prev) + (j % Ns_prev);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds[j0 + r * Ns_prev] = v[i][r];
+        }
+        wave_sync2();
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int j = lane + 64 * i;
+            const int k = j % Ns;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                cpx x = lds[j + Q * r];
+                if (r > 0) {
+                    const cpx w = twr[(r * k * (Q / Ns)) & (N2 - 1)];
+                    x = INV ? cmulc(x, w) : cmul(x, w);
+                }
+                v[i][r] = x;
+            }
+            dft4<INV>(v[i][0], v[i][1], v[i][2], v[i][3]);
+        }
+        wave_sync2();
+    }
+}
+
+template <int L2>
+__global__ void __launch_bounds__(256)
+ols_row_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *__restrict__ twrg,
+               const cpx *__restrict__ tlo, const cpx *__restrict__ thi, int64_t nrows)
+{
+    constexpr int N2 = 1 << (2 * L2), Q = N2 / 4, NB = Q / 64;
+    constexpr int64_t N = (int64_t)OLS_N1 * N2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cpx *twr = (cpx *)smem;                      // [N2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    cpx *lds = twr + N2 + wave * N2;             // per-wave [N2]
+    for (int i = tid; i < N2; i += 256) twr[i] = twrg[i];
+    __syncthreads();
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= nrows) return;
+    const int k1 = (int)(row % OLS_N1);
+    cpx *base = T + row * N2;
+    const cpx *hrow = Hp + (int64_t)k1 * N2;
+
+    cpx v[NB][4], w[NB][4];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n2 = lane + 64 * i + Q * r;
+            const unsigned m = (unsigned)(((int64_t)k1 * n2) & (N - 1));
+            w[i][r] = cmul(tlo[m & 511], thi[m >> 9]);        // W_N^(k1 n2)
+            v[i][r] = cmul(base[n2], w[i][r]);
+        }
+    }
+    row_stages<L2, false>(v, lds, twr, lane);
+    // now v[i][r] = X[k2 = lane + 64 i + Q r]; multiply by the permuted, conjugated, scaled spectrum
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[i][r] = cmul(v[i][r], hrow[lane + 64 * i + Q * r]);
+    row_stages<L2, true>(v, lds, twr, lane);
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) base[lane + 64 * i + Q * r] = cmulc(v[i][r], w[i][r]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host: plan (tables + permuted spectrum) cache and orchestration
+// ---------------------------------------------------------------------------------------------
+struct NativePlan {
+    int64_t N = 0, K = 0;
+    int N2 = 0;
+    cpx *Hp = nullptr, *tw256 = nullptr, *twr = nullptr, *tlo = nullptr, *thi = nullptr;
+};
+static std::mutex g_np_mu;
+static std::map<std::vector<char>, NativePlan *> g_nplans;
+
+static void host_fft(std::vector<double> &re, std::vector<double> &im)   // in-place radix-2, forward
+{
+    const size_t n = re.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const double ang = -2.0 * M_PI / (double)len;
+        const size_t half = len / 2;
+        std::vector<double> wr(half), wi(half);
+        for (size_t k = 0; k < half; ++k) { wr[k] = cos(ang * (double)k); wi[k] = sin(ang * (double)k); }
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < half; ++k) {
+                const double ur = re[i + k], ui = im[i + k];
+                const double vr = re[i + k + half] * wr[k] - im[i + k + half] * wi[k];
+                const double vi = re[i + k + half] * wi[k] + im[i + k + half] * wr[k];
+                re[i + k] = ur + vr; im[i + k] = ui + vi;
+                re[i + k + half] = ur - vr; im[i + k + half] = ui - vi;
+            }
+    }
+}
+
+static cpx *upload_cpx(const std::vector<cpx> &h)
+{
+    cpx *d = nullptr;
+    TFX_HIP(hipMalloc((void **)&d, h.size() * sizeof(cpx)));
+    TFX_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(cpx), hipMemcpyHostToDevice));
+    return d;
+}
+static std::vector<cpx> twiddles(int64_t n, int64_t count, int64_t step)   // W_n^(step*i), i < count
+{
+    std::vector<cpx> t((size_t)count);
+    for (int64_t i = 0; i < count; ++i) {
+        const double a = -2.0 * M_PI * (double)((step * i) % n) / (double)n;
+        t[(size_t)i] = make_float2((float)cos(a), (float)sin(a));
+    }
+    return t;
+}
+
+static NativePlan *get_native_plan(const float *kf, int64_t K, int64_t N)
+{
+    std::vector<char> key((const char *)kf, (const char *)kf + K * sizeof(float));
+    key.insert(key.end(), (const char *)&N, (const char *)&N + sizeof(N));
+    auto it = g_nplans.find(key);
+    if (it != g_nplans.end()) return it->second;
+    if (g_nplans.size() > 16) {
+        (void)hipDeviceSynchronize();
+        for (auto &kv : g_nplans) {
+            NativePlan *p = kv.second;
+            for (cpx *q : {p->Hp, p->tw256, p->twr, p->tlo, p->thi}) if (q) (void)hipFree(q);
+            delete p;
+        }
+        g_nplans.clear();
+    }
+    NativePlan *pl = new NativePlan();
+    pl->N = N; pl->K = K; pl->N2 = (int)(N / OLS_N1);
+    // spectrum in float64: conj(FFT(kf zero-padded)) / N   (_fftconv.py:123-124,131 + irfft scaling)
+    std::vector<double> re((size_t)N, 0.0), im((size_t)N, 0.0);
+    for (int64_t i = 0; i < K; ++i) re[(size_t)i] = (double)kf[i];
+    host_fft(re, im);
+    std::vector<cpx> hp((size_t)N);
+    const int N2 = pl->N2;
+    for (int k1 = 0; k1 < OLS_N1; ++k1)
+        for (int k2 = 0; k2 < N2; ++k2) {
+            const size_t k = (size_t)k1 + (size_t)OLS_N1 * (size_t)k2;
+            hp[(size_t)k1 * N2 + k2] = make_float2((float)(re[k] / (double)N), (float)(-im[k] / (double)N));
+        }
+    pl->Hp = upload_cpx(hp);
+    pl->tw256 = upload_cpx(twiddles(256, 256, 1));
+    pl->twr = upload_cpx(twiddles(N2, N2, 1));
+    pl->tlo = upload_cpx(twiddles(N, 512, 1));
+    pl->thi = upload_cpx(twiddles(N, N / 512, 512));
+    g_nplans[key] = pl;
+    return pl;
+}
+
+void olsnative_clear()
+{
+    std::lock_guard<std::mutex> lk(g_np_mu);
+    (void)hipDeviceSynchronize();
+    for (auto &kv : g_nplans) {
+        NativePlan *p = kv.second;
+        for (cpx *q : {p->Hp, p->tw256, p->twr, p->tlo, p->thi}) if (q) (void)hipFree(q);
+        delete p;
+    }
+    g_nplans.clear();
+}
+
+static int64_t envi(const char *name, int64_t dflt)
+{
+    const char *e = getenv(name);
+    return (e && *e) ? atoll(e) : dflt;
+}
+
+// block sizes this path implements: N = 256 * 4^L2, L2 in {4, 5}
+bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out)
+{
+    if (envi("TFX_OLS_NATIVE", 1) == 0) return false;
+    int64_t N = 0;
+    const int64_t lg = envi("TFX_FFT_LOG2N", 0);
+    if (lg == 16 || lg == 18) N = (int64_t)1 << lg;
+    else if (lg != 0) return false;
+    else if (4 * K <= (1 << 16) && K >= 4096) N = 1 << 16;
+    else if (2 * K <= (1 << 18) && 4 * K > (1 << 16)) N = 1 << 18;
+    else return false;
+    if (N < 2 * K) return false;
+    if (L < N) return false;            // short signals: one small rocFFT block is cheaper
+    *N_out = N;
+    return true;
+}
+
+void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const float *kf_host, int64_t K,
+                       int64_t pl, int64_t pr, int64_t N, hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lk(g_np_mu);
+    NativePlan *plan = get_native_plan(kf_host, K, N);
+    OlsGeom g;
+    const int64_t L = Tn + pl + pr;
+    g.Tn = Tn; g.Tout = L - K + 1; g.S = N - K + 1; g.F = ceil_div(g.Tout, g.S);
+    g.pad_left = pl; g.nframes = C * g.F; g.N2 = plan->N2;
+    const int64_t npairs = ceil_div(g.nframes, 2);
+    int64_t slab = envi("TFX_OLS_PAIRS_PER_SLAB", 64);
+    if (slab < 1) slab = 1;
+    if (slab > npairs) slab = npairs;
+    cpx *T = (cpx *)scratch("olsn_T", (size_t)slab * (size_t)N * sizeof(cpx));
+    const size_t shm_col = (size_t)(OLS_N1 * OLS_CB + 256) * sizeof(cpx);
+    const size_t shm_row = (size_t)(g.N2 * 5) * sizeof(cpx);
+    static bool attr = false;
+    if (!attr) {
+        TFX_HIP(hipFuncSetAttribute((const void *)ols_col_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_col));
+        TFX_HIP(hipFuncSetAttribute((const void *)ols_col_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_col));
+        attr = true;
+    }
+    const int ncb = g.N2 / OLS_CB;
+    for (int64_t p0 = 0; p0 < npairs; p0 += slab) {
+        const int64_t np = (npairs - p0 < slab) ? (npairs - p0) : slab;
+        {
+            ProfScope ps("ols_col_fwd_kernel", stream);
+            hipLaunchKernelGGL(ols_col_fwd_kernel, dim3((unsigned)(np * ncb)), dim3(256), shm_col, stream,
+                               x, T, plan->tw256, g, 2 * p0);
+            TFX_HIP(hipGetLastError());
+        }
+        {
+            const int64_t nrows = np * OLS_N1;
+            ProfScope ps("ols_row_kernel", stream);
+            if (g.N2 == 1024)
+                hipLaunchKernelGGL(ols_row_kernel<5>, dim3((unsigned)ceil_div(nrows, 4)), dim3(256), shm_row, stream,
+                                   T, plan->Hp, plan->twr, plan->tlo, plan->thi, nrows);
+            else
+                hipLaunchKernelGGL(ols_row_kernel<4>, dim3((unsigned)ceil_div(nrows, 4)), dim3(256), shm_row, stream,
+                                   T, plan->Hp, plan->twr, plan->tlo, plan->thi, nrows);
+            TFX_HIP(hipGetLastError());
+        }
+        {
+            ProfScope ps("ols_col_inv_kernel", stream);
+            hipLaunchKernelGGL(ols_col_inv_kernel, dim3((unsigned)(np * ncb)), dim3(256), shm_col, stream,
+                               T, y, plan->tw256, g, 2 * p0);
+            TFX_HIP(hipGetLastError());
+        }
+    }
+}
+
+}  // namespace tfx
