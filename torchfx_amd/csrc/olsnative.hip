@@ -287,12 +287,139 @@ ols_row_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *__res
 }
 
 // ---------------------------------------------------------------------------------------------
+// Row pass B, N2 = 1024, radix (16, 16, 4) Stockham: the lane's 16 elements  n2 = lane + 64 t  are
+// exactly the inputs of one radix-16 butterfly, so two of the three stages run in registers and a
+// direction needs only two LDS exchanges (the radix-4 version above needs four).  LDS positions
+// are padded by one element per 16 so the stride-16 writes of the first stage are conflict-free.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int pad16(int p) { return p + (p >> 4); }
+
+template <bool INV>
+__device__ __forceinline__ void dft16(cpx (&v)[16])
+{
+    // t = t1 + 4 t2, k = 4 k1 + k2:  W16^(tk) = W4^(t1 k1) W16^(t1 k2) W4^(t2 k2)
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+#pragma unroll
+    for (int t1 = 0; t1 < 4; ++t1) dft4<INV>(v[t1], v[t1 + 4], v[t1 + 8], v[t1 + 12]);
+    // v[t1 + 4 k2] *= W16^(t1 k2)   (forward: exp(-i pi n/8); inverse: conjugate)
+    auto tw = [&](cpx &x, float c, float sn) {           // multiply by (c - i sn) forward, (c + i sn) inverse
+        const float s_ = INV ? -sn : sn;
+        x = make_float2(x.x * c + x.y * s_, x.y * c - x.x * s_);
+    };
+    tw(v[1 + 4], C1, S1);  tw(v[1 + 8], R2, R2);  tw(v[1 + 12], S1, C1);      // n = 1, 2, 3
+    tw(v[2 + 4], R2, R2);  tw(v[2 + 8], 0.f, 1.f); tw(v[2 + 12], -R2, R2);    // n = 2, 4, 6
+    tw(v[3 + 4], S1, C1);  tw(v[3 + 8], -R2, R2); tw(v[3 + 12], -C1, -S1);    // n = 3, 6, 9
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) dft4<INV>(v[4 * k2], v[4 * k2 + 1], v[4 * k2 + 2], v[4 * k2 + 3]);
+    // X[k] now sits at v[4 (k % 4) + k / 4]
+}
+#define DFT16_AT(k) (4 * ((k) & 3) + ((k) >> 2))
+
+// in: v[t] = element at position lane + 64 t (natural order).  out: same arrangement, transformed.
+template <bool INV>
+__device__ __forceinline__ void row_fft1024(cpx (&v)[16], cpx *lds, const cpx *twr, int lane)
+{
+    // stage A: radix 16, Ns = 1
+    dft16<INV>(v);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[pad16(16 * lane + k)] = v[DFT16_AT(k)];
+    wave_sync2();
+    // stage B: radix 16, Ns = 16: inputs lane + 64 t, twiddle W256^(t k), k = lane % 16
+    const int kb = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        cpx x = lds[pad16(lane + 64 * t)];
+        if (t > 0) {
+            const cpx w = twr[(4 * t * kb) & 1023];
+            x = INV ? cmulc(x, w) : cmul(x, w);
+        }
+        v[t] = x;
+        if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);    // bound the number of loads in flight
+    }
+    wave_sync2();
+    dft16<INV>(v);
+    const int j0 = (lane >> 4) * 256 + kb;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[pad16(j0 + 16 * k)] = v[DFT16_AT(k)];
+    wave_sync2();
+    // stage C: radix 4, Ns = 256: butterflies j = lane + 64 i, inputs j + 256 r, twiddle W1024^(r j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = lane + 64 * i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            cpx x = lds[pad16(j + 256 * r)];
+            if (r > 0) {
+                const cpx w = twr[(r * j) & 1023];
+                x = INV ? cmulc(x, w) : cmul(x, w);
+            }
+            v[i + 4 * r] = x;
+        }
+        dft4<INV>(v[i], v[i + 4], v[i + 8], v[i + 12]);     // outputs j + 256 r  ->  t = i + 4 r
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    wave_sync2();
+}
+
+__global__ void __launch_bounds__(256, 3)
+ols_row1024_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *__restrict__ twrg,
+                   const cpx *__restrict__ tlo, const cpx *__restrict__ thi, const cpx *__restrict__ tu,
+                   int64_t nrows, int64_t Nmask)
+{
+    constexpr int N2 = 1024, LDSROW = N2 + N2 / 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cpx *twr = (cpx *)smem;                      // [1024]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform, and the compiler knows it
+    cpx *lds = twr + N2 + wave * LDSROW;
+    for (int i = tid; i < N2; i += 256) twr[i] = twrg[i];
+    __syncthreads();
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= nrows) return;
+    const int k1 = (int)(row % OLS_N1);
+    cpx *base = T + row * N2;
+    const cpx *hrow = Hp + (int64_t)k1 * N2;
+    typedef const float __attribute__((address_space(4))) *cfp;
+    const cfp tuc = (cfp)(uintptr_t)tu;          // uniform per row: W_N^(64 k1 t) -> scalar loads
+
+    // W_N^(k1 n2), n2 = lane + 64 t  =  W_N^(k1 lane) * W_N^(64 k1 t)
+    const unsigned ml = (unsigned)(k1 * lane);
+    const cpx wl = cmul(tlo[ml & 511], thi[ml >> 9]);
+    cpx v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const unsigned iu = 2u * ((unsigned)(k1 * t) & (unsigned)(Nmask >> 6));
+        const cpx ut = make_float2(tuc[iu], tuc[iu + 1]);
+        v[t] = cmul(base[lane + 64 * t], cmul(wl, ut));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    row_fft1024<false>(v, lds, twr, lane);
+    __builtin_amdgcn_sched_barrier(0);      // keep the spectrum loads from being hoisted over the FFT
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = cmul(v[t], hrow[lane + 64 * t]);
+    __builtin_amdgcn_sched_barrier(0);
+    row_fft1024<true>(v, lds, twr, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    // recompute the row twiddles instead of keeping 16 of them live across both FFTs: the empty
+    // asm hides wl from common-subexpression elimination
+    float wlx = wl.x, wly = wl.y;
+    asm volatile("" : "+v"(wlx), "+v"(wly));
+    const cpx wl2 = make_float2(wlx, wly);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const unsigned iu = 2u * ((unsigned)(k1 * t) & (unsigned)(Nmask >> 6));
+        const cpx ut = make_float2(tuc[iu], tuc[iu + 1]);
+        base[lane + 64 * t] = cmulc(v[t], cmul(wl2, ut));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Host: plan (tables + permuted spectrum) cache and orchestration
 // ---------------------------------------------------------------------------------------------
 struct NativePlan {
     int64_t N = 0, K = 0;
     int N2 = 0;
-    cpx *Hp = nullptr, *tw256 = nullptr, *twr = nullptr, *tlo = nullptr, *thi = nullptr;
+    cpx *Hp = nullptr, *tw256 = nullptr, *twr = nullptr, *tlo = nullptr, *thi = nullptr, *tu = nullptr;
 };
 static std::mutex g_np_mu;
 static std::map<std::vector<char>, NativePlan *> g_nplans;
@@ -349,7 +476,7 @@ static NativePlan *get_native_plan(const float *kf, int64_t K, int64_t N)
         (void)hipDeviceSynchronize();
         for (auto &kv : g_nplans) {
             NativePlan *p = kv.second;
-            for (cpx *q : {p->Hp, p->tw256, p->twr, p->tlo, p->thi}) if (q) (void)hipFree(q);
+            for (cpx *q : {p->Hp, p->tw256, p->twr, p->tlo, p->thi, p->tu}) if (q) (void)hipFree(q);
             delete p;
         }
         g_nplans.clear();
@@ -372,6 +499,7 @@ static NativePlan *get_native_plan(const float *kf, int64_t K, int64_t N)
     pl->twr = upload_cpx(twiddles(N2, N2, 1));
     pl->tlo = upload_cpx(twiddles(N, 512, 1));
     pl->thi = upload_cpx(twiddles(N, N / 512, 512));
+    pl->tu = upload_cpx(twiddles(N, N / 64, 64));
     g_nplans[key] = pl;
     return pl;
 }
@@ -382,7 +510,7 @@ void olsnative_clear()
     (void)hipDeviceSynchronize();
     for (auto &kv : g_nplans) {
         NativePlan *p = kv.second;
-        for (cpx *q : {p->Hp, p->tw256, p->twr, p->tlo, p->thi}) if (q) (void)hipFree(q);
+        for (cpx *q : {p->Hp, p->tw256, p->twr, p->tlo, p->thi, p->tu}) if (q) (void)hipFree(q);
         delete p;
     }
     g_nplans.clear();
@@ -445,7 +573,11 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
         {
             const int64_t nrows = np * OLS_N1;
             ProfScope ps("ols_row_kernel", stream);
-            if (g.N2 == 1024)
+            if (g.N2 == 1024 && envi("TFX_OLS_ROW_R4", 0) == 0)
+                hipLaunchKernelGGL(ols_row1024_kernel, dim3((unsigned)ceil_div(nrows, 4)), dim3(256),
+                                   (size_t)(1024 + 4 * (1024 + 64)) * sizeof(cpx), stream,
+                                   T, plan->Hp, plan->twr, plan->tlo, plan->thi, plan->tu, nrows, N - 1);
+            else if (g.N2 == 1024)
                 hipLaunchKernelGGL(ols_row_kernel<5>, dim3((unsigned)ceil_div(nrows, 4)), dim3(256), shm_row, stream,
                                    T, plan->Hp, plan->twr, plan->tlo, plan->thi, nrows);
             else

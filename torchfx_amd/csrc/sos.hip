@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
     constexpr int EO = 16 / sizeof(TOut), NUO = LC / EO;  // (out)
 
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform -> SGPR addressing
     const int K = p.K;
     const int64_t sid = (int64_t)blockIdx.x * 4 + wave;
     if (sid >= p.C * p.nseg) return;                       // wave-uniform
@@ -257,6 +257,9 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
 
             // (3) add the homogeneous response of the true chunk-start state (h1,h2) =
             //     (y[-1], y[-2]): h[n] = -a1 h[n-1] - a2 h[n-2], run as a recurrence (no table)
+            //     (A two-step form h[n] = (a1^2-a2) h[n-2] + a1 a2 h[n-3] would halve the dependent
+            //     chain but adds the spurious characteristic root z = a1, |a1| up to 2: round-off
+            //     grows like 2^LC.  Not used.)
 #pragma unroll
             for (int n = 0; n < LC; ++n) {
                 const TC h = fma(na1, h1, na2 * h2);
@@ -593,18 +596,57 @@ static int device_cus()
     return g_cus;
 }
 
+// Time segmentation.  Streams are persistent (one wavefront walks its whole segment), so the
+// launch should be exactly ONE resident round: nstreams <= CUs x resident waves, otherwise the
+// second round doubles the time.  `resident_waves_per_cu` comes from the occupancy query of the
+// kernel actually launched.  Segments shorter than TFX_SOS_MIN_SEG_OVER_WARM x warm-up are not
+// worth their halo.
+static void plan_segments(SosParams &p, int64_t plan_warm, int TILE, int resident_waves_per_cu)
+{
+    const int64_t tiles_total = ceil_div(p.T, TILE);
+    int64_t nseg = 1, seg_len = tiles_total * TILE, warm = 0;
+    const int force_nseg = env_int("TFX_SOS_NSEG", 0);
+    if (plan_warm >= 0) {
+        warm = (plan_warm + 3) & ~(int64_t)3;
+        const int wpc = env_int("TFX_SOS_WAVES_PER_CU", 0);
+        const int64_t capacity = (int64_t)device_cus() * (wpc > 0 ? wpc : resident_waves_per_cu);
+        int64_t nseg_target = force_nseg > 0 ? force_nseg : capacity / p.C;      // floor: one round
+        if (nseg_target < 1) nseg_target = 1;
+        int64_t seg_tiles = ceil_div(tiles_total, nseg_target);
+        if (force_nseg <= 0) {
+            const int64_t min_tiles = ceil_div(env_int("TFX_SOS_MIN_SEG_OVER_WARM", 8) * warm, TILE);
+            if (seg_tiles < min_tiles) seg_tiles = min_tiles;
+        }
+        if (seg_tiles < 1) seg_tiles = 1;
+        nseg = ceil_div(tiles_total, seg_tiles);
+        seg_len = seg_tiles * TILE;
+        if (nseg == 1) warm = 0;
+    }
+    p.nseg = (int)nseg; p.seg_len = seg_len; p.warm = warm;
+}
+
 template <typename TIn, typename TOut, typename TC, int LC, bool VEC, bool TAPS, bool PF, int MINW>
-static void launch_one(const SosParams &p, int64_t nstreams, hipStream_t stream)
+static void launch_one(SosParams p, int64_t plan_warm, hipStream_t stream)
 {
     constexpr int IOB = sizeof(TIn) > sizeof(TOut) ? sizeof(TIn) : sizeof(TOut);
     constexpr int STAGE_B = 64 * (LC * IOB + 16);
     const int carry_b = (((p.K * 4 + 2 * LC) * (int)sizeof(TC)) + 15) & ~15;
     const size_t shmem = 4 * (size_t)(STAGE_B + carry_b);
     TFX_CHECK(shmem <= 160 * 1024, "sos_forward: K=%d needs %zu B of LDS (max 163840)", p.K, shmem);
-    const unsigned grid = (unsigned)ceil_div(nstreams, 4);
     auto kern = sos_stream_kernel<TIn, TOut, TC, LC, VEC, TAPS, PF, MINW>;
     if (shmem > 64 * 1024)
         TFX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    static int blocks_per_cu = 0;          // per template instance
+    static size_t blocks_shmem = 0;
+    if (!blocks_per_cu || blocks_shmem != shmem) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, 256, shmem) != hipSuccess || nb < 1) nb = 1;
+        blocks_per_cu = nb;
+        blocks_shmem = shmem;
+    }
+    plan_segments(p, plan_warm, 64 * LC, blocks_per_cu * 4);
+    const int64_t nstreams = p.C * p.nseg;
+    const unsigned grid = (unsigned)ceil_div(nstreams, 4);
     ProfScope ps(sizeof(TC) == 8 ? "sos_stream_kernel<f64>" : "sos_stream_kernel<f32>", stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, stream, p);
     TFX_HIP(hipGetLastError());
@@ -613,7 +655,7 @@ static void launch_one(const SosParams &p, int64_t nstreams, hipStream_t stream)
 // Variants (TFX_SOS_VARIANT): 0 = LC32, 1 = LC16, 2 = LC32 + register prefetch, 3 = LC16 + prefetch.
 // Register budgets (waves/SIMD) were chosen from -Rpass-analysis so that nothing spills.
 template <typename TIn, typename TOut, typename TC>
-static void launch_main(const SosParams &p, bool vec, int variant, int64_t nstreams, hipStream_t stream)
+static void launch_main(const SosParams &p, bool vec, int variant, int64_t nstreams, hipStream_t stream)   // nstreams = plan warm-up
 {
     constexpr bool F32 = sizeof(TC) == 4;
     if (p.taps || !vec) {     // debug taps / unaligned rows: plain dword path
@@ -627,15 +669,15 @@ static void launch_main(const SosParams &p, bool vec, int variant, int64_t nstre
         return;
     }
     switch (variant) {
-    case 1: launch_one<TIn, TOut, TC, 16, true, false, false, F32 ? 6 : 4>(p, nstreams, stream); break;
-    case 2: launch_one<TIn, TOut, TC, 32, true, false, true, F32 ? 3 : 2>(p, nstreams, stream); break;
-    case 3: launch_one<TIn, TOut, TC, 16, true, false, true, F32 ? 5 : 3>(p, nstreams, stream); break;
-    default: launch_one<TIn, TOut, TC, 32, true, false, false, F32 ? 4 : 3>(p, nstreams, stream); break;
+    case 1: launch_one<TIn, TOut, TC, 16, true, false, false, F32 ? 8 : 5>(p, nstreams, stream); break;
+    case 2: launch_one<TIn, TOut, TC, 32, true, false, true, F32 ? 4 : 2>(p, nstreams, stream); break;
+    case 3: launch_one<TIn, TOut, TC, 16, true, false, true, F32 ? 6 : 4>(p, nstreams, stream); break;
+    default: launch_one<TIn, TOut, TC, 32, true, false, false, F32 ? 5 : 3>(p, nstreams, stream); break;
     }
 }
 // rarely used dtype mixes: one configuration only
 template <typename TIn, typename TOut, typename TC>
-static void launch_rare(const SosParams &p, bool vec, int64_t nstreams, hipStream_t stream)
+static void launch_rare(const SosParams &p, bool vec, int64_t nstreams, hipStream_t stream)   // nstreams = plan warm-up
 {
     if (p.taps) launch_one<TIn, TOut, TC, 16, false, true, false, 3>(p, nstreams, stream);
     else if (vec) launch_one<TIn, TOut, TC, 16, true, false, false, 4>(p, nstreams, stream);
@@ -675,34 +717,13 @@ void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C, in
     const bool rare = !(x_dtype == TFX_F32 && y_dtype == TFX_F32);
 
     const int variant = rare ? 1 : env_int("TFX_SOS_VARIANT", 0);
-    const int LC = (variant & 1) ? 16 : 32, TILE = 64 * LC;
+    const int LC = (variant & 1) ? 16 : 32;
     SosParams p{};
     p.x = x; p.y = y; p.taps = y_sections;
     p.sx_in = sx_in; p.sy_in = sy_in; p.sx_out = sx_out; p.sy_out = sy_out;
     p.C = C; p.T = T; p.K = (int)K;
 
-    // ---- time segmentation
-    const int64_t tiles_total = ceil_div(T, TILE);
-    int64_t nseg = 1, seg_len = tiles_total * TILE, warm = 0;
-    const int force_nseg = env_int("TFX_SOS_NSEG", 0);
-    if (pl->warm >= 0) {
-        warm = (pl->warm + 3) & ~(int64_t)3;
-        const int waves_per_cu = env_int("TFX_SOS_WAVES_PER_CU", 16);
-        const int64_t target = (int64_t)device_cus() * waves_per_cu;
-        int64_t nseg_target = force_nseg > 0 ? force_nseg : (target + C - 1) / C;
-        if (nseg_target < 1) nseg_target = 1;
-        int64_t seg_tiles = ceil_div(tiles_total, nseg_target);
-        if (force_nseg <= 0) {
-            const int64_t min_tiles = ceil_div(env_int("TFX_SOS_MIN_SEG_OVER_WARM", 16) * warm, TILE);
-            if (seg_tiles < min_tiles) seg_tiles = min_tiles;
-        }
-        if (seg_tiles < 1) seg_tiles = 1;
-        nseg = ceil_div(tiles_total, seg_tiles);
-        seg_len = seg_tiles * TILE;
-        if (nseg == 1) warm = 0;
-    }
-    p.nseg = (int)nseg; p.seg_len = seg_len; p.warm = warm;
-    const int64_t nstreams = C * nseg;
+    const int64_t nstreams = pl->warm;     // segmentation is decided per kernel instance (launch_one)
 
     const int xsz = x_dtype == TFX_F32 ? 4 : 8, ysz = y_dtype == TFX_F32 ? 4 : 8;
     const bool vec = (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0) &&
