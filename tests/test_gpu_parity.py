@@ -354,7 +354,7 @@ def test_delay_and_passthrough(golden):
 # ------------------------------------------------------------------ native LDS-FFT overlap-save
 @pytest.mark.parametrize("C,T,K", [(1, 70000, 4096), (3, 200001, 9000), (2, 300000, 16384),
                                    (1, 262144, 65536), (3, 600000, 65536), (2, 700003, 66559),
-                                   (5, 400000, 40000)])
+                                   (5, 400000, 40000), (2, 2500000, 65536), (3, 1100000, 5000)])
 def test_native_ols_vs_rocfft_and_f64(C, T, K, monkeypatch):
     """The hand-written four-step pipeline (two frames per complex FFT) against the rocFFT path
     and against a float64 FFT convolution; odd frame counts leave an unpaired frame."""
@@ -376,6 +376,16 @@ def test_native_ols_vs_rocfft_and_f64(C, T, K, monkeypatch):
     monkeypatch.setenv("TFX_OLS_NATIVE", "1")
     yn2 = ext().fft_conv_forward(xd, k[::-1].copy(), (K - 1, 0))
     assert torch.equal(yn, yn2)          # slab size does not change results
+    # every block size the native path implements (256 x {256, 1024, 4096})
+    for lg in (16, 18, 20):
+        if (1 << lg) >= 2 * K and T + K - 1 >= (1 << lg):
+            monkeypatch.setenv("TFX_FFT_LOG2N", str(lg))
+            yl = ext().fft_conv_forward(xd, k[::-1].copy(), (K - 1, 0))
+            close(yl, exp.astype(np.float32), 4e-6, f"native log2N={lg} vs f64")
+    monkeypatch.setenv("TFX_OLS_ROW_R4", "1")          # the radix-4 row pass stays as a cross-check
+    monkeypatch.setenv("TFX_FFT_LOG2N", "18")
+    if (1 << 18) >= 2 * K and T + K - 1 >= (1 << 18):
+        close(ext().fft_conv_forward(xd, k[::-1].copy(), (K - 1, 0)), exp.astype(np.float32), 4e-6, "radix-4 rows")
 
 
 def test_native_ols_padding_variants(monkeypatch):

@@ -44,7 +44,7 @@ def main():
         print("plan", E.sos_plan_info(sos))
         for prec in ("f64", "f32"):
             for var in (0, 1, 2, 3):
-                for wpc in (8, 12, 16, 24, 32):
+                for wpc in (0, 8):
                     os.environ["TFX_SOS_VARIANT"] = str(var)
                     os.environ["TFX_SOS_WAVES_PER_CU"] = str(wpc)
                     wall, prof = timed(lambda: E.sos_forward(x, None, sos_t, None, None, precision=prec))

@@ -65,6 +65,7 @@ struct OlsGeom {
     int64_t pad_left;
     int64_t nframes;   // C * F
     int N2;            // row length (N = 256 * N2)
+    int P2;            // row pitch of the workspace T in elements (N2 + pad: breaks the power-of-two stride)
 };
 
 constexpr int OLS_N1 = 256;
@@ -151,12 +152,12 @@ ols_col_fwd_kernel(const float *__restrict__ x, cpx *__restrict__ T, const cpx *
     }
     __syncthreads();      // tw256 visible
     col_stages<false>(v, lds, tw256, col, q);
-    cpx *Tp = T + pair * ((int64_t)OLS_N1 * g.N2);
+    cpx *Tp = T + pair * ((int64_t)OLS_N1 * g.P2);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int j = q + 8 * i;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Tp[(int64_t)(j + 64 * r) * g.N2 + n2] = v[i][r];
+        for (int r = 0; r < 4; ++r) Tp[(int64_t)(j + 64 * r) * g.P2 + n2] = v[i][r];
     }
 }
 
@@ -173,13 +174,13 @@ ols_col_inv_kernel(const cpx *__restrict__ T, float *__restrict__ y, const cpx *
     const int64_t pair = blockIdx.x / ncb;
     const int cb = blockIdx.x % ncb;
     const int n2 = cb * OLS_CB + col;
-    const cpx *Tp = T + pair * ((int64_t)OLS_N1 * g.N2);
+    const cpx *Tp = T + pair * ((int64_t)OLS_N1 * g.P2);
     cpx v[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int j = q + 8 * i;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[i][r] = Tp[(int64_t)(j + 64 * r) * g.N2 + n2];
+        for (int r = 0; r < 4; ++r) v[i][r] = Tp[(int64_t)(j + 64 * r) * g.P2 + n2];
     }
     __syncthreads();
     col_stages<true>(v, lds, tw256, col, q);
@@ -246,7 +247,7 @@ __device__ __forceinline__ void row_stages(cpx (&v)[(1 << (2 * L2)) / 256][4], c
 template <int L2>
 __global__ void __launch_bounds__(256)
 ols_row_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *__restrict__ twrg,
-               const cpx *__restrict__ tlo, const cpx *__restrict__ thi, int64_t nrows)
+               const cpx *__restrict__ tlo, const cpx *__restrict__ thi, int64_t nrows, int P2)
 {
     constexpr int N2 = 1 << (2 * L2), Q = N2 / 4, NB = Q / 64;
     constexpr int64_t N = (int64_t)OLS_N1 * N2;
@@ -259,7 +260,7 @@ ols_row_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *__res
     const int64_t row = (int64_t)blockIdx.x * 4 + wave;
     if (row >= nrows) return;
     const int k1 = (int)(row % OLS_N1);
-    cpx *base = T + row * N2;
+    cpx *base = T + row * P2;
     const cpx *hrow = Hp + (int64_t)k1 * N2;
 
     cpx v[NB][4], w[NB][4];
@@ -364,7 +365,7 @@ __device__ __forceinline__ void row_fft1024(cpx (&v)[16], cpx *lds, const cpx *t
 __global__ void __launch_bounds__(256, 3)
 ols_row1024_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *__restrict__ twrg,
                    const cpx *__restrict__ tlo, const cpx *__restrict__ thi, const cpx *__restrict__ tu,
-                   int64_t nrows, int64_t Nmask)
+                   int64_t nrows, int64_t Nmask, int P2)
 {
     constexpr int N2 = 1024, LDSROW = N2 + N2 / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -377,7 +378,7 @@ ols_row1024_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *_
     const int64_t row = (int64_t)blockIdx.x * 4 + wave;
     if (row >= nrows) return;
     const int k1 = (int)(row % OLS_N1);
-    cpx *base = T + row * N2;
+    cpx *base = T + row * P2;
     const cpx *hrow = Hp + (int64_t)k1 * N2;
     typedef const float __attribute__((address_space(4))) *cfp;
     const cfp tuc = (cfp)(uintptr_t)tu;          // uniform per row: W_N^(64 k1 t) -> scalar loads
@@ -414,12 +415,109 @@ ols_row1024_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Row pass B, N2 = 4096 (N = 2^20: 93.6 % of every block is valid output at K = 65536 instead of
+// 74.6 % at N = 2^18).  One workgroup per row, thread j owns elements n2 = j + 256 t: radix
+// (16, 16, 16) Stockham, three register stages and two LDS exchanges per direction.
+// ---------------------------------------------------------------------------------------------
+template <bool INV>
+__device__ __forceinline__ void row_fft4096(cpx (&v)[16], cpx *lds, const cpx *tw256, const cpx *t4lo,
+                                            const cpx *t4hi, int j)
+{
+    dft16<INV>(v);                                             // stage A, Ns = 1
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[pad16(16 * j + k)] = v[DFT16_AT(k)];
+    __syncthreads();
+    const int kb = j & 15;                                     // stage B, Ns = 16: twiddle W256^(t kb)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        cpx x = lds[pad16(j + 256 * t)];
+        if (t > 0) {
+            const cpx w = tw256[(t * kb) & 255];
+            x = INV ? cmulc(x, w) : cmul(x, w);
+        }
+        v[t] = x;
+    }
+    __syncthreads();
+    dft16<INV>(v);
+    const int j0 = (j >> 4) * 256 + kb;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[pad16(j0 + 16 * k)] = v[DFT16_AT(k)];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {                             // stage C, Ns = 256: twiddle W4096^(t j)
+        cpx x = lds[pad16(j + 256 * t)];
+        if (t > 0) {
+            const unsigned m = (unsigned)(t * j) & 4095u;
+            const cpx w = cmul(t4lo[m & 63], t4hi[m >> 6]);
+            x = INV ? cmulc(x, w) : cmul(x, w);
+        }
+        v[t] = x;
+    }
+    __syncthreads();
+    dft16<INV>(v);
+    // natural order: X[j + 256 k] = v[DFT16_AT(k)]
+    cpx o[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) o[k] = v[DFT16_AT(k)];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = o[k];
+}
+
+__global__ void __launch_bounds__(256, 3)
+ols_row4096_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *__restrict__ tw256g,
+                   const cpx *__restrict__ t4log, const cpx *__restrict__ t4hig,
+                   const cpx *__restrict__ tlo, const cpx *__restrict__ thi, const cpx *__restrict__ tu,
+                   int64_t Nmask, int P2)
+{
+    constexpr int N2 = 4096;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cpx *lds = (cpx *)smem;                      // [4096 + 256]
+    cpx *tw256 = lds + N2 + N2 / 16;             // [256]
+    cpx *t4lo = tw256 + 256, *t4hi = t4lo + 64;  // [64] [64]
+    const int j = threadIdx.x;
+    tw256[j] = tw256g[j];
+    if (j < 64) { t4lo[j] = t4log[j]; t4hi[j] = t4hig[j]; }
+    const int64_t row = blockIdx.x;
+    const int k1 = (int)(row % OLS_N1);
+    cpx *base = T + row * P2;
+    const cpx *hrow = Hp + (int64_t)k1 * N2;
+    typedef const float __attribute__((address_space(4))) *cfp;
+    const cfp tuc = (cfp)(uintptr_t)tu;          // uniform per row: W_N^(256 k1 t)
+    const unsigned ml = (unsigned)(k1 * j);
+    const cpx wl = cmul(tlo[ml & 511], thi[ml >> 9]);
+    const unsigned umask = (unsigned)(Nmask >> 8);
+    cpx v[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const unsigned iu = 2u * ((unsigned)(k1 * t) & umask);
+        const cpx ut = make_float2(tuc[iu], tuc[iu + 1]);
+        v[t] = cmul(base[j + 256 * t], cmul(wl, ut));
+    }
+    __syncthreads();                             // tables visible
+    row_fft4096<false>(v, lds, tw256, t4lo, t4hi, j);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = cmul(v[t], hrow[j + 256 * t]);
+    __builtin_amdgcn_sched_barrier(0);
+    row_fft4096<true>(v, lds, tw256, t4lo, t4hi, j);
+    float wlx = wl.x, wly = wl.y;
+    asm volatile("" : "+v"(wlx), "+v"(wly));     // recompute, do not keep 16 twiddles live (see row1024)
+    const cpx wl2 = make_float2(wlx, wly);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const unsigned iu = 2u * ((unsigned)(k1 * t) & umask);
+        const cpx ut = make_float2(tuc[iu], tuc[iu + 1]);
+        base[j + 256 * t] = cmulc(v[t], cmul(wl2, ut));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Host: plan (tables + permuted spectrum) cache and orchestration
 // ---------------------------------------------------------------------------------------------
 struct NativePlan {
     int64_t N = 0, K = 0;
     int N2 = 0;
-    cpx *Hp = nullptr, *tw256 = nullptr, *twr = nullptr, *tlo = nullptr, *thi = nullptr, *tu = nullptr;
+    cpx *Hp = nullptr, *tw256 = nullptr, *twr = nullptr, *tlo = nullptr, *thi = nullptr, *tu = nullptr, *t4lo = nullptr, *t4hi = nullptr;
 };
 static std::mutex g_np_mu;
 static std::map<std::vector<char>, NativePlan *> g_nplans;
@@ -476,7 +574,7 @@ static NativePlan *get_native_plan(const float *kf, int64_t K, int64_t N)
         (void)hipDeviceSynchronize();
         for (auto &kv : g_nplans) {
             NativePlan *p = kv.second;
-            for (cpx *q : {p->Hp, p->tw256, p->twr, p->tlo, p->thi, p->tu}) if (q) (void)hipFree(q);
+            for (cpx *q : {p->Hp, p->tw256, p->twr, p->tlo, p->thi, p->tu, p->t4lo, p->t4hi}) if (q) (void)hipFree(q);
             delete p;
         }
         g_nplans.clear();
@@ -499,7 +597,10 @@ static NativePlan *get_native_plan(const float *kf, int64_t K, int64_t N)
     pl->twr = upload_cpx(twiddles(N2, N2, 1));
     pl->tlo = upload_cpx(twiddles(N, 512, 1));
     pl->thi = upload_cpx(twiddles(N, N / 512, 512));
-    pl->tu = upload_cpx(twiddles(N, N / 64, 64));
+    // row-uniform factors: W_N^(64 i) for the 1024-point rows, W_N^(256 i) for the 4096-point rows
+    pl->tu = (N2 == 4096) ? upload_cpx(twiddles(N, N / 256, 256)) : upload_cpx(twiddles(N, N / 64, 64));
+    pl->t4lo = upload_cpx(twiddles(4096, 64, 1));
+    pl->t4hi = upload_cpx(twiddles(4096, 64, 64));
     g_nplans[key] = pl;
     return pl;
 }
@@ -510,7 +611,7 @@ void olsnative_clear()
     (void)hipDeviceSynchronize();
     for (auto &kv : g_nplans) {
         NativePlan *p = kv.second;
-        for (cpx *q : {p->Hp, p->tw256, p->twr, p->tlo, p->thi, p->tu}) if (q) (void)hipFree(q);
+        for (cpx *q : {p->Hp, p->tw256, p->twr, p->tlo, p->thi, p->tu, p->t4lo, p->t4hi}) if (q) (void)hipFree(q);
         delete p;
     }
     g_nplans.clear();
@@ -522,19 +623,25 @@ static int64_t envi(const char *name, int64_t dflt)
     return (e && *e) ? atoll(e) : dflt;
 }
 
-// block sizes this path implements: N = 256 * 4^L2, L2 in {4, 5}
+// block sizes this path implements: N = 256 * N2, N2 in {256, 1024, 4096}
 bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out)
 {
     if (envi("TFX_OLS_NATIVE", 1) == 0) return false;
     int64_t N = 0;
     const int64_t lg = envi("TFX_FFT_LOG2N", 0);
-    if (lg == 16 || lg == 18) N = (int64_t)1 << lg;
+    if (lg == 16 || lg == 18 || lg == 20) N = (int64_t)1 << lg;
     else if (lg != 0) return false;
-    else if (4 * K <= (1 << 16) && K >= 4096) N = 1 << 16;
-    else if (2 * K <= (1 << 18) && 4 * K > (1 << 16)) N = 1 << 18;
+    else if (K < 4096) return false;                    // short kernels: rocFFT's single-kernel plans win
+    else if (4 * K <= (1 << 16)) N = 1 << 16;
+    else if (2 * K <= (1 << 18) && L < 4 * ((int64_t)1 << 20)) N = 1 << 18;
+    else if (2 * K <= (1 << 20)) N = (int64_t)1 << 20;  // long signals: 4x fewer blocks, less overlap
     else return false;
     if (N < 2 * K) return false;
-    if (L < N) return false;            // short signals: one small rocFFT block is cheaper
+    if (L < N) {                                        // signal shorter than one block
+        if (lg != 0) return false;
+        while (N > (1 << 16) && L < N) N >>= 2;
+        if (L < N || N < 2 * K) return false;
+    }
     *N_out = N;
     return true;
 }
@@ -548,15 +655,18 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     const int64_t L = Tn + pl + pr;
     g.Tn = Tn; g.Tout = L - K + 1; g.S = N - K + 1; g.F = ceil_div(g.Tout, g.S);
     g.pad_left = pl; g.nframes = C * g.F; g.N2 = plan->N2;
+    g.P2 = g.N2 + (int)envi("TFX_OLS_PITCH_PAD", 32);
     const int64_t npairs = ceil_div(g.nframes, 2);
-    int64_t slab = envi("TFX_OLS_PAIRS_PER_SLAB", 64);
+    int64_t slab = envi("TFX_OLS_PAIRS_PER_SLAB", 0);
+    if (slab <= 0) slab = (envi("TFX_OLS_SLAB_MB", 128) << 20) / ((int64_t)OLS_N1 * g.P2 * (int64_t)sizeof(cpx));
     if (slab < 1) slab = 1;
     if (slab > npairs) slab = npairs;
-    cpx *T = (cpx *)scratch("olsn_T", (size_t)slab * (size_t)N * sizeof(cpx));
+    cpx *T = (cpx *)scratch("olsn_T", (size_t)slab * (size_t)OLS_N1 * (size_t)g.P2 * sizeof(cpx));
     const size_t shm_col = (size_t)(OLS_N1 * OLS_CB + 256) * sizeof(cpx);
     const size_t shm_row = (size_t)(g.N2 * 5) * sizeof(cpx);
     static bool attr = false;
     if (!attr) {
+        TFX_HIP(hipFuncSetAttribute((const void *)ols_row4096_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 256 + 128) * sizeof(cpx))));
         TFX_HIP(hipFuncSetAttribute((const void *)ols_col_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_col));
         TFX_HIP(hipFuncSetAttribute((const void *)ols_col_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_col));
         attr = true;
@@ -573,16 +683,20 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
         {
             const int64_t nrows = np * OLS_N1;
             ProfScope ps("ols_row_kernel", stream);
-            if (g.N2 == 1024 && envi("TFX_OLS_ROW_R4", 0) == 0)
+            if (g.N2 == 4096)
+                hipLaunchKernelGGL(ols_row4096_kernel, dim3((unsigned)nrows), dim3(256),
+                                   (size_t)(4096 + 256 + 256 + 128) * sizeof(cpx), stream,
+                                   T, plan->Hp, plan->tw256, plan->t4lo, plan->t4hi, plan->tlo, plan->thi, plan->tu, N - 1, g.P2);
+            else if (g.N2 == 1024 && envi("TFX_OLS_ROW_R4", 0) == 0)
                 hipLaunchKernelGGL(ols_row1024_kernel, dim3((unsigned)ceil_div(nrows, 4)), dim3(256),
                                    (size_t)(1024 + 4 * (1024 + 64)) * sizeof(cpx), stream,
-                                   T, plan->Hp, plan->twr, plan->tlo, plan->thi, plan->tu, nrows, N - 1);
+                                   T, plan->Hp, plan->twr, plan->tlo, plan->thi, plan->tu, nrows, N - 1, g.P2);
             else if (g.N2 == 1024)
                 hipLaunchKernelGGL(ols_row_kernel<5>, dim3((unsigned)ceil_div(nrows, 4)), dim3(256), shm_row, stream,
-                                   T, plan->Hp, plan->twr, plan->tlo, plan->thi, nrows);
+                                   T, plan->Hp, plan->twr, plan->tlo, plan->thi, nrows, g.P2);
             else
                 hipLaunchKernelGGL(ols_row_kernel<4>, dim3((unsigned)ceil_div(nrows, 4)), dim3(256), shm_row, stream,
-                                   T, plan->Hp, plan->twr, plan->tlo, plan->thi, nrows);
+                                   T, plan->Hp, plan->twr, plan->tlo, plan->thi, nrows, g.P2);
             TFX_HIP(hipGetLastError());
         }
         {

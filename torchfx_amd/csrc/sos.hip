@@ -60,6 +60,27 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// DPP shift of a value across lanes; lanes with no source lane receive 0.
+template <int CTRL> __device__ __forceinline__ float dpp_shift(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL> __device__ __forceinline__ double dpp_shift(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float read_lane(float v, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ __forceinline__ double read_lane(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                            __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
 template <typename T> struct U16 {               // 16 bytes of T
     static constexpr int N = 16 / sizeof(T);
     union { uint4 u; T e[N]; };
@@ -241,19 +262,51 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
                 if ((n & (SB - 1)) == SB - 1) __builtin_amdgcn_sched_barrier(0);
             }
 
-            // (2) inclusive scan of chunk end-states over lanes:  S_j = sum_i P^(j-i) z_i
-            TC s0 = u1, s1 = u2;
+            // (2) inclusive scan of chunk end-states over lanes:  S_j = sum_i P^(j-i) z_i, then the
+            //     exclusive shift (h1,h2) = S_{j-1}.  All cross-lane traffic is DPP (row_shr within a
+            //     16-lane row, v_readlane for the three row aggregates, wave_shr:1 for the final
+            //     shift): a few cycles of latency per step instead of an LDS round trip per
+            //     ds_bpermute -- the kernel is latency-bound, not issue-bound.
+            //       a. intra-row Kogge-Stone with P^1, P^2, P^4, P^8 (lanes without a source add 0)
+            //       b. row aggregates R_r = I at lane 16r+15; E_1 = R_0, E_r = R_{r-1} + P^16 E_{r-1}
+            //       c. effect of E_r on lane p of row r is P^(p+1) E_r: binary expansion of p with
+            //          the same P^(2^k) matrices, no shuffles
             const ctab_t pm = tb + 8;
-            for (int k = 0; k < p.nsteps; ++k) {
-                const int dd = 1 << k;
-                const TC t0 = __shfl_up(s0, dd);
-                const TC t1 = __shfl_up(s1, dd);
-                const TC a0 = fma(pm[4 * k + 0], t0, pm[4 * k + 1] * t1);
-                const TC a1 = fma(pm[4 * k + 2], t0, pm[4 * k + 3] * t1);
-                if (lane >= dd) { s0 += a0; s1 += a1; }
+            TC s0 = u1, s1 = u2;
+#define TFX_KS_STEP(K_, CTRL_)                                                            \
+            {                                                                             \
+                const TC t0 = dpp_shift<CTRL_>(s0), t1 = dpp_shift<CTRL_>(s1);            \
+                s0 += fma(pm[4 * K_ + 0], t0, pm[4 * K_ + 1] * t1);                       \
+                s1 += fma(pm[4 * K_ + 2], t0, pm[4 * K_ + 3] * t1);                       \
             }
-            TC h1 = __shfl_up(s0, 1), h2 = __shfl_up(s1, 1);
-            if (lane == 0) { h1 = (TC)0; h2 = (TC)0; }
+            TFX_KS_STEP(0, 0x111)   // row_shr:1
+            TFX_KS_STEP(1, 0x112)   // row_shr:2
+            TFX_KS_STEP(2, 0x114)   // row_shr:4
+            TFX_KS_STEP(3, 0x118)   // row_shr:8
+#undef TFX_KS_STEP
+            {
+                const TC r00 = read_lane(s0, 15), r01 = read_lane(s1, 15);
+                const TC r10 = read_lane(s0, 31), r11 = read_lane(s1, 31);
+                const TC r20 = read_lane(s0, 47), r21 = read_lane(s1, 47);
+                const TC p00 = pm[16], p01 = pm[17], p10 = pm[18], p11 = pm[19];      // P^16
+                const TC e20 = r10 + fma(p00, r00, p01 * r01), e21 = r11 + fma(p10, r00, p11 * r01);
+                const TC e30 = r20 + fma(p00, e20, p01 * e21), e31 = r21 + fma(p10, e20, p11 * e21);
+                const int row = lane >> 4, pp = lane & 15;
+                TC e0 = row == 1 ? r00 : (row == 2 ? e20 : e30);
+                TC e1 = row == 1 ? r01 : (row == 2 ? e21 : e31);
+                if (row == 0) { e0 = (TC)0; e1 = (TC)0; }
+                // q = P^(pp+1) e
+                TC q0 = fma(pm[0], e0, pm[1] * e1), q1 = fma(pm[2], e0, pm[3] * e1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const TC n0 = fma(pm[4 * k + 0], q0, pm[4 * k + 1] * q1);
+                    const TC n1 = fma(pm[4 * k + 2], q0, pm[4 * k + 3] * q1);
+                    if (pp & (1 << k)) { q0 = n0; q1 = n1; }
+                }
+                s0 += q0;
+                s1 += q1;
+            }
+            TC h1 = dpp_shift<0x138>(s0), h2 = dpp_shift<0x138>(s1);     // wave_shr:1, lane 0 gets 0
 
             // (3) add the homogeneous response of the true chunk-start state (h1,h2) =
             //     (y[-1], y[-2]): h[n] = -a1 h[n-1] - a2 h[n-2], run as a recurrence (no table)
@@ -716,7 +769,7 @@ void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C, in
     if (x_dtype == TFX_F64 || y_dtype == TFX_F64) prec = TFX_PREC_F64;   // f64 signals: always f64 math
     const bool rare = !(x_dtype == TFX_F32 && y_dtype == TFX_F32);
 
-    const int variant = rare ? 1 : env_int("TFX_SOS_VARIANT", 0);
+    const int variant = rare ? 1 : env_int("TFX_SOS_VARIANT", 2);   // 2 = LC32 + register prefetch: measured best
     const int LC = (variant & 1) ? 16 : 32;
     SosParams p{};
     p.x = x; p.y = y; p.taps = y_sections;
