@@ -8,8 +8,8 @@ x = torch.randn(C, T, device="cuda:0")
 ir = np.random.default_rng(0).standard_normal(K) * np.exp(-np.arange(K) / 8000.0)
 k = (ir / np.abs(ir).sum()).astype(np.float32)[::-1].copy()
 for lg in (18, 20):
-    for pad in (0, 32, 8):
+    for r4 in (0, 1):
         os.environ["TFX_FFT_LOG2N"] = str(lg)
-        os.environ["TFX_OLS_PITCH_PAD"] = str(pad)
-        wall, prof = timed(lambda: E.fft_conv_forward(x, k, (K - 1, 0)), reps=2, warm=1)
-        print(f"log2N={lg} pitchpad={pad:3d}: wall {wall:7.3f} ms  {C*T/wall/1e3:9.1f} Msamp/s  " + " ".join(f"{n.replace('_kernel','')}={v:.2f}" for n, v in prof.items()), flush=True)
+        os.environ["TFX_OLS_COL_R4"] = str(r4)
+        wall, prof = timed(lambda: E.fft_conv_forward(x, k, (K - 1, 0)), reps=3, warm=1)
+        print(f"log2N={lg} col_r4={r4}: wall {wall:7.3f} ms  {C*T/wall/1e3:9.1f} Msamp/s  " + " ".join(f"{n.replace('_kernel','')}={v:.2f}" for n, v in prof.items()), flush=True)

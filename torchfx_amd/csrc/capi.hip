@@ -30,33 +30,52 @@ static thread_local std::string t_last_error;
 void set_last_error(const std::string &msg) { t_last_error = msg; }
 
 // ---- profiling -----------------------------------------------------------------------------------
+// Low-overhead per-kernel timing: events come from a pool (no create/destroy per launch) and
+// consecutive launches inside one API call share the boundary event (end of A == begin of B),
+// so a launch costs one hipEventRecord.
 struct ProfRec {
-    std::string name;
+    const char *name;      // string literals only
     hipEvent_t a, b;
 };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
-static std::vector<ProfRec> g_open;
+static std::vector<hipEvent_t> g_pool;         // free events
+static std::vector<hipEvent_t> g_used;         // to be recycled at collect
+static const char *g_open_name = nullptr;
+static hipEvent_t g_open_a = nullptr;
+static hipEvent_t g_last_end = nullptr;        // reusable as the next begin while g_chain is true
+static bool g_chain = false;
 
+static hipEvent_t pool_get()
+{
+    hipEvent_t e = nullptr;
+    if (!g_pool.empty()) { e = g_pool.back(); g_pool.pop_back(); }
+    else if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    g_used.push_back(e);
+    return e;
+}
 bool prof_on() { return g_prof_on; }
+void prof_break_chain() { g_chain = false; }
 void prof_begin(const char *name, hipStream_t s)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    ProfRec r;
-    r.name = name;
-    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
-    (void)hipEventRecord(r.a, s);
-    g_open.push_back(r);
+    g_open_name = name;
+    if (g_chain && g_last_end) { g_open_a = g_last_end; return; }
+    g_open_a = pool_get();
+    if (g_open_a) (void)hipEventRecord(g_open_a, s);
 }
 void prof_end(hipStream_t s)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (g_open.empty()) return;
-    ProfRec r = g_open.back();
-    g_open.pop_back();
-    (void)hipEventRecord(r.b, s);
-    g_prof.push_back(r);
+    if (!g_open_name || !g_open_a) return;
+    hipEvent_t b = pool_get();
+    if (!b) return;
+    (void)hipEventRecord(b, s);
+    g_prof.push_back(ProfRec{g_open_name, g_open_a, b});
+    g_last_end = b;
+    g_chain = true;
+    g_open_name = nullptr;
 }
 
 // ---- scratch -------------------------------------------------------------------------------------
@@ -129,7 +148,7 @@ __global__ void __launch_bounds__(256) sum_kernel(SumArgs a, T *__restrict__ y, 
 
 using namespace tfx;
 
-#define TFX_API_BEGIN try {
+#define TFX_API_BEGIN try { prof_break_chain();
 #define TFX_API_END                                                                           \
     return 0;                                                                                 \
     }                                                                                         \
@@ -260,10 +279,12 @@ const char *tfx_prof_collect(void)
             agg[r.name].first += 1;
             agg[r.name].second += ms;
         }
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
     }
     g_prof.clear();
+    for (hipEvent_t e : g_used) g_pool.push_back(e);
+    g_used.clear();
+    g_last_end = nullptr;
+    g_chain = false;
     out = "{";
     bool first = true;
     for (auto &n : order) {

@@ -41,6 +41,7 @@ void set_last_error(const std::string &msg);
 bool prof_on();
 void prof_begin(const char *name, hipStream_t s);
 void prof_end(hipStream_t s);
+void prof_break_chain();   // called at every API entry: events are only shared inside one call
 
 struct ProfScope {
     hipStream_t s;

@@ -71,6 +71,30 @@ struct OlsGeom {
 constexpr int OLS_N1 = 256;
 constexpr int OLS_CB = 32;      // columns per workgroup in the column passes
 
+__device__ __forceinline__ int pad16(int p) { return p + (p >> 4); }
+
+template <bool INV>
+__device__ __forceinline__ void dft16(cpx (&v)[16])
+{
+    // t = t1 + 4 t2, k = 4 k1 + k2:  W16^(tk) = W4^(t1 k1) W16^(t1 k2) W4^(t2 k2)
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+#pragma unroll
+    for (int t1 = 0; t1 < 4; ++t1) dft4<INV>(v[t1], v[t1 + 4], v[t1 + 8], v[t1 + 12]);
+    // v[t1 + 4 k2] *= W16^(t1 k2)   (forward: exp(-i pi n/8); inverse: conjugate)
+    auto tw = [&](cpx &x, float c, float sn) {           // multiply by (c - i sn) forward, (c + i sn) inverse
+        const float s_ = INV ? -sn : sn;
+        x = make_float2(x.x * c + x.y * s_, x.y * c - x.x * s_);
+    };
+    tw(v[1 + 4], C1, S1);  tw(v[1 + 8], R2, R2);  tw(v[1 + 12], S1, C1);      // n = 1, 2, 3
+    tw(v[2 + 4], R2, R2);  tw(v[2 + 8], 0.f, 1.f); tw(v[2 + 12], -R2, R2);    // n = 2, 4, 6
+    tw(v[3 + 4], S1, C1);  tw(v[3 + 8], -R2, R2); tw(v[3 + 12], -C1, -S1);    // n = 3, 6, 9
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) dft4<INV>(v[4 * k2], v[4 * k2 + 1], v[4 * k2 + 2], v[4 * k2 + 3]);
+    // X[k] now sits at v[4 (k % 4) + k / 4]
+}
+#define DFT16_AT(k) (4 * ((k) & 3) + ((k) >> 2))
+
+
 // ---------------------------------------------------------------------------------------------
 // Column pass (A: forward from the signal, C: inverse to the output).  256 threads:
 // col = tid & 31, q = tid >> 5; thread owns butterflies j = q + 8 i (i < 8) of its column.
@@ -205,6 +229,129 @@ ols_col_inv_kernel(const cpx *__restrict__ T, float *__restrict__ y, const cpx *
 }
 
 // ---------------------------------------------------------------------------------------------
+// Column pass, radix (16, 16): thread (col = tid & 31, q = tid >> 5) owns butterflies j = q + 8 i
+// (i < 2) of its column, 16 rows each (rows j + 16 t).  One LDS exchange instead of three.
+// ---------------------------------------------------------------------------------------------
+template <bool INV>
+__device__ __forceinline__ void col_stages16(cpx (&v)[2][16], cpx *lds, const cpx *tw256, int col, int q)
+{
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        dft16<INV>(v[i]);
+        const int j = q + 8 * i;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lds[(16 * j + k) * OLS_CB + col] = v[i][DFT16_AT(k)];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int j = q + 8 * i;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            cpx x = lds[(j + 16 * t) * OLS_CB + col];
+            if (t > 0) {
+                const cpx w = tw256[(t * j) & 255];
+                x = INV ? cmulc(x, w) : cmul(x, w);
+            }
+            v[i][t] = x;
+        }
+        dft16<INV>(v[i]);          // natural-order output row j + 16 k sits at v[i][DFT16_AT(k)]
+    }
+}
+
+__global__ void __launch_bounds__(256, 2)
+ols_col_fwd16_kernel(const float *__restrict__ x, cpx *__restrict__ T, const cpx *__restrict__ tw256g,
+                     OlsGeom g, int64_t frame0)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cpx *lds = (cpx *)smem;                    // [256][32]
+    cpx *tw256 = lds + OLS_N1 * OLS_CB;        // [256]
+    const int tid = threadIdx.x, col = tid & 31, q = tid >> 5;
+    tw256[tid] = tw256g[tid];
+    const int ncb = g.N2 / OLS_CB;
+    const int64_t pair = blockIdx.x / ncb;
+    const int cb = blockIdx.x % ncb;
+    const int n2 = cb * OLS_CB + col;
+    const int64_t fa = frame0 + 2 * pair, fb = fa + 1;
+    const int64_t ca = fa / g.F, ia0 = (fa % g.F) * g.S - g.pad_left;
+    const bool has_b = fb < g.nframes;
+    const int64_t cb_ = has_b ? fb / g.F : 0, ib0 = has_b ? (fb % g.F) * g.S - g.pad_left : 0;
+    const float *xa = x + ca * g.Tn, *xb = x + cb_ * g.Tn;
+    cpx v[2][16];
+    // interior frames (the common case) need no bounds checks
+    const int64_t span = (int64_t)OLS_N1 * g.N2;
+    const bool inner = ia0 >= 0 && ia0 + span <= g.Tn && has_b && ib0 >= 0 && ib0 + span <= g.Tn;
+    if (inner) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int64_t n = (int64_t)(q + 8 * i + 16 * t) * g.N2 + n2;
+                v[i][t] = make_float2(xa[ia0 + n], xb[ib0 + n]);
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int64_t n = (int64_t)(q + 8 * i + 16 * t) * g.N2 + n2;
+                const int64_t ia = ia0 + n, ib = ib0 + n;
+                const float re = (ia >= 0 && ia < g.Tn) ? xa[ia] : 0.0f;
+                const float im = (has_b && ib >= 0 && ib < g.Tn) ? xb[ib] : 0.0f;
+                v[i][t] = make_float2(re, im);
+            }
+    }
+    __syncthreads();
+    col_stages16<false>(v, lds, tw256, col, q);
+    cpx *Tp = T + pair * ((int64_t)OLS_N1 * g.P2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            Tp[(int64_t)(q + 8 * i + 16 * k) * g.P2 + n2] = v[i][DFT16_AT(k)];
+}
+
+__global__ void __launch_bounds__(256, 2)
+ols_col_inv16_kernel(const cpx *__restrict__ T, float *__restrict__ y, const cpx *__restrict__ tw256g,
+                     OlsGeom g, int64_t frame0)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cpx *lds = (cpx *)smem;
+    cpx *tw256 = lds + OLS_N1 * OLS_CB;
+    const int tid = threadIdx.x, col = tid & 31, q = tid >> 5;
+    tw256[tid] = tw256g[tid];
+    const int ncb = g.N2 / OLS_CB;
+    const int64_t pair = blockIdx.x / ncb;
+    const int cb = blockIdx.x % ncb;
+    const int n2 = cb * OLS_CB + col;
+    const cpx *Tp = T + pair * ((int64_t)OLS_N1 * g.P2);
+    cpx v[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[i][t] = Tp[(int64_t)(q + 8 * i + 16 * t) * g.P2 + n2];
+    __syncthreads();
+    col_stages16<true>(v, lds, tw256, col, q);
+
+    const int64_t fa = frame0 + 2 * pair, fb = fa + 1;
+    const int64_t ca = fa / g.F, oa0 = (fa % g.F) * g.S;
+    const bool has_b = fb < g.nframes;
+    const int64_t cb_ = has_b ? fb / g.F : 0, ob0 = has_b ? (fb % g.F) * g.S : 0;
+    float *ya = y + ca * g.Tout, *yb = y + cb_ * g.Tout;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int64_t n = (int64_t)(q + 8 * i + 16 * k) * g.N2 + n2;
+            if (n < g.S) {                                   // valid part of the block
+                const cpx o = v[i][DFT16_AT(k)];
+                if (oa0 + n < g.Tout) ya[oa0 + n] = o.x;
+                if (has_b && ob0 + n < g.Tout) yb[ob0 + n] = o.y;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Row pass B: one wavefront per row of N2 = 4^L2 points; lane owns butterflies j = lane + 64 i.
 // ---------------------------------------------------------------------------------------------
 template <int L2, bool INV>
@@ -293,29 +440,6 @@ ols_row_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *__res
 // direction needs only two LDS exchanges (the radix-4 version above needs four).  LDS positions
 // are padded by one element per 16 so the stride-16 writes of the first stage are conflict-free.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int pad16(int p) { return p + (p >> 4); }
-
-template <bool INV>
-__device__ __forceinline__ void dft16(cpx (&v)[16])
-{
-    // t = t1 + 4 t2, k = 4 k1 + k2:  W16^(tk) = W4^(t1 k1) W16^(t1 k2) W4^(t2 k2)
-    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
-#pragma unroll
-    for (int t1 = 0; t1 < 4; ++t1) dft4<INV>(v[t1], v[t1 + 4], v[t1 + 8], v[t1 + 12]);
-    // v[t1 + 4 k2] *= W16^(t1 k2)   (forward: exp(-i pi n/8); inverse: conjugate)
-    auto tw = [&](cpx &x, float c, float sn) {           // multiply by (c - i sn) forward, (c + i sn) inverse
-        const float s_ = INV ? -sn : sn;
-        x = make_float2(x.x * c + x.y * s_, x.y * c - x.x * s_);
-    };
-    tw(v[1 + 4], C1, S1);  tw(v[1 + 8], R2, R2);  tw(v[1 + 12], S1, C1);      // n = 1, 2, 3
-    tw(v[2 + 4], R2, R2);  tw(v[2 + 8], 0.f, 1.f); tw(v[2 + 12], -R2, R2);    // n = 2, 4, 6
-    tw(v[3 + 4], S1, C1);  tw(v[3 + 8], -R2, R2); tw(v[3 + 12], -C1, -S1);    // n = 3, 6, 9
-#pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2) dft4<INV>(v[4 * k2], v[4 * k2 + 1], v[4 * k2 + 2], v[4 * k2 + 3]);
-    // X[k] now sits at v[4 (k % 4) + k / 4]
-}
-#define DFT16_AT(k) (4 * ((k) & 3) + ((k) >> 2))
-
 // in: v[t] = element at position lane + 64 t (natural order).  out: same arrangement, transformed.
 template <bool INV>
 __device__ __forceinline__ void row_fft1024(cpx (&v)[16], cpx *lds, const cpx *twr, int lane)
@@ -655,7 +779,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     const int64_t L = Tn + pl + pr;
     g.Tn = Tn; g.Tout = L - K + 1; g.S = N - K + 1; g.F = ceil_div(g.Tout, g.S);
     g.pad_left = pl; g.nframes = C * g.F; g.N2 = plan->N2;
-    g.P2 = g.N2 + (int)envi("TFX_OLS_PITCH_PAD", 32);
+    g.P2 = g.N2 + (int)envi("TFX_OLS_PITCH_PAD", 0);
     const int64_t npairs = ceil_div(g.nframes, 2);
     int64_t slab = envi("TFX_OLS_PAIRS_PER_SLAB", 0);
     if (slab <= 0) slab = (envi("TFX_OLS_SLAB_MB", 128) << 20) / ((int64_t)OLS_N1 * g.P2 * (int64_t)sizeof(cpx));
@@ -668,16 +792,23 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     if (!attr) {
         TFX_HIP(hipFuncSetAttribute((const void *)ols_row4096_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 256 + 128) * sizeof(cpx))));
         TFX_HIP(hipFuncSetAttribute((const void *)ols_col_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_col));
+        TFX_HIP(hipFuncSetAttribute((const void *)ols_col_fwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_col));
+        TFX_HIP(hipFuncSetAttribute((const void *)ols_col_inv16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_col));
         TFX_HIP(hipFuncSetAttribute((const void *)ols_col_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_col));
         attr = true;
     }
     const int ncb = g.N2 / OLS_CB;
+    const bool col_r4 = envi("TFX_OLS_COL_R4", 0) != 0;
     for (int64_t p0 = 0; p0 < npairs; p0 += slab) {
         const int64_t np = (npairs - p0 < slab) ? (npairs - p0) : slab;
         {
             ProfScope ps("ols_col_fwd_kernel", stream);
-            hipLaunchKernelGGL(ols_col_fwd_kernel, dim3((unsigned)(np * ncb)), dim3(256), shm_col, stream,
-                               x, T, plan->tw256, g, 2 * p0);
+            if (col_r4)
+                hipLaunchKernelGGL(ols_col_fwd_kernel, dim3((unsigned)(np * ncb)), dim3(256), shm_col, stream,
+                                   x, T, plan->tw256, g, 2 * p0);
+            else
+                hipLaunchKernelGGL(ols_col_fwd16_kernel, dim3((unsigned)(np * ncb)), dim3(256), shm_col, stream,
+                                   x, T, plan->tw256, g, 2 * p0);
             TFX_HIP(hipGetLastError());
         }
         {
@@ -701,8 +832,12 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
         }
         {
             ProfScope ps("ols_col_inv_kernel", stream);
-            hipLaunchKernelGGL(ols_col_inv_kernel, dim3((unsigned)(np * ncb)), dim3(256), shm_col, stream,
-                               T, y, plan->tw256, g, 2 * p0);
+            if (col_r4)
+                hipLaunchKernelGGL(ols_col_inv_kernel, dim3((unsigned)(np * ncb)), dim3(256), shm_col, stream,
+                                   T, y, plan->tw256, g, 2 * p0);
+            else
+                hipLaunchKernelGGL(ols_col_inv16_kernel, dim3((unsigned)(np * ncb)), dim3(256), shm_col, stream,
+                                   T, y, plan->tw256, g, 2 * p0);
             TFX_HIP(hipGetLastError());
         }
     }
