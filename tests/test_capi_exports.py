@@ -65,3 +65,15 @@ def test_errors_without_device_are_loud():
         E.fir_direct_forward(torch.zeros(1, 8), torch.ones(3))
     with pytest.raises(RuntimeError, match="no CPU path"):
         E.fft_conv_forward(torch.zeros(1, 8), torch.ones(3), (2, 0))
+
+
+def test_custom_ops_registered_with_meta_and_no_cpu_kernel():
+    import pytest
+    import torch
+    import torchfx_amd.ops  # noqa: F401
+    x = torch.empty(3, 100, device="meta")
+    y, sx, sy = torch.ops.torchfx_hip.sos_forward(x, torch.empty(2, 6, dtype=torch.float64), None, None)
+    assert y.shape == (3, 100) and sx.shape == (2, 3, 2) and sx.dtype == torch.float64
+    assert torch.ops.torchfx_hip.fft_conv_forward(x, torch.empty(8), 7, 0).shape == (3, 100)
+    with pytest.raises(NotImplementedError):          # there is deliberately no CPU implementation
+        torch.ops.torchfx_hip.fir_direct_forward(torch.zeros(1, 8), torch.ones(3))

@@ -397,3 +397,13 @@ def test_native_ols_padding_variants(monkeypatch):
         y = ext().fft_conv_forward(dev(x), k, pad)
         e = O.fft_conv1d(x.astype(np.float64), k.astype(np.float64), pad)
         close(y, e.astype(np.float32), 2e-5, f"pad={pad}")
+
+
+def test_custom_ops_on_device(golden):
+    import torchfx_amd.ops  # noqa: F401
+    g = golden("iir_cfg1")
+    y, sx, sy = torch.ops.torchfx_hip.sos_forward(dev(g["x"]), torch.from_numpy(g["sos"]), None, None)
+    close(y, g["y"], TOL_IIR_F32OUT, "custom op sos")
+    f = golden("fir")
+    close(torch.ops.torchfx_hip.fir_direct_forward(dev(f["x"]), torch.from_numpy(f["k32"])), f["direct32"], TOL_CONV_F32)
+    close(torch.ops.torchfx_hip.fft_conv_forward(dev(f["x"]), torch.from_numpy(f["k32"]), 31, 0), f["fft32"], TOL_CONV_F32)
