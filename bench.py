@@ -203,6 +203,15 @@ def main() -> None:
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                     "note": "algorithmic 8 B/sample-channel x samples of one step / step time (all launches of the step)"}
+        # HBM bytes per step measured with rocprofv3 PMC passes of this same command (profiles/);
+        # counters cannot be read from inside the process, so the last profiled value is reported
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if args.workload in tr and C == 64 and seconds == 600.0:
+                roof["traffic"] = tr[args.workload]["bytes_per_step"]
+                roof["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        except Exception:
+            pass
         roof["dominant_kernel"] = dom
         if dom:
             roof["dominant_kernel_avg_ms"] = kernels[dom]["avg_ms_per_launch"]
