@@ -221,11 +221,12 @@ def main() -> None:
             a = alg_gb / (kernels[kn]["ms_per_step"] * 1e-3)
             roof["iir_kernel"] = {"name": kn, "achieved": round(a, 1), "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4)}
         line = {
-            "metric": "Msamples/s (64-ch fused biquad->FIR->FFT-conv chain per GPU); % HBM roofline"
+            # BASELINE.json's metric string; `value` is the whole-job aggregate, `per_gpu_value` the per-GPU rate
+            "metric": "Msamples/s/GPU (64-ch fused biquad\u2192FIR\u2192FFT-conv chain); % HBM roofline"
                       if args.workload == "chain" else f"Msamples/s ({args.workload})",
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 I/O; f64 IIR recurrences, f32 FFT",
+            "scaling": "weak", "vs_baseline": None, "dtype": {"chain": "f64 (IIR) + f32 (FFT); f32 I/O", "sos": "f64; f32 I/O", "fir": "f32", "fftconv": "f32"}[args.workload],
             "data": "synthetic", "per_gpu_value": round(value / world, 1),
             "config": {"workload": desc, "channels_per_gpu": C, "seconds": seconds, "fs": FS,
                        "samples_per_gpu": samples, "parallelism": f"channel-shard x{world}, no data-path collective",
