@@ -72,6 +72,10 @@ struct OlsGeom {
 constexpr int OLS_N1 = 256;
 constexpr int OLS_CB = 32;      // columns per workgroup in the column passes
 
+// LDS positions of the row passes are padded by one element per 16: the stride-16 writes of a
+// radix-16 Stockham stage become conflict-free and every address stays base + immediate.  (An XOR
+// swizzle removes the remaining 2-way read conflict but costs 32 computed addresses per stage and
+// measured slower.)
 __device__ __forceinline__ int pad16(int p) { return p + (p >> 4); }
 
 template <bool INV>
