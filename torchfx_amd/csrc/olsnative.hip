@@ -593,11 +593,14 @@ __device__ __forceinline__ void row_fft4096(cpx (&v)[16], cpx *lds, const cpx *t
     for (int k = 0; k < 16; ++k) v[k] = o[k];
 }
 
-__global__ void __launch_bounds__(256, 3)
+// PF = persistent workgroups with the next row's loads in flight during the current row's FFTs
+// (the plain version leaves the memory system idle while a workgroup is in its six FFT stages)
+template <bool PF>
+__global__ void __launch_bounds__(256, PF ? 2 : 3)
 ols_row4096_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *__restrict__ tw256g,
                    const cpx *__restrict__ t4log, const cpx *__restrict__ t4hig,
                    const cpx *__restrict__ tlo, const cpx *__restrict__ thi, const cpx *__restrict__ tu,
-                   int64_t Nmask, int P2)
+                   int64_t Nmask, int P2, int64_t nrows)
 {
     constexpr int N2 = 4096;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -607,37 +610,53 @@ ols_row4096_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *_
     const int j = threadIdx.x;
     twB[j] = tw256g[((j >> 4) * (j & 15)) & 255];
     twA[j] = t4log[j];
-    const int64_t row = blockIdx.x;
-    const int k1 = (int)(row % OLS_N1);
-    cpx *base = T + row * P2;
-    const cpx *hrow = Hp + (int64_t)k1 * N2;
     typedef const float __attribute__((address_space(4))) *cfp;
     const cfp tuc = (cfp)(uintptr_t)tu;          // uniform per row: W_N^(256 k1 t)
-    const unsigned ml = (unsigned)(k1 * j);
-    const cpx wl = cmul(tlo[ml & 511], thi[ml >> 9]);
     const unsigned umask = (unsigned)(Nmask >> 8);
-    cpx v[16];
+    cpx nv[PF ? 16 : 1];
+    int64_t row = blockIdx.x;
+    if (PF) {
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const unsigned iu = 2u * ((unsigned)(k1 * t) & umask);
-        const cpx ut = make_float2(tuc[iu], tuc[iu + 1]);
-        v[t] = cmul(base[j + 256 * t], cmul(wl, ut));
+        for (int t = 0; t < 16; ++t) nv[t] = T[row * P2 + j + 256 * t];
     }
     __syncthreads();                             // tables visible
-    row_fft4096<false>(v, lds, twB, twA, j);
-    __builtin_amdgcn_sched_barrier(0);
+    for (; row < nrows; row += gridDim.x) {
+        const int k1 = (int)(row % OLS_N1);
+        cpx *base = T + row * P2;
+        const cpx *hrow = Hp + (int64_t)k1 * N2;
+        const unsigned ml = (unsigned)(k1 * j);
+        const cpx wl = cmul(tlo[ml & 511], thi[ml >> 9]);
+        cpx v[16];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) v[t] = cmul(v[t], hrow[j + 256 * t]);
-    __builtin_amdgcn_sched_barrier(0);
-    row_fft4096<true>(v, lds, twB, twA, j);
-    float wlx = wl.x, wly = wl.y;
-    asm volatile("" : "+v"(wlx), "+v"(wly));     // recompute, do not keep 16 twiddles live (see row1024)
-    const cpx wl2 = make_float2(wlx, wly);
+        for (int t = 0; t < 16; ++t) {
+            const unsigned iu = 2u * ((unsigned)(k1 * t) & umask);
+            const cpx ut = make_float2(tuc[iu], tuc[iu + 1]);
+            v[t] = cmul(PF ? nv[t] : base[j + 256 * t], cmul(wl, ut));
+        }
+        if (PF) {
+            const int64_t nrow = row + gridDim.x;
+            if (nrow < nrows) {
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const unsigned iu = 2u * ((unsigned)(k1 * t) & umask);
-        const cpx ut = make_float2(tuc[iu], tuc[iu + 1]);
-        base[j + 256 * t] = cmulc(v[t], cmul(wl2, ut));
+                for (int t = 0; t < 16; ++t) nv[t] = T[nrow * P2 + j + 256 * t];
+            }
+        }
+        row_fft4096<false>(v, lds, twB, twA, j);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = cmul(v[t], hrow[j + 256 * t]);
+        __builtin_amdgcn_sched_barrier(0);
+        row_fft4096<true>(v, lds, twB, twA, j);
+        float wlx = wl.x, wly = wl.y;
+        asm volatile("" : "+v"(wlx), "+v"(wly));     // recompute, do not keep 16 twiddles live (see row1024)
+        const cpx wl2 = make_float2(wlx, wly);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const unsigned iu = 2u * ((unsigned)(k1 * t) & umask);
+            const cpx ut = make_float2(tuc[iu], tuc[iu + 1]);
+            base[j + 256 * t] = cmulc(v[t], cmul(wl2, ut));
+        }
+        if (!PF) break;
+        __syncthreads();                         // LDS reuse by the next row
     }
 }
 
@@ -820,7 +839,8 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     const size_t shm_row = (size_t)(g.N2 * 5) * sizeof(cpx);
     static bool attr = false;
     if (!attr) {
-        TFX_HIP(hipFuncSetAttribute((const void *)ols_row4096_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
+        TFX_HIP(hipFuncSetAttribute((const void *)ols_row4096_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
+        TFX_HIP(hipFuncSetAttribute((const void *)ols_row4096_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
         TFX_HIP(hipFuncSetAttribute((const void *)ols_col_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_col));
         TFX_HIP(hipFuncSetAttribute((const void *)ols_col_fwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_col));
         TFX_HIP(hipFuncSetAttribute((const void *)ols_col_inv16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_col));
@@ -844,10 +864,17 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
         {
             const int64_t nrows = np * OLS_N1;
             ProfScope ps("ols_row_kernel", stream);
-            if (g.N2 == 4096)
-                hipLaunchKernelGGL(ols_row4096_kernel, dim3((unsigned)nrows), dim3(256),
+            if (g.N2 == 4096 && envi("TFX_OLS_ROW_PF", 0) != 0) {
+                const int64_t wgs = (int64_t)envi("TFX_OLS_ROW_WGS_PER_CU", 2) * 256;
+                hipLaunchKernelGGL(ols_row4096_kernel<true>, dim3((unsigned)(nrows < wgs ? nrows : wgs)), dim3(256),
                                    (size_t)(4096 + 256 + 512) * sizeof(cpx), stream,
-                                   T, plan->Hp, plan->tw256, plan->t4lo, plan->t4hi, plan->tlo, plan->thi, plan->tu, N - 1, g.P2);
+                                   T, plan->Hp, plan->tw256, plan->t4lo, plan->t4hi, plan->tlo, plan->thi, plan->tu,
+                                   N - 1, g.P2, nrows);
+            } else if (g.N2 == 4096)
+                hipLaunchKernelGGL(ols_row4096_kernel<false>, dim3((unsigned)nrows), dim3(256),
+                                   (size_t)(4096 + 256 + 512) * sizeof(cpx), stream,
+                                   T, plan->Hp, plan->tw256, plan->t4lo, plan->t4hi, plan->tlo, plan->thi, plan->tu,
+                                   N - 1, g.P2, nrows);
             else if (g.N2 == 1024 && envi("TFX_OLS_ROW_R4", 0) == 0)
                 hipLaunchKernelGGL(ols_row1024_kernel, dim3((unsigned)ceil_div(nrows, 4)), dim3(256),
                                    (size_t)(1024 + 4 * (1024 + 64)) * sizeof(cpx), stream,
