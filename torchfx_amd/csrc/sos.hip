@@ -37,8 +37,9 @@ namespace tfx {
 // Table layout per section (TC elements):
 //   [0..4]  b0 b1 b2 -a1 -a2      [5..7] pad
 //   [8 + 4k + {0..3}]             Cmp^(LC * 2^k) row-major, k < 6   (Cmp = [[-a1,-a2],[1,0]])
+//   [32 + 4p + {0..3}]            Cmp^(LC * (p+1)), p < 16: per-lane matrix of the scan's row step
 // ------------------------------------------------------------------------------------------
-__host__ __device__ constexpr int tab_stride(int) { return 8 + 24; }
+__host__ __device__ constexpr int tab_stride(int) { return 32 + 64; }
 
 struct SosParams {
     const void *x;
@@ -214,6 +215,12 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
         for (int s = 0; s < K; ++s) {
             const ctab_t tb = tab + s * TS;
             const TC b0 = tb[0], b1 = tb[1], b2 = tb[2], na1 = tb[3], na2 = tb[4];
+            TC mq[4];
+            {
+                const TC *mp = (const TC *)p.tab + s * TS + 32 + 4 * (lane & 15);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mq[i] = mp[i];
+            }
             const TC cv1 = carry[s * 4 + 0], cv2 = carry[s * 4 + 1];
             const TC cy1 = carry[s * 4 + 2], cy2 = carry[s * 4 + 3];
 
@@ -291,18 +298,13 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
                 const TC p00 = pm[16], p01 = pm[17], p10 = pm[18], p11 = pm[19];      // P^16
                 const TC e20 = r10 + fma(p00, r00, p01 * r01), e21 = r11 + fma(p10, r00, p11 * r01);
                 const TC e30 = r20 + fma(p00, e20, p01 * e21), e31 = r21 + fma(p10, e20, p11 * e21);
-                const int row = lane >> 4, pp = lane & 15;
+                const int row = lane >> 4;
                 TC e0 = row == 1 ? r00 : (row == 2 ? e20 : e30);
                 TC e1 = row == 1 ? r01 : (row == 2 ? e21 : e31);
                 if (row == 0) { e0 = (TC)0; e1 = (TC)0; }
-                // q = P^(pp+1) e
-                TC q0 = fma(pm[0], e0, pm[1] * e1), q1 = fma(pm[2], e0, pm[3] * e1);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const TC n0 = fma(pm[4 * k + 0], q0, pm[4 * k + 1] * q1);
-                    const TC n1 = fma(pm[4 * k + 2], q0, pm[4 * k + 3] * q1);
-                    if (pp & (1 << k)) { q0 = n0; q1 = n1; }
-                }
+                // q = P^(pp+1) e with the lane's own matrix (one 4-element gather per section instead
+                // of a 4-step conditional binary expansion)
+                const TC q0 = fma(mq[0], e0, mq[1] * e1), q1 = fma(mq[2], e0, mq[3] * e1);
                 s0 += q0;
                 s1 += q1;
             }
@@ -499,6 +501,15 @@ static void fill_tables(const std::vector<double> &sos, int K, int LC, std::vect
             al2 = al1; al1 = al; be2 = be1; be1 = be;
         }
         P[0] = al1; P[1] = be1; P[2] = al2; P[3] = be2;          // Cmp^LC
+        {
+            ld Q[4] = {P[0], P[1], P[2], P[3]};                   // Cmp^(LC (p+1))
+            for (int pp = 0; pp < 16; ++pp) {
+                for (int i = 0; i < 4; ++i) tb[32 + 4 * pp + i] = (TC)Q[i];
+                const ld q0 = Q[0] * P[0] + Q[1] * P[2], q1 = Q[0] * P[1] + Q[1] * P[3];
+                const ld q2 = Q[2] * P[0] + Q[3] * P[2], q3 = Q[2] * P[1] + Q[3] * P[3];
+                Q[0] = q0; Q[1] = q1; Q[2] = q2; Q[3] = q3;
+            }
+        }
         int need = 0;
         for (int k = 0; k < 6; ++k) {
             for (int i = 0; i < 4; ++i) tb[8 + 4 * k + i] = (TC)P[i];
