@@ -211,6 +211,31 @@ def main() -> None:
             kernels[name] = {"launches_per_step": round(calls_per_step, 2),
                              "avg_ms_per_launch": round(v["total_ms"] / v["calls"], 4),
                              "ms_per_step": round(v["total_ms"] / args.steps, 4)}
+        # per-kernel HBM model: the bytes each launch group must move by design (not the 8 B/sample
+        # algorithmic figure) -> achieved GB/s of that kernel; PMC-measured traffic agrees within
+        # a few % (profiles/r01_traffic.json)
+        try:
+            from torchfx_amd import torchfx_ext as E
+            model = {"sos_stream_kernel<f64>": 8.0 * samples, "sos_stream_kernel<f32>": 8.0 * samples}
+            if args.workload in ("chain", "fftconv"):
+                kk = 66559 if args.workload == "chain" else 65536
+                info = E.ols_plan_info(kk, T, (kk - 1, 0))
+                frames = C * info["F"]
+                pairs = (frames + 1) // 2
+                n = info["N"]
+                model.update({"ols_col_fwd_kernel": frames * n * 4.0 + pairs * n * 8.0,
+                              "ols_row_kernel": pairs * n * 16.0,
+                              "ols_col_inv_kernel": pairs * n * 8.0 + 4.0 * samples})
+                line_ols = {"fft_block": n, "hop": info["S"], "blocks_per_row": info["F"], "native_lds_fft": info["native"]}
+            else:
+                line_ols = None
+            for name, k in kernels.items():
+                if name in model and k["ms_per_step"] > 0:
+                    k["model_GB_per_step"] = round(model[name] / 1e9, 3)
+                    k["GBps"] = round(model[name] / 1e9 / (k["ms_per_step"] * 1e-3), 1)
+                    k["frac_of_8TBps"] = round(k["GBps"] / HBM_PEAK_GBS, 4)
+        except Exception:
+            line_ols = None
         dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"]) if kernels else None
         gpu_ms = sum(k["ms_per_step"] for k in kernels.values())
         # per-GPU algorithmic bytes of one step: 8 B per sample-channel
@@ -256,6 +281,8 @@ def main() -> None:
             "roofline": roof,
             "kernels": kernels, "gpu_ms_per_step_sum_of_kernels": round(gpu_ms, 4),
         }
+        if line_ols:
+            line["config"]["overlap_save"] = line_ols
         if gather_ms is not None:
             line["gather_ms"] = round(gather_ms, 2)
         if not args.no_cpu_baseline:

@@ -135,6 +135,13 @@ int tfx_fft_conv_forward(const void *x, void *y, int dtype,
                          int64_t pad_left, int64_t pad_right,
                          tfx_stream_t stream);
 
+/* Block geometry the overlap-save op would use for a [*, T] signal and a K-tap kernel with
+ * padding (l, r): *N = FFT block length, *S = hop (valid outputs per block), *F = blocks per row,
+ * *native = 1 when the hand-written LDS-FFT path runs (0 = rocFFT path).  For bench/DESIGN
+ * traffic models; no GPU needed. */
+int tfx_ols_plan_info(int64_t K, int64_t T, int64_t pad_left, int64_t pad_right,
+                      int64_t *N, int64_t *S, int64_t *F, int *native);
+
 /* ---------------------------------------------------------------------------
  * tfx_delay_line_forward -- kept because the reference extension exports it
  * (binding.cpp:68-81,92-95; tests/test_ops_dispatch.py:29-35); out of the

@@ -24,6 +24,8 @@ void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, c
                       int64_t K, int64_t pad_left, int64_t pad_right, hipStream_t stream);
 void fftconv_clear();
 void olsnative_clear();
+bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out);
+int64_t fftconv_block_size(int64_t K, int64_t L);
 
 // ---- errors ------------------------------------------------------------------------------------
 static thread_local std::string t_last_error;
@@ -216,6 +218,32 @@ int tfx_fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T
 {
     TFX_API_BEGIN
     fft_conv_forward(x, y, dtype, C, T, kernel_host, K, pad_left, pad_right, (hipStream_t)stream);
+    TFX_API_END
+}
+
+int tfx_ols_plan_info(int64_t K, int64_t T, int64_t pad_left, int64_t pad_right, int64_t *N, int64_t *S,
+                      int64_t *F, int *native)
+{
+    TFX_API_BEGIN
+    const int64_t L = T + pad_left + pad_right;
+    TFX_CHECK(K >= 1 && L >= K, "ols_plan_info: kernel size %lld larger than the padded signal %lld", (long long)K, (long long)L);
+    int64_t n = 0;
+    const bool nat = olsnative_supported(K, L, &n);
+    int64_t hop;
+    if (nat) {
+        const int64_t tout = L - K + 1;
+        const bool align = (T % 32 == 0) && (tout % 32 == 0);
+        const int64_t lead = align ? (32 - (pad_left % 32)) % 32 : 0;
+        hop = n - (K + lead) + 1;
+        if (align && hop > 64) hop -= hop % 32;
+    } else {
+        n = fftconv_block_size(K, L);
+        hop = n - K + 1;
+    }
+    if (N) *N = n;
+    if (S) *S = hop;
+    if (F) *F = ceil_div(L - K + 1, hop);
+    if (native) *native = nat ? 1 : 0;
     TFX_API_END
 }
 

@@ -29,7 +29,7 @@ from torchfx_amd import _lib as L
 
 __all__ = [
     "biquad_forward", "sos_forward", "delay_line_forward",
-    "fir_direct_forward", "fft_conv_forward", "sum_forward", "sos_plan_info",
+    "fir_direct_forward", "fft_conv_forward", "sum_forward", "sos_plan_info", "ols_plan_info",
 ]
 
 _TORCH_DT = {L.TFX_F32: torch.float32, L.TFX_F64: torch.float64}
@@ -220,3 +220,12 @@ def sos_plan_info(sos) -> dict:
                                   ctypes.byref(prec), ctypes.byref(warm), ctypes.byref(eb)))
     return {"auto_precision": "f32" if prec.value == L.PREC_F32 else "f64",
             "warmup": warm.value, "f32_error_bound": eb.value}
+
+
+def ols_plan_info(K: int, T: int, padding: tuple[int, int] = (0, 0)) -> dict:
+    """Block geometry of the overlap-save op (FFT length N, hop S, blocks per row F, native path?)."""
+    lib = L.load()
+    n, s_, f, nat = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int(0)
+    L.check(lib.tfx_ols_plan_info(int(K), int(T), int(padding[0]), int(padding[1]), ctypes.byref(n),
+                                  ctypes.byref(s_), ctypes.byref(f), ctypes.byref(nat)))
+    return {"N": n.value, "S": s_.value, "F": f.value, "native": bool(nat.value)}
