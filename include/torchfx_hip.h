@@ -82,6 +82,21 @@ int tfx_sos_forward(const void *x, int x_dtype, void *y, int y_dtype,
                     double *state_x_out, double *state_y_out,
                     void *y_sections, int precision, tfx_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * tfx_sos_bank_forward -- filter bank: n_bands independent K-section cascades applied to the SAME
+ * input rows in one launch (x is read from HBM once, the bands' re-reads hit cache).
+ * Replaces the loop of LogFilterBank.forward (src/torchfx/filter/filterbank.py:157-185:
+ * `torch.stack([f(x) for f in self.filters])`) -- SURVEY.md 8(f) rank 2.
+ *   x DEVICE [C,T];  y DEVICE [n_bands, C, T];  sos_host HOST [n_bands, K, 6];
+ *   states DEVICE [K, n_bands*C, 2] float64 (band-major rows), NULL = zeros.
+ * ------------------------------------------------------------------------- */
+int tfx_sos_bank_forward(const void *x, int x_dtype, void *y, int y_dtype,
+                         int64_t C, int64_t T,
+                         const double *sos_host, int64_t n_bands, int64_t K,
+                         const double *state_x_in, const double *state_y_in,
+                         double *state_x_out, double *state_y_out,
+                         int precision, tfx_stream_t stream);
+
 /* What AUTO would pick for this SOS, and the plan facts (for DESIGN/bench
  * reporting and tests): *precision (TFX_PREC_F32/F64), *warmup (samples of
  * warm-up halo per time segment; -1 = filter memory too long, sequential

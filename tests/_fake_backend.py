@@ -21,6 +21,22 @@ def sos_forward(x, sos, sos_cpu, state_x, state_y, *, out_dtype=None, precision=
     return out + (torch.from_numpy(sec).to(odt),) if return_sections else out
 
 
+def sos_bank_forward(x, sos_banks, state_x, state_y, *, out_dtype=None, precision=None):
+    banks = _np(sos_banks) if hasattr(sos_banks, "detach") else np.asarray(sos_banks)
+    nb, k = banks.shape[0], banks.shape[1]
+    c = x.shape[0]
+    calls.append(("sos_bank_forward", tuple(x.shape), nb))
+    ys, sxs, sys_ = [], [], []
+    for b in range(nb):
+        sx = None if state_x is None else _np(state_x)[:, b * c:(b + 1) * c]
+        sy = None if state_y is None else _np(state_y)[:, b * c:(b + 1) * c]
+        y, nx, ny = O.sos_forward(_np(x), banks[b], sx, sy)
+        ys.append(y), sxs.append(nx), sys_.append(ny)
+    odt = x.dtype if out_dtype is None else out_dtype
+    return (torch.from_numpy(np.stack(ys)).to(odt), torch.from_numpy(np.concatenate(sxs, axis=1)),
+            torch.from_numpy(np.concatenate(sys_, axis=1)))
+
+
 def biquad_forward(x, b, a1, a2, state_x, state_y, *, out_dtype=None, precision=None):
     calls.append(("biquad_forward", tuple(x.shape)))
     y, sx, sy = O.biquad_forward(_np(x), _np(b), a1, a2, _np(state_x), _np(state_y))

@@ -407,3 +407,34 @@ def test_custom_ops_on_device(golden):
     f = golden("fir")
     close(torch.ops.torchfx_hip.fir_direct_forward(dev(f["x"]), torch.from_numpy(f["k32"])), f["direct32"], TOL_CONV_F32)
     close(torch.ops.torchfx_hip.fft_conv_forward(dev(f["x"]), torch.from_numpy(f["k32"]), 31, 0), f["fft32"], TOL_CONV_F32)
+
+
+# ------------------------------------------------------------------ filter bank (8f rank 2)
+@pytest.mark.parametrize("C,T,NB,K", [(2, 3000, 5, 1), (3, 70001, 4, 2), (64, 100000, 8, 1), (1, 17, 3, 1)])
+def test_filter_bank_vs_oracle(C, T, NB, K, sos_variant):
+    from scipy.signal import butter
+    rng = np.random.default_rng(NB * 100 + K)
+    banks = np.stack([np.vstack([butter(2, [f, min(0.95, f * 1.5)], "bandpass", output="sos")[:K]])
+                      for f in rng.uniform(0.01, 0.5, NB)])
+    x = rnd((C, T), T + NB)
+    sx0, sy0 = rng.standard_normal((K, NB * C, 2)), rng.standard_normal((K, NB * C, 2))
+    y, sx, sy = ext().sos_bank_forward(dev(x), banks, dev(sx0), dev(sy0))
+    assert y.shape == (NB, C, T)
+    for b in range(NB):
+        ey, esx, esy = O.sos_forward(x, banks[b], sx0[:, b * C:(b + 1) * C], sy0[:, b * C:(b + 1) * C])
+        close(y[b], ey.astype(np.float32), 2.5e-7, f"band {b}")
+        close(sx[:, b * C:(b + 1) * C], esx, TOL_STATE, f"band {b} sx")
+        close(sy[:, b * C:(b + 1) * C], esy, TOL_STATE, f"band {b} sy")
+
+
+def test_log_filter_bank_module_on_device():
+    from torchfx_amd import filter as F
+    fb = F.LogFilterBank(6, f_min=40, f_max=12000, q=1.414, fs=48000)
+    x = rnd((2, 50000), 9)
+    y = fb(dev(x))
+    assert y.shape == (6, 2, 50000)
+    for i, f in enumerate(fb.filters):
+        e, _, _ = O.iir_module_forward(x, f._sos.numpy())
+        close(y[i], e, TOL_IIR_F32OUT, f"band {i}")
+    y2 = torch.cat([fb(dev(x[:, :20000])), fb(dev(x[:, 20000:]))], dim=-1)    # state carried per band
+    fb.filters[0].reset_state()

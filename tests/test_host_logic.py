@@ -230,3 +230,27 @@ def test_ops_module_surface():
     for n in ("biquad_forward", "sos_forward", "delay_line_forward"):
         assert hasattr(torchfx_ext, n)
     assert fx.is_native_available() is True
+
+
+# ------------------------------------------------------------------ filter bank (8f rank 2)
+def test_log_filter_bank(oracle_backend):
+    from oracle import oracle as O
+    fb = F.LogFilterBank(5, f_min=50, f_max=8000, q=2.0)
+    assert len(fb.center_frequencies) == 5 and abs(fb.center_frequencies[-1] - 8000) < 1e-6
+    x = torch.randn(2, 3000, generator=torch.Generator().manual_seed(3))
+    with pytest.raises(ValueError, match="Sample rate"):
+        fb(x)
+    w = fx.Wave(x, 44100) | fb                  # fs propagates to the bands through the setter
+    y = w.ys
+    assert tuple(y.shape) == (5, 2, 3000) and y.dtype == torch.float32
+    names = [c[0] for c in oracle_backend.calls if c[0].startswith("sos")]
+    assert names[-1] == "sos_bank_forward"       # one launch for all bands
+    for i, f in enumerate(fb.filters):
+        e, _, _ = O.iir_module_forward(x.numpy(), f._sos.numpy())
+        close(y[i], e, 1e-7)
+        assert tuple(f._state_x.shape) == (1, 2, 2)
+    # chunked == contiguous (per-band state carried on the member filters)
+    fb2 = F.LogFilterBank(5, f_min=50, f_max=8000, q=2.0, fs=44100)
+    ya, yb = fb2(x[:, :1000]), fb2(x[:, 1000:])
+    close(torch.cat([ya, yb], dim=-1), y.numpy(), 1e-6)
+    assert F.LogFilterBank(3, fs=8000)(torch.zeros(100)).shape == (3, 100)

@@ -48,7 +48,8 @@ struct SosParams {
     const void *tab;     // device table, TC
     const double *sx_in, *sy_in;
     double *sx_out, *sy_out;
-    int64_t C, T;
+    int64_t C, T;        // C = output rows (= bands x input rows in filter-bank mode)
+    int64_t C_in;        // input rows: output row c reads input row c % C_in with the tables of band c / C_in
     int64_t seg_len;     // multiple of 4 (VEC alignment)
     int64_t warm;        // multiple of 4
     int K, nseg, nsteps;
@@ -119,12 +120,13 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
     TC *cap = carry + K * 4;                               // [2][LC] final-state capture scratch
 
     const int64_t T = p.T;
-    const TIn *__restrict__ xrow = (const TIn *)p.x + c * T;
+    const int64_t band = c / p.C_in;
+    const TIn *__restrict__ xrow = (const TIn *)p.x + (c - band * p.C_in) * T;
     TOut *__restrict__ yrow = (TOut *)p.y + c * T;
     // Coefficient tables live in the CONSTANT address space: wave-uniform indices then lower to
     // s_load (scalar cache, SGPR operands) instead of per-lane vector loads.
     typedef const TC __attribute__((address_space(4))) *ctab_t;
-    const ctab_t tab = (ctab_t)(uintptr_t)p.tab;
+    const ctab_t tab = (ctab_t)(uintptr_t)p.tab + band * (int64_t)K * TS;
 
     const int64_t out_begin = (int64_t)g * p.seg_len;
     if (out_begin >= T) return;
@@ -217,7 +219,7 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
             const TC b0 = tb[0], b1 = tb[1], b2 = tb[2], na1 = tb[3], na2 = tb[4];
             TC mq[4];
             {
-                const TC *mp = (const TC *)p.tab + s * TS + 32 + 4 * (lane & 15);
+                const TC *mp = (const TC *)p.tab + (band * K + s) * TS + 32 + 4 * (lane & 15);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) mq[i] = mp[i];
             }
@@ -397,7 +399,8 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
 typedef long double ld;
 
 struct SosPlan {
-    int K = 0;
+    int K = 0;          // sections per band
+    int NB = 1;         // bands (filter-bank mode: independent SOS sets sharing the input)
     int nsteps32 = 6, nsteps16 = 6;
     int64_t warm = -1;            // samples; -1 = too long / not decaying
     double err_bound_f32 = -1.0;  // worst-case |err| of f32 arithmetic for |x| <= 1 (lazy)
@@ -587,7 +590,14 @@ static void free_plan(SosPlan *pl)
 static double plan_err_bound(SosPlan *pl)
 {
     std::lock_guard<std::mutex> lk(g_plan_mu);
-    if (pl->err_bound_f32 < 0) pl->err_bound_f32 = f32_error_bound(pl->sos, pl->K);
+    if (pl->err_bound_f32 < 0) {
+        double worst = 0.0;
+        for (int b = 0; b < pl->NB; ++b) {
+            std::vector<double> one(pl->sos.begin() + (size_t)b * pl->K * 6, pl->sos.begin() + (size_t)(b + 1) * pl->K * 6);
+            worst = fmax(worst, f32_error_bound(one, pl->K));
+        }
+        pl->err_bound_f32 = worst;
+    }
     return pl->err_bound_f32;
 }
 static double auto_bound()
@@ -596,22 +606,28 @@ static double auto_bound()
     return (e && *e) ? atof(e) : 2e-6;
 }
 
-static SosPlan *get_plan(const double *sos_host, int64_t K, hipStream_t stream)
+static SosPlan *get_plan(const double *sos_host, int64_t K, hipStream_t stream, int64_t NB = 1)
 {
-    std::vector<double> key(sos_host, sos_host + K * 6);
+    std::vector<double> key(sos_host, sos_host + NB * K * 6);
+    key.push_back((double)NB);             // a bank of NB x K sections is not a cascade of NB*K
     std::lock_guard<std::mutex> lk(g_plan_mu);
     auto it = g_plans.find(key);
     if (it != g_plans.end()) return it->second;
     if (g_plans.size() > 256) {   // bound the cache
-        for (auto &kv : g_plans) {
-            free_plan(kv.second);
-        }
+        for (auto &kv : g_plans) free_plan(kv.second);
         g_plans.clear();
     }
     SosPlan *pl = new SosPlan();
     pl->K = (int)K;
-    pl->sos = key;
-    pl->warm = warmup_length(key, (int)K);
+    pl->NB = (int)NB;
+    pl->sos.assign(sos_host, sos_host + NB * K * 6);
+    pl->warm = 0;
+    for (int64_t b = 0; b < NB; ++b) {     // every band must have forgotten its start state
+        std::vector<double> one(sos_host + b * K * 6, sos_host + (b + 1) * K * 6);
+        const int64_t w = warmup_length(one, (int)K);
+        if (w < 0) { pl->warm = -1; break; }
+        if (w > pl->warm) pl->warm = w;
+    }
     g_plans[key] = pl;
     return pl;
 }
@@ -622,7 +638,12 @@ static void *ensure_table(SosPlan *pl, void **slot, int LC, int *nsteps, hipStre
     std::lock_guard<std::mutex> lk(g_plan_mu);
     if (!*slot) {
         std::vector<TC> h;
-        fill_tables<TC>(pl->sos, pl->K, LC, h, *nsteps);
+        for (int b = 0; b < pl->NB; ++b) {
+            std::vector<double> one(pl->sos.begin() + (size_t)b * pl->K * 6, pl->sos.begin() + (size_t)(b + 1) * pl->K * 6);
+            std::vector<TC> hb;
+            fill_tables<TC>(one, pl->K, LC, hb, *nsteps);
+            h.insert(h.end(), hb.begin(), hb.end());
+        }
         void *d = nullptr;
         TFX_HIP(hipMalloc(&d, h.size() * sizeof(TC)));
         // synchronous copy from a temporary: happens once per distinct filter
@@ -748,11 +769,16 @@ static void launch_rare(const SosParams &p, bool vec, int64_t nstreams, hipStrea
     else launch_one<TIn, TOut, TC, 16, false, false, false, 3>(p, nstreams, stream);
 }
 
-void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C, int64_t T,
+// NB > 1 = filter-bank mode: NB independent K-section cascades applied to the same C_in input
+// rows; output rows (and state rows) are band-major: row = band * C_in + c.  C is the number of
+// INPUT rows.
+void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C_in, int64_t T,
                  const double *sos_host, int64_t K,
                  const double *sx_in, const double *sy_in, double *sx_out, double *sy_out,
-                 void *y_sections, int precision, hipStream_t stream)
+                 void *y_sections, int precision, hipStream_t stream, int64_t NB)
 {
+    TFX_CHECK(NB >= 1, "sos_forward: need at least one band");
+    const int64_t C = C_in * NB;
     TFX_CHECK(C >= 0 && T >= 0 && K >= 0, "sos_forward: negative size");
     TFX_CHECK(x_dtype == TFX_F32 || x_dtype == TFX_F64, "sos_forward: bad x dtype %d", x_dtype);
     TFX_CHECK(y_dtype == TFX_F32 || y_dtype == TFX_F64, "sos_forward: bad y dtype %d", y_dtype);
@@ -766,15 +792,15 @@ void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C, in
         if (sy_out && K) { if (sy_in) TFX_HIP(hipMemcpyAsync(sy_out, sy_in, st_bytes, hipMemcpyDeviceToDevice, stream));
                            else TFX_HIP(hipMemsetAsync(sy_out, 0, st_bytes, stream)); }
         if (K == 0 && T > 0) {
-            TFX_CHECK(x_dtype == y_dtype, "sos_forward: K=0 needs equal dtypes");
+            TFX_CHECK(x_dtype == y_dtype && NB == 1, "sos_forward: K=0 needs equal dtypes and a single band");
             TFX_HIP(hipMemcpyAsync(y, x, (size_t)C * T * (x_dtype == TFX_F32 ? 4 : 8), hipMemcpyDeviceToDevice, stream));
         }
         return;
     }
-    for (int64_t i = 0; i < K * 6; ++i)
+    for (int64_t i = 0; i < NB * K * 6; ++i)
         TFX_CHECK(std::isfinite(sos_host[i]), "sos_forward: non-finite SOS coefficient");
 
-    SosPlan *pl = get_plan(sos_host, K, stream);
+    SosPlan *pl = get_plan(sos_host, K, stream, NB);
     int prec = precision;
     if (prec == TFX_PREC_AUTO) prec = (plan_err_bound(pl) <= auto_bound()) ? TFX_PREC_F32 : TFX_PREC_F64;
     if (x_dtype == TFX_F64 || y_dtype == TFX_F64) prec = TFX_PREC_F64;   // f64 signals: always f64 math
@@ -785,7 +811,7 @@ void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C, in
     SosParams p{};
     p.x = x; p.y = y; p.taps = y_sections;
     p.sx_in = sx_in; p.sy_in = sy_in; p.sx_out = sx_out; p.sy_out = sy_out;
-    p.C = C; p.T = T; p.K = (int)K;
+    p.C = C; p.C_in = C_in; p.T = T; p.K = (int)K;
 
     const int64_t nstreams = pl->warm;     // segmentation is decided per kernel instance (launch_one)
 
@@ -811,7 +837,7 @@ void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C, in
 
 void sos_plan_info(const double *sos_host, int64_t K, int *precision, int64_t *warmup, double *err_bound)
 {
-    SosPlan *pl = get_plan(sos_host, K, nullptr);
+    SosPlan *pl = get_plan(sos_host, K, nullptr, 1);
     const double eb = plan_err_bound(pl);
     if (precision) *precision = (eb <= auto_bound()) ? TFX_PREC_F32 : TFX_PREC_F64;
     if (warmup) *warmup = pl->warm;

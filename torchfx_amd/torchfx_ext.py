@@ -28,7 +28,7 @@ from torch import Tensor
 from torchfx_amd import _lib as L
 
 __all__ = [
-    "biquad_forward", "sos_forward", "delay_line_forward",
+    "biquad_forward", "sos_forward", "sos_bank_forward", "delay_line_forward",
     "fir_direct_forward", "fft_conv_forward", "sum_forward", "sos_plan_info", "ols_plan_info",
 ]
 
@@ -93,6 +93,36 @@ def sos_forward(x: Tensor, sos: Tensor, sos_cpu: Tensor | None, state_x: Tensor 
             L.precision_code(precision), ctypes.c_void_p(L.stream_ptr(x))))
     if return_sections:
         return y, nsx, nsy, sec
+    return y, nsx, nsy
+
+
+def sos_bank_forward(x: Tensor, sos_banks, state_x: Tensor | None, state_y: Tensor | None, *,
+                     out_dtype: torch.dtype | None = None, precision=None):
+    """Filter bank: ``sos_banks [NB,K,6]`` (host), ``x [C,T]`` -> ``y [NB,C,T]`` in one launch;
+    states ``[K, NB*C, 2]`` (band-major rows) or ``None``.  Replaces the Python loop of
+    ``LogFilterBank.forward`` (``filterbank.py:157-185``)."""
+    if x.dim() != 2:
+        raise RuntimeError(f"sos_bank_forward: x must be [C, T], got {tuple(x.shape)}")
+    L.require_device(x, "x")
+    lib = L.load()
+    x = x.contiguous()
+    C, T = x.shape
+    sos_h = _host_f64(sos_banks, 6)
+    if sos_h.ndim != 3:
+        raise RuntimeError("sos_bank_forward: sos_banks must be [NB, K, 6]")
+    NB, K = sos_h.shape[0], sos_h.shape[1]
+    sx = _state(state_x, (K, NB * C, 2), x.device, "state_x")
+    sy = _state(state_y, (K, NB * C, 2), x.device, "state_y")
+    odt = x.dtype if out_dtype is None else out_dtype
+    y = torch.empty((NB, C, T), dtype=odt, device=x.device)
+    nsx = torch.empty((K, NB * C, 2), dtype=torch.float64, device=x.device)
+    nsy = torch.empty_like(nsx)
+    with torch.cuda.device(x.device):
+        L.check(lib.tfx_sos_bank_forward(
+            _ptr(x), L.dtype_code(x), _ptr(y), L.dtype_code(y), C, T,
+            sos_h.ctypes.data_as(ctypes.c_void_p), NB, K,
+            _ptr(sx), _ptr(sy), _ptr(nsx), _ptr(nsy),
+            L.precision_code(precision), ctypes.c_void_p(L.stream_ptr(x))))
     return y, nsx, nsy
 
 
