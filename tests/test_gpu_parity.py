@@ -438,3 +438,25 @@ def test_log_filter_bank_module_on_device():
         close(y[i], e, TOL_IIR_F32OUT, f"band {i}")
     y2 = torch.cat([fb(dev(x[:, :20000])), fb(dev(x[:, 20000:]))], dim=-1)    # state carried per band
     fb.filters[0].reset_state()
+
+
+# ------------------------------------------------------------------ streaming (8f rank 1)
+def test_streaming_chunks_equal_one_shot_on_device():
+    from scipy.signal import firwin
+    from torchfx_amd import filter as F
+    from torchfx_amd.realtime import StatefulFIR, StreamProcessor
+    x = rnd((4, 300000), 21)
+    taps = firwin(1024, 5000, fs=48000)
+
+    def effects():
+        return [F.LoButterworth(2000, order=6), F.ParametricEQ(1000, 2.0, 3.0), StatefulFIR(taps)]
+    whole = dev(x)
+    for e in effects():
+        e.fs = 48000
+        whole = e(whole)
+    for chunk in (65536, 4096, 1000):
+        out = StreamProcessor(effects(), chunk_size=chunk, device=DEV).process_tensor(torch.from_numpy(x), 48000)
+        close(out, whole.cpu().numpy(), 2e-6, f"chunk={chunk}")
+    sos = np.vstack([e._sos.numpy() for e in effects()[:2] if e.compute_coefficients() is None])
+    ref = O.chain_forward(x, sos, [O.flipped_kernel(taps)])
+    close(whole, ref, TOL_CONV_F32, "one-shot vs oracle")

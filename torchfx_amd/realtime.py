@@ -1,0 +1,120 @@
+"""Chunked (streaming) execution with carried state -- SURVEY.md 8(f) rank 1.
+
+Reference: ``StreamProcessor`` (``src/torchfx/realtime/stream.py:164-347``) reads a file in
+chunks of ``chunk_size`` frames with ``overlap``, runs every effect's ``forward`` per chunk and
+relies on the IIR modules' carried DF1 state for continuity; FIR modules are stateless there, so
+seams are only right with ``overlap >= K-1``.  File I/O is out of scope here (host-side
+``soundfile``), so this mirror works on tensors already on the device, with the same chunk /
+overlap arithmetic, plus what the reference lacks: :class:`StatefulFIR`, an FIR that carries its
+last K-1 input samples so that ``overlap = 0`` streaming is exact for FIR stages too.
+"""
+from __future__ import annotations
+
+from collections.abc import Generator, Sequence
+
+import torch
+from torch import Tensor, nn
+
+from torchfx_amd.effect import FX
+from torchfx_amd.filter._base import AbstractFilter
+from torchfx_amd.filter.fir import FIR
+
+
+class StatefulFIR(FIR):
+    """FIR whose K-1 sample input history survives between calls (``reset_state()`` clears it):
+    filtering a signal chunk by chunk equals filtering it in one piece."""
+
+    def __init__(self, b, conv_mode: str = "fft") -> None:
+        super().__init__(b, conv_mode)
+        self._hist: Tensor | None = None
+
+    def reset_state(self) -> None:
+        self._hist = None
+
+    @torch.no_grad()
+    def forward(self, x: Tensor) -> Tensor:
+        from torchfx_amd import torchfx_ext
+
+        if x.ndim not in (1, 2, 3):
+            raise ValueError("Input must be of shape [T], [C, T], or [B, C, T]")
+        shape = x.shape
+        rows = x.reshape(-1, shape[-1])
+        taps = self.kernel.reshape(-1)
+        k = taps.numel()
+        if k == 1:
+            return super().forward(x)
+        h = self._hist
+        if h is None or h.shape[0] != rows.shape[0] or h.dtype != rows.dtype or h.device != rows.device:
+            h = rows.new_zeros((rows.shape[0], k - 1))
+        cat = torch.cat([h, rows], dim=1)                  # [rows, K-1+T]: history replaces the zero pad
+        self._hist = cat[:, -(k - 1):].clone()
+        if self._conv_mode == "direct":
+            y = torchfx_ext.fir_direct_forward(cat, taps)[:, k - 1:]
+        else:
+            y = torchfx_ext.fft_conv_forward(cat, taps, (0, 0))
+        return y.reshape(shape)
+
+
+class StreamProcessor:
+    """Run a list of effects over a long ``[C, T]`` tensor chunk by chunk."""
+
+    def __init__(self, effects: Sequence[FX] | nn.Sequential, chunk_size: int = 65536, overlap: int = 0,
+                 device: str = "cuda") -> None:
+        if chunk_size <= 0:
+            raise ValueError(f"chunk_size must be positive, got {chunk_size}")
+        if overlap < 0:
+            raise ValueError(f"Overlap must be non-negative, got {overlap}")
+        if overlap >= chunk_size:
+            raise ValueError(f"Overlap ({overlap}) must be less than chunk_size ({chunk_size})")
+        self._effects = list(effects)
+        for e in self._effects:
+            if not isinstance(e, FX):
+                raise TypeError("All effects must inherit from FX when used in StreamProcessor")
+        self._chunk_size, self._overlap, self._device = chunk_size, overlap, device
+
+    chunk_size = property(lambda self: self._chunk_size)
+    overlap = property(lambda self: self._overlap)
+    effects = property(lambda self: self._effects)
+
+    def __enter__(self) -> "StreamProcessor":
+        return self
+
+    def __exit__(self, *exc) -> None:
+        return None
+
+    def _configure_effects(self, fs: int) -> None:
+        """fs propagation, redesign on change, Nyquist check (``stream.py:119-162``)."""
+        nyquist = fs / 2.0
+        for e in self._effects:
+            cutoff = getattr(e, "cutoff", None)
+            if isinstance(e, AbstractFilter) and isinstance(cutoff, (int, float)) and cutoff >= nyquist:
+                raise ValueError(
+                    f"{type(e).__name__} cutoff ({cutoff} Hz) must be below the Nyquist frequency "
+                    f"({nyquist} Hz) for sample rate {fs} Hz. Reduce the cutoff or use a higher sample rate file.")
+            if hasattr(e, "fs") and e.fs != fs:
+                e.fs = fs
+                if isinstance(e, AbstractFilter):
+                    e.compute_coefficients()
+                    if callable(getattr(e, "reset_state", None)):
+                        e.reset_state()
+            if isinstance(e, AbstractFilter) and not e._has_computed_coeff:
+                e.compute_coefficients()
+
+    @torch.no_grad()
+    def process_chunks(self, x: Tensor, fs: int) -> Generator[Tensor, None, None]:
+        """Yield processed chunks; with overlap the first ``overlap`` samples of every chunk but the
+        first are dropped (``stream.py:327-331``)."""
+        self._configure_effects(fs)
+        n = x.shape[-1]
+        hop = self._chunk_size - self._overlap
+        offset = 0
+        while offset < n:
+            w = x[..., offset:offset + self._chunk_size].to(self._device)
+            for e in self._effects:
+                w = e(w)
+            yield w[..., self._overlap:] if (self._overlap > 0 and offset > 0) else w
+            offset += hop
+
+    @torch.no_grad()
+    def process_tensor(self, x: Tensor, fs: int) -> Tensor:
+        return torch.cat(list(self.process_chunks(x, fs)), dim=-1)
