@@ -457,6 +457,9 @@ def test_streaming_chunks_equal_one_shot_on_device():
     for chunk in (65536, 4096, 1000):
         out = StreamProcessor(effects(), chunk_size=chunk, device=DEV).process_tensor(torch.from_numpy(x), 48000)
         close(out, whole.cpu().numpy(), 2e-6, f"chunk={chunk}")
-    sos = np.vstack([e._sos.numpy() for e in effects()[:2] if e.compute_coefficients() is None])
-    ref = O.chain_forward(x, sos, [O.flipped_kernel(taps)])
+    two = effects()[:2]
+    for e in two:
+        e.fs = 48000
+        e.compute_coefficients()
+    ref = O.chain_forward(x, np.vstack([e._sos.numpy() for e in two]), [O.flipped_kernel(taps)])
     close(whole, ref, TOL_CONV_F32, "one-shot vs oracle")
