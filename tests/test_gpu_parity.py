@@ -354,7 +354,8 @@ def test_delay_and_passthrough(golden):
 # ------------------------------------------------------------------ native LDS-FFT overlap-save
 @pytest.mark.parametrize("C,T,K", [(1, 70000, 4096), (3, 200001, 9000), (2, 300000, 16384),
                                    (1, 262144, 65536), (3, 600000, 65536), (2, 700003, 66559),
-                                   (5, 400000, 40000), (2, 2500000, 65536), (3, 1100000, 5000)])
+                                   (5, 400000, 40000), (2, 2500000, 65536), (3, 1100000, 5000),
+                                   (2, 200000, 1024), (1, 70000, 16), (3, 150016, 100)])
 def test_native_ols_vs_rocfft_and_f64(C, T, K, monkeypatch):
     """The hand-written four-step pipeline (two frames per complex FFT) against the rocFFT path
     and against a float64 FFT convolution; odd frame counts leave an unpaired frame."""

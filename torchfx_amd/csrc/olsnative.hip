@@ -792,7 +792,7 @@ bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out)
     const int64_t lg = envi("TFX_FFT_LOG2N", 0);
     if (lg == 16 || lg == 18 || lg == 20) N = (int64_t)1 << lg;
     else if (lg != 0) return false;
-    else if (K < 4096) return false;                    // short kernels: rocFFT's single-kernel plans win
+    else if (K < envi("TFX_OLS_NATIVE_MIN_K", 16)) return false;   // a handful of taps: use the direct kernel / rocFFT
     else if (4 * K <= (1 << 16)) N = 1 << 16;
     else if (2 * K <= (1 << 18) && L < 4 * ((int64_t)1 << 20)) N = 1 << 18;
     else if (2 * K <= (1 << 20)) N = (int64_t)1 << 20;  // long signals: 4x fewer blocks, less overlap
