@@ -464,3 +464,19 @@ def test_streaming_chunks_equal_one_shot_on_device():
         e.compute_coefficients()
     ref = O.chain_forward(x, np.vstack([e._sos.numpy() for e in two]), [O.flipped_kernel(taps)])
     close(whole, ref, TOL_CONV_F32, "one-shot vs oracle")
+
+
+def test_spectral_fusion_on_device(golden):
+    """Opt-in: the whole LTI chain as one overlap-save pass == staged reference output."""
+    from scipy.signal import firwin
+    from torchfx_amd import Wave
+    from torchfx_amd import filter as F
+    g = golden("chain")
+    irs = np.random.default_rng(1).standard_normal(4097) * np.exp(-np.arange(4097) / 500.0)
+    irs = irs / np.abs(irs).sum()
+    w = Wave(g["xc"], 48000, device=DEV)
+    w.fuse_fir = w.fuse_spectral = True
+    w = (w | F.LoButterworth(2000, order=6) | F.ParametricEQ(frequency=1000, q=2.0, gain=3.0)
+         | F.FIR(firwin(1024, 5000, fs=48000)) | F.FIR(irs))
+    assert len(w.plan()) == 1
+    close(w.ys, g["yc"], TOL_CONV_F32, "spectral chain")

@@ -283,3 +283,30 @@ def test_stream_processor_chunked_equals_contiguous(oracle_backend):
         StreamProcessor([F.LoButterworth(20000, order=2)], device="cpu").process_tensor(x, 32000)
     with pytest.raises(TypeError):
         StreamProcessor([nn.Identity()])
+
+
+def test_spectral_fusion_is_opt_in_and_matches_staged(oracle_backend, golden):
+    g = golden("chain")
+    from scipy.signal import firwin
+    irs = np.random.default_rng(1).standard_normal(4097) * np.exp(-np.arange(4097) / 500.0)
+    irs = irs / np.abs(irs).sum()
+
+    def pipe(spectral):
+        w = fx.Wave(g["xc"], 48000)
+        w.fuse_fir, w.fuse_spectral = True, spectral
+        return (w | F.LoButterworth(2000, order=6) | F.ParametricEQ(frequency=1000, q=2.0, gain=3.0)
+                | F.FIR(firwin(1024, 5000, fs=48000)) | F.FIR(irs))
+    assert [type(m).__name__ for m in pipe(False).plan()] == ["FusedSOSCascade", "FIR"]
+    ws = pipe(True)
+    plan = ws.plan()
+    assert [type(m).__name__ for m in plan] == ["FIR"]                 # the whole LTI run is one FIR
+    oracle_backend.calls.clear()
+    close(ws.ys, g["yc"], 2e-5)
+    assert [c[0] for c in oracle_backend.calls] == ["fft_conv_forward"]
+    # a cascade whose memory never dies out is left alone
+    w = fx.Wave(g["xc"], 48000)
+    w.fuse_fir = w.fuse_spectral = True
+    integ = F.Biquad(100, 1.0, fs=48000)
+    integ._set_coefficients(1.0, 0.0, 0.0, -1.0, 0.0)
+    w = w | integ | F.Notch(50, 2.0) | F.FIR([0.5, 0.5])
+    assert [type(m).__name__ for m in w.plan()] == ["FusedSOSCascade", "FIR"]

@@ -45,6 +45,29 @@ def _merge_fir_run(run: list) -> nn.Module:
     return merged
 
 
+def _iir_as_fir(run: list, max_taps: int = 1 << 17) -> nn.Module | None:
+    """A *fresh* (stateless) run of IIR/Biquad steps as an equivalent FIR: the cascade's impulse
+    response truncated where the kernel planner says the filter has forgotten its past to float64
+    round-off (`warmup`: max|A^W| < 2^-60).  None when the memory is too long."""
+    import scipy.signal as sg
+
+    from torchfx_amd import torchfx_ext
+    from torchfx_amd.filter.fir import FIR
+
+    sos = torch.cat([f._sos for f in run]).numpy()
+    w = torchfx_ext.sos_plan_info(sos)["warmup"]
+    if w < 0 or w > max_taps:
+        return None
+    imp = np.zeros(int(w) + 1)
+    imp[0] = 1.0
+    h = sg.sosfilt(sos, imp)                       # float64 impulse response, |tail| < 1e-18
+    fir = FIR.__new__(FIR)
+    nn.Module.__init__(fir)
+    fir._conv_mode, fir.a = "fft", [1.0]
+    fir.register_buffer("kernel", torch.from_numpy(h[::-1].copy()).reshape(1, 1, -1))
+    return fir
+
+
 class Wave:
     """Discrete-time signal ``ys [C,T]`` sampled at ``fs`` with a deferred filter pipeline."""
 
@@ -56,6 +79,7 @@ class Wave:
         self._ys = ys if isinstance(ys, Tensor) else Tensor(ys)   # Tensor(ys): float32, as wave.py:137
         self.metadata = metadata or {}
         self.fuse_fir = os.environ.get("TORCHFX_AMD_FUSE_FIR", "0") == "1"
+        self.fuse_spectral = os.environ.get("TORCHFX_AMD_FUSE_SPECTRAL", "0") == "1"
         self.to(device)
 
     # ------------------------------------------------------------------ lazy data
@@ -99,7 +123,36 @@ class Wave:
                 run.append(m)
                 kind = k
         flush()
+        if getattr(self, "fuse_spectral", False):
+            plan = self._spectral_plan(plan)
         return plan
+
+    @staticmethod
+    def _spectral_plan(plan: list[nn.Module]) -> list[nn.Module]:
+        """Opt-in (``fuse_spectral``): an LTI run  IIR-cascade | FIR...  is ONE linear system, so a
+        freshly created (stateless) cascade that is followed by FFT-mode FIRs is folded into them as
+        its truncated impulse response -- the whole run becomes a single overlap-save pass and the
+        recursive kernel is not launched at all.  Arithmetic then is float32 FFT convolution instead
+        of float64 recursion (error ~1e-6 instead of 1 ulp), which is why this is not the default."""
+        from torchfx_amd.filter.fir import FIR
+        from torchfx_amd.filter.fused import FusedSOSCascade
+
+        out: list[nn.Module] = []
+        i = 0
+        while i < len(plan):
+            m = plan[i]
+            nxt = plan[i + 1] if i + 1 < len(plan) else None
+            if (isinstance(m, FusedSOSCascade) and m._state_x is None and isinstance(nxt, FIR)
+                    and nxt._conv_mode != "direct"):
+                members = [type("S", (), {"_sos": m._sos})()]
+                eq = _iir_as_fir(members)
+                if eq is not None:
+                    out.append(_merge_fir_run([eq, nxt]))
+                    i += 2
+                    continue
+            out.append(m)
+            i += 1
+        return out
 
     def _materialize(self) -> None:
         if not self._pipeline:
@@ -112,9 +165,10 @@ class Wave:
 
     @classmethod
     def _deferred(cls, ys: Tensor, fs: int, device, metadata, pipeline: list[nn.Module],
-                  fuse_fir: bool = False) -> "Wave":
+                  fuse_fir: bool = False, fuse_spectral: bool = False) -> "Wave":
         w = object.__new__(cls)
         w._ys, w.fs, w._device, w.metadata, w._pipeline, w.fuse_fir = ys, fs, device, metadata, pipeline, fuse_fir
+        w.fuse_spectral = fuse_spectral
         return w
 
     # ------------------------------------------------------------------ device
@@ -144,7 +198,7 @@ class Wave:
                     m.compute_coefficients()
         steps = list(f.children()) if isinstance(f, nn.Sequential) else [f]
         return Wave._deferred(self._ys, self.fs, self._device, self.metadata,
-                              self._pipeline + steps, self.fuse_fir)
+                              self._pipeline + steps, self.fuse_fir, getattr(self, "fuse_spectral", False))
 
     def __len__(self) -> int:
         return self.ys.shape[1]
