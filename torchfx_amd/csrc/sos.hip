@@ -252,7 +252,9 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
             if (final_tile) capture2(r - 1, r - 2, cv1, cv2, sx1, sx2);
             if (lane == 63) { carry[s * 4 + 0] = d[LC - 1]; carry[s * 4 + 1] = d[LC - 2]; }
 
-            // (1) zero-state response of this chunk (lane 0 starts from the true state)
+            // (1) feed-forward part f[n] = b0 v[n] + b1 v[n-1] + b2 v[n-2] is stored in place; the
+            //     recursion is run alongside only to get this chunk's END STATE from zero start
+            //     state (lane 0: from the carried true state) -- 5 flop/sample
             TC u1 = (lane == 0) ? cy1 : (TC)0;
             TC u2 = (lane == 0) ? cy2 : (TC)0;
 #pragma unroll
@@ -261,9 +263,9 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
                 TC f = b0 * v;
                 f = fma(b1, pv1, f);
                 f = fma(b2, pv2, f);
+                d[n] = f;
                 const TC t = fma(na2, u2, f);
                 const TC u = fma(na1, u1, t);
-                d[n] = u;
                 pv2 = pv1; pv1 = v;
                 u2 = u1;   u1 = u;
                 // keep the update in place: stop the scheduler hoisting all LC feed-forward parts
@@ -310,18 +312,18 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
                 s0 += q0;
                 s1 += q1;
             }
-            TC h1 = dpp_shift<0x138>(s0), h2 = dpp_shift<0x138>(s1);     // wave_shr:1, lane 0 gets 0
+            TC h1 = dpp_shift<0x138>(s0), h2 = dpp_shift<0x138>(s1);     // wave_shr:1: state at chunk start
+            if (lane == 0) { h1 = cy1; h2 = cy2; }                       // lane 0: the carried true state
 
-            // (3) add the homogeneous response of the true chunk-start state (h1,h2) =
-            //     (y[-1], y[-2]): h[n] = -a1 h[n-1] - a2 h[n-2], run as a recurrence (no table)
-            //     (A two-step form h[n] = (a1^2-a2) h[n-2] + a1 a2 h[n-3] would halve the dependent
-            //     chain but adds the spurious characteristic root z = a1, |a1| up to 2: round-off
-            //     grows like 2^LC.  Not used.)
+            // (3) the recursion proper from the TRUE start state over the stored f[n]: 2 flop/sample,
+            //     writes the section output in place.  (Cheaper than correcting the zero-state output
+            //     with its homogeneous response, 3 flop/sample, and no table.)
 #pragma unroll
             for (int n = 0; n < LC; ++n) {
-                const TC h = fma(na1, h1, na2 * h2);
-                d[n] += h;
-                h2 = h1; h1 = h;
+                const TC t = fma(na2, h2, d[n]);
+                const TC yv = fma(na1, h1, t);
+                d[n] = yv;
+                h2 = h1; h1 = yv;
                 if ((n & (SB - 1)) == SB - 1) __builtin_amdgcn_sched_barrier(0);
             }
 
