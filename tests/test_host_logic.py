@@ -310,3 +310,21 @@ def test_spectral_fusion_is_opt_in_and_matches_staged(oracle_backend, golden):
     integ._set_coefficients(1.0, 0.0, 0.0, -1.0, 0.0)
     w = w | integ | F.Notch(50, 2.0) | F.FIR([0.5, 0.5])
     assert [type(m).__name__ for m in w.plan()] == ["FusedSOSCascade", "FIR"]
+
+
+def test_pad_to_and_unfold_helpers():
+    from torchfx_amd.filter._fftconv import pad_to, unfold
+    x = torch.ones(5)
+    assert torch.equal(pad_to(x, 8), torch.tensor([1., 1, 1, 1, 1, 0, 0, 0]))
+    assert pad_to(torch.randn(3, 4, 5), 8).shape == (3, 4, 8)
+    y = torch.randn(10)
+    assert torch.equal(pad_to(y, 10), y)
+    a = torch.arange(20, dtype=torch.float32)
+    fr = unfold(a, kernel_size=5, stride=3)
+    assert fr.shape == (6, 5)
+    for i in range(5):
+        assert torch.equal(fr[i], a[3 * i:3 * i + 5])
+    assert torch.equal(fr[5], torch.tensor([15., 16, 17, 18, 19]))
+    assert unfold(torch.randn(100), 10, 5).shape == (19, 10)
+    assert unfold(torch.randn(4, 2, 100), 10, 5).shape == (4, 2, 19, 10)
+    assert unfold(torch.randn(17), 5, 3).shape[0] == 5          # tail frame zero-padded
