@@ -6,8 +6,8 @@ C, T, K = 64, 28_800_000, 65536
 x = torch.randn(C, T, device="cuda:0")
 ir = np.random.default_rng(0).standard_normal(K) * np.exp(-np.arange(K) / 8000.0)
 k = (ir / np.abs(ir).sum()).astype(np.float32)[::-1].copy()
-for lg in (18, 20):
-    for mb in (8, 16, 32, 64, 128, 256):
+for lg in (20,):
+    for mb in (24, 32, 48, 64, 96, 128):
         os.environ["TFX_FFT_LOG2N"] = str(lg); os.environ["TFX_OLS_SLAB_MB"] = str(mb)
         for _ in range(2): E.fft_conv_forward(x, k, (K - 1, 0))
         torch.cuda.synchronize(); t0 = time.perf_counter()

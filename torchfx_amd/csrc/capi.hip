@@ -48,6 +48,7 @@ static const char *g_open_name = nullptr;
 static hipEvent_t g_open_a = nullptr;
 static hipEvent_t g_last_end = nullptr;        // reusable as the next begin while g_chain is true
 static bool g_chain = false;
+static hipStream_t g_last_stream = nullptr;
 
 static hipEvent_t pool_get()
 {
@@ -63,7 +64,7 @@ void prof_begin(const char *name, hipStream_t s)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_open_name = name;
-    if (g_chain && g_last_end) { g_open_a = g_last_end; return; }
+    if (g_chain && g_last_end && g_last_stream == s) { g_open_a = g_last_end; return; }
     g_open_a = pool_get();
     if (g_open_a) (void)hipEventRecord(g_open_a, s);
 }
@@ -76,6 +77,7 @@ void prof_end(hipStream_t s)
     (void)hipEventRecord(b, s);
     g_prof.push_back(ProfRec{g_open_name, g_open_a, b});
     g_last_end = b;
+    g_last_stream = s;
     g_chain = true;
     g_open_name = nullptr;
 }

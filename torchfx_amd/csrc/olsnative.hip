@@ -831,7 +831,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     g.P2 = g.N2 + (int)envi("TFX_OLS_PITCH_PAD", 0);
     const int64_t npairs = ceil_div(g.nframes, 2);
     int64_t slab = envi("TFX_OLS_PAIRS_PER_SLAB", 0);
-    if (slab <= 0) slab = (envi("TFX_OLS_SLAB_MB", 128) << 20) / ((int64_t)OLS_N1 * g.P2 * (int64_t)sizeof(cpx));
+    if (slab <= 0) slab = (envi("TFX_OLS_SLAB_MB", 64) << 20) / ((int64_t)OLS_N1 * g.P2 * (int64_t)sizeof(cpx));
     if (slab < 1) slab = 1;
     if (slab > npairs) slab = npairs;
     cpx *T = (cpx *)scratch("olsn_T", (size_t)slab * (size_t)OLS_N1 * (size_t)g.P2 * sizeof(cpx));
@@ -849,8 +849,38 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     }
     const int ncb = g.N2 / OLS_CB;
     const bool col_r4 = envi("TFX_OLS_COL_R4", 0) != 0;
-    for (int64_t p0 = 0; p0 < npairs; p0 += slab) {
+    // Two internal streams, slabs alternate between them: while one slab drains the tail of a pass
+    // (the last, partially filled round of workgroups) the other slab's pass fills the idle CUs.
+    // Fork/join with events on the caller's stream; each lane has its own workspace.
+    constexpr int MAXL = 4;
+    int nlanes = (int)envi("TFX_OLS_STREAMS", 2);
+    if (nlanes < 1) nlanes = 1;
+    if (nlanes > MAXL) nlanes = MAXL;
+    if (npairs <= slab) nlanes = 1;
+    static hipStream_t lane_stream[MAXL] = {nullptr, nullptr, nullptr, nullptr};
+    static hipEvent_t ev_fork = nullptr, ev_join[MAXL] = {nullptr, nullptr, nullptr, nullptr};
+    cpx *Tlane[MAXL] = {T, T, T, T};
+    hipStream_t user_stream = stream;
+    if (nlanes > 1) {
+        if (!lane_stream[0]) {
+            for (int i = 0; i < MAXL; ++i) {
+                TFX_HIP(hipStreamCreateWithFlags(&lane_stream[i], hipStreamNonBlocking));
+                TFX_HIP(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
+            }
+            TFX_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        }
+        static const char *tags[MAXL] = {"olsn_T", "olsn_T2", "olsn_T3", "olsn_T4"};
+        for (int i = 1; i < nlanes; ++i)
+            Tlane[i] = (cpx *)scratch(tags[i], (size_t)slab * (size_t)OLS_N1 * (size_t)g.P2 * sizeof(cpx));
+        TFX_HIP(hipEventRecord(ev_fork, user_stream));
+        for (int i = 0; i < nlanes; ++i) TFX_HIP(hipStreamWaitEvent(lane_stream[i], ev_fork, 0));
+    }
+    int64_t slab_idx = 0;
+    for (int64_t p0 = 0; p0 < npairs; p0 += slab, ++slab_idx) {
         const int64_t np = (npairs - p0 < slab) ? (npairs - p0) : slab;
+        const int ln = nlanes > 1 ? (int)(slab_idx % nlanes) : 0;
+        hipStream_t stream = nlanes > 1 ? lane_stream[ln] : user_stream;   // shadows the parameter
+        cpx *T = Tlane[ln];
         {
             ProfScope ps("ols_col_fwd_kernel", stream);
             if (col_r4)
@@ -896,6 +926,12 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
                 hipLaunchKernelGGL(ols_col_inv16_kernel, dim3((unsigned)(np * ncb)), dim3(256), shm_col, stream,
                                    T, y, plan->tw256, g, 2 * p0);
             TFX_HIP(hipGetLastError());
+        }
+    }
+    if (nlanes > 1) {
+        for (int i = 0; i < nlanes; ++i) {
+            TFX_HIP(hipEventRecord(ev_join[i], lane_stream[i]));
+            TFX_HIP(hipStreamWaitEvent(user_stream, ev_join[i], 0));
         }
     }
 }
