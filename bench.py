@@ -350,7 +350,7 @@ def main() -> None:
             line["gather_ms"] = round(gather_ms, 2)
         if not args.no_cpu_baseline:
             try:
-                sec, ch = {"chain": (600.0, 12), "sos": (600.0, 32), "fir": (600.0, 12), "fftconv": (600.0, 16)}[args.workload]
+                sec, ch = {"chain": (600.0, 12), "sos": (600.0, 16), "fir": (300.0, 8), "fftconv": (600.0, 16)}[args.workload]
                 line["cpu_baseline"] = cpu_baseline(args.workload, sec, ch)     # ~10-20 s of CPU work
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 line["cpu_baseline"] = {"error": repr(e)}
