@@ -150,6 +150,8 @@ def main() -> None:
     ap.add_argument("--seconds", type=float, default=None, help="signal length (default: 600 chain/fftconv, 60 sos/fir)")
     ap.add_argument("--gather", action="store_true", help="also time the final RCCL gather to rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only warm-up + timed steps (for rocprofv3 runs: no single-stream / variant passes)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -205,7 +207,7 @@ def main() -> None:
     # internal streams in the timed region, which inflates each kernel's elapsed time; one extra,
     # untimed pass on a single stream gives the clean per-kernel numbers
     prof_serial = None
-    if args.workload in ("chain", "fftconv"):
+    if args.workload in ("chain", "fftconv") and not args.no_extras:
         old_env = os.environ.get("TFX_OLS_STREAMS")
         os.environ["TFX_OLS_STREAMS"] = "1"
         try:
@@ -224,7 +226,7 @@ def main() -> None:
             else:
                 os.environ["TFX_OLS_STREAMS"] = old_env
     variant = None
-    if args.workload == "chain" and rank == 0:
+    if args.workload == "chain" and rank == 0 and not args.no_extras:
         try:                                   # secondary figure, outside the timed region
             vstep, vdesc, _ = make_step("chain_spectral", x)
             vout = vstep()

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-extras $*"
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $R/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o fetch -- python $R/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o write -- python $R/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.err
