@@ -1,0 +1,31 @@
+"""bench.py pieces that run without a GPU: the CPU baseline leg and the filter set of the workload."""
+import json
+
+import numpy as np
+
+
+def test_cpu_baseline_fields_and_workload_filters():
+    import bench
+    f1, f2, fir, rev = bench.build_filters()
+    assert f1._sos.shape == (3, 6) and f2._sos.shape == (1, 6)            # 4 sections fused
+    assert fir.kernel.numel() == 1024 and rev.kernel.numel() == 65536
+    ir = bench.reverb_ir()
+    assert abs(float(np.abs(ir).sum()) - 1.0) < 1e-5 and ir.dtype == np.float32
+    cb = bench.cpu_baseline("chain", 1.0, 2)
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0
+    json.dumps(cb)
+
+
+def test_traffic_file_is_consistent():
+    import os
+    from tests.conftest import ROOT
+    tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+    c = tr["chain"]
+    per = c["per_kernel_GB_per_launch"]
+    total = 0.0
+    for name, v in per.items():
+        total += (v["read"] + v["write"]) * v.get("launches_per_step", 1)
+    assert abs(total * 1e9 - c["bytes_per_step"]) / c["bytes_per_step"] < 0.03
+    assert c["bytes_per_step"] > c["algorithmic_bytes_per_step"]

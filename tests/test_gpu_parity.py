@@ -480,3 +480,57 @@ def test_spectral_fusion_on_device(golden):
          | F.FIR(firwin(1024, 5000, fs=48000)) | F.FIR(irs))
     assert len(w.plan()) == 1
     close(w.ys, g["yc"], TOL_CONV_F32, "spectral chain")
+
+
+# ------------------------------------------------------------------ robustness sweeps
+def test_unaligned_base_pointer_and_wide_batches():
+    """Contiguous views whose storage offset breaks 16-byte alignment take the dword path;
+    many rows / few samples and few rows / many sections are also exercised."""
+    from scipy.signal import butter, ellip
+    sos = butter(4, 0.2, output="sos")
+    big = dev(rnd((3 * 5000 + 8,), 1))
+    for off in (1, 2, 3, 5):
+        x = big[off:off + 3 * 5000].view(3, 5000)
+        assert x.is_contiguous() and x.data_ptr() % 16 != 0
+        ey, _, esy = O.sos_forward(x.cpu().numpy(), sos)
+        y, _, sy = ext().sos_forward(x, None, torch.from_numpy(sos), None, None)
+        close(y, ey.astype(np.float32), TOL_IIR_F32OUT, f"offset {off}")
+        close(sy, esy, TOL_STATE)
+        k = rnd((200,), off)
+        close(ext().fir_direct_forward(x, k), O.fir_direct(x.cpu().numpy(), k), TOL_CONV_F32)
+        close(ext().fft_conv_forward(x, k, (199, 0)), O.fir_direct(x.cpu().numpy(), k), TOL_CONV_F32)
+    # many rows
+    x = rnd((1000, 3000), 2)
+    ey, _, _ = O.sos_forward(x, sos)
+    y, _, _ = ext().sos_forward(dev(x), None, torch.from_numpy(sos), None, None)
+    close(y, ey.astype(np.float32), TOL_IIR_F32OUT, "1000 rows")
+    # many sections (order-40 elliptic: K = 20) and a 64-section cascade of mild biquads
+    for sosk in (ellip(40, 0.5, 60, 0.3, output="sos"),
+                 np.vstack([butter(2, f, output="sos") for f in np.linspace(0.05, 0.8, 64)])):
+        x = rnd((2, 20000), sosk.shape[0])
+        ey, esx, esy = O.sos_forward(x, sosk)
+        y, sx, sy = ext().sos_forward(dev(x), None, torch.from_numpy(sosk), None, None, out_dtype=torch.float64)
+        close(y, ey, 1e-9, f"K={sosk.shape[0]}")
+        close(sy, esy, 1e-8 * max(1.0, np.abs(esy).max()))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_stable_cascades_near_the_unit_circle(seed):
+    """Random pole/zero placements with pole radii up to 0.9995 (memory of ~80k samples):
+    segments + warm-up halo vs the sequential oracle, float64 in/out."""
+    rng = np.random.default_rng(100 + seed)
+    K = int(rng.integers(1, 7))
+    rows = []
+    for _ in range(K):
+        r, th = rng.uniform(0.5, 0.9995), rng.uniform(0.01, 3.1)
+        zr, zth = rng.uniform(0.0, 1.2), rng.uniform(0.0, 3.14)
+        b = np.array([1.0, -2 * zr * np.cos(zth), zr * zr]) * rng.uniform(0.2, 1.0)
+        rows.append([*b, 1.0, -2 * r * np.cos(th), r * r])
+    sos = np.array(rows)
+    C, T = int(rng.integers(1, 5)), int(rng.integers(200_000, 900_000))
+    x = rnd((C, T), seed).astype(np.float64)
+    ey, esx, esy = O.sos_forward(x, sos)
+    y, sx, sy = ext().sos_forward(dev(x), None, torch.from_numpy(sos), None, None)
+    scale = max(1.0, float(np.abs(ey).max()))
+    close(y, ey, 1e-9 * scale / max(1.0, scale) , f"seed {seed}: K={K} T={T}")
+    close(sy, esy, 1e-8 * max(1.0, float(np.abs(esy).max())))
