@@ -328,3 +328,18 @@ def test_pad_to_and_unfold_helpers():
     assert unfold(torch.randn(100), 10, 5).shape == (19, 10)
     assert unfold(torch.randn(4, 2, 100), 10, 5).shape == (4, 2, 19, 10)
     assert unfold(torch.randn(17), 5, 3).shape[0] == 5          # tail frame zero-padded
+
+
+def test_wave_transform_and_merge():
+    a = fx.Wave(torch.ones(2, 10), 8000)
+    b = fx.Wave(2 * torch.ones(2, 6), 8000)
+    m = fx.Wave.merge([a, b])
+    assert m.ys.shape == (2, 10) and float(m.ys[0, 0]) == 3.0 and float(m.ys[0, 9]) == 1.0
+    assert fx.Wave.merge([a, b], split_channels=False).fs == 8000
+    assert fx.Wave.merge([a, fx.Wave(torch.zeros(1, 10), 8000)], split_channels=True).channels() == 3
+    with pytest.raises(ValueError, match="mismatch"):
+        fx.Wave.merge([a, fx.Wave(torch.ones(2, 4), 16000)])
+    with pytest.raises(ValueError, match="No waves"):
+        fx.Wave.merge([])
+    t = a.transform(lambda y, k: y * k, 4.0)
+    assert isinstance(t, fx.Wave) and float(t.ys[1, 3]) == 4.0 and len(t) == 10 and t.duration("ms") == 1.25

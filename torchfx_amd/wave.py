@@ -200,6 +200,31 @@ class Wave:
         return Wave._deferred(self._ys, self.fs, self._device, self.metadata,
                               self._pipeline + steps, self.fuse_fir, getattr(self, "fuse_spectral", False))
 
+    def transform(self, func, *args, **kwargs) -> "Wave":
+        """Apply ``func`` to the (materialised) samples and wrap the result (``wave.py:334-360``)."""
+        self._materialize()
+        return Wave(func(self._ys, *args, **kwargs), self.fs)
+
+    @classmethod
+    def merge(cls, waves: tp.Sequence["Wave"], split_channels: bool = False) -> "Wave":
+        """Mix (sum, zero-padded to the longest) or stack (``split_channels``) several waves of one
+        sample rate (``wave.py:760-830``)."""
+        if not waves:
+            raise ValueError("No waves to merge. Provide at least one wave.")
+        fs = waves[0].fs
+        for w in waves:
+            if w.fs != fs:
+                raise ValueError(f"Sampling frequency mismatch: {w.fs} != {fs}. "
+                                 "All waves must have the same sampling frequency.")
+        if split_channels:
+            return Wave(torch.cat([w.ys for w in waves], dim=0), fs)
+        longest = max(len(w) for w in waves)
+        first = waves[0].ys
+        mix = torch.zeros((first.shape[0], longest), dtype=first.dtype, device=first.device)
+        for w in waves:
+            mix[:, : len(w)] += w.ys
+        return Wave(mix, fs)
+
     def __len__(self) -> int:
         return self.ys.shape[1]
 
