@@ -275,9 +275,11 @@ def main() -> None:
                 frames = C * info["F"]
                 pairs = (frames + 1) // 2
                 n = info["N"]
-                model.update({"ols_col_fwd_kernel": frames * n * 4.0 + pairs * n * 8.0,
-                              "ols_row_kernel": pairs * n * 16.0,
-                              "ols_col_inv_kernel": pairs * n * 8.0 + 4.0 * samples})
+                for sfx in ("", "16"):
+                    model["ols_col_fwd%s_kernel" % sfx] = frames * n * 4.0 + pairs * n * 8.0
+                    model["ols_col_inv%s_kernel" % sfx] = pairs * n * 8.0 + 4.0 * samples
+                for nm in ("ols_row_kernel", "ols_row1024_kernel", "ols_row4096_kernel"):
+                    model[nm] = pairs * n * 16.0
                 line_ols = {"fft_block": n, "hop": info["S"], "blocks_per_row": info["F"], "native_lds_fft": info["native"]}
             else:
                 line_ols = None
@@ -300,22 +302,40 @@ def main() -> None:
         gpu_ms = sum(k["ms_per_step"] for k in kernels.values())
         # per-GPU algorithmic bytes of one step: 8 B per sample-channel
         alg_gb = 8.0 * samples / 1e9
+        # roofline object = the DOMINANT kernel: algorithmic work of one launch / its average
+        # duration in the timed region (HIP events on the launch stream).  The whole-step figure
+        # (all passes of the step share the one 8 B/sample) is reported beside it as step_*.
         if args.workload == "fir":
-            ach = 2.0 * 1024 * samples / (ms_step * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TF, "unit": "TFLOP/s",
-                    "frac": round(ach / FP32_PEAK_TF, 4), "traffic": None,
+            step_ach = 2.0 * 1024 * samples / (ms_step * 1e-3) / 1e12
+            roof = {"bound": "mfma", "peak": FP32_PEAK_TF, "unit": "TFLOP/s", "traffic": None,
                     "note": "2*1024 flop/sample on exact-f32 MFMA (v_mfma_f32_32x32x2_f32); HBM roof unreachable (SURVEY 7.3-3)"}
+            unit_work = 2.0 * 1024 / 1e12                                  # TFLOP per sample
         else:
-            ach = alg_gb / (ms_step * 1e-3)
-            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                    "note": "algorithmic 8 B/sample-channel x samples of one step / step time (all launches of the step)"}
-        # HBM bytes per step measured with rocprofv3 PMC passes of this same command (profiles/);
-        # counters cannot be read from inside the process, so the last profiled value is reported
+            step_ach = alg_gb / (ms_step * 1e-3)
+            roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+                    "note": "achieved = 8 B/sample-channel x samples one launch of the dominant kernel covers / its "
+                            "average duration; step_achieved = 8 B x samples of the step / step time (all passes)"}
+            unit_work = 8.0 / 1e9                                          # GB per sample
+        if dom:
+            per_launch = samples / max(kernels[dom]["launches_per_step"], 1e-9)
+            ach = unit_work * per_launch / (kernels[dom]["avg_ms_per_launch"] * 1e-3)
+        else:
+            ach = step_ach
+        roof["achieved"] = round(ach, 2)
+        roof["frac"] = round(ach / roof["peak"], 4)
+        roof["step_achieved"] = round(step_ach, 2)
+        roof["step_frac"] = round(step_ach / roof["peak"], 4)
+        # HBM bytes measured with rocprofv3 PMC passes of this same command (profiles/): counters
+        # cannot be read from inside the process, so the last profiled values are reported --
+        # `traffic` per launch of the dominant kernel (like `achieved`), `step_traffic` per step
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
             if args.workload in tr and C == 64 and seconds == 600.0:
-                roof["traffic"] = tr[args.workload]["bytes_per_step"]
+                ent = tr[args.workload]
+                roof["step_traffic"] = ent["bytes_per_step"]
+                pk = ent.get("per_kernel_GB_per_launch", {}).get(dom)
+                if pk:
+                    roof["traffic"] = round((pk["read"] + pk["write"]) * 1e9)
                 roof["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         except Exception:
             pass

@@ -257,6 +257,22 @@ def test_fir_direct_shapes_vs_f64(C, T, K):
     close(y2, exp.astype(np.float32), TOL_CONV_F32, "fft vs lfilter f64")
 
 
+@pytest.mark.parametrize("kc", [None, 128, 512, 1024])
+@pytest.mark.parametrize("C,T,K", [(2, 777, 1), (1, 20000, 101), (2, 16384, 128), (1, 16500, 129), (2, 33000, 400),
+                                   (1, 9000, 513), (1, 50000, 1024), (1, 20000, 1100), (1, 3, 700)])
+def test_fir_direct_chunk_sizes_vs_oracle(C, T, K, kc, monkeypatch):
+    """Every tap-chunk instantiation of the MFMA kernel (and the cost-based default) against the
+    oracle's float32 direct form: tile edges, rows shorter than the filter, K on chunk borders."""
+    if kc is not None:
+        monkeypatch.setenv("TFX_FIR_KC", str(kc))
+    rng = np.random.default_rng(1000 * K + T)
+    kf = (rng.standard_normal(K) / np.sqrt(K)).astype(np.float32)
+    x = rnd((C, T), K * 7 + T)
+    exp = O.fir_direct(x, kf)
+    y = ext().fir_direct_forward(dev(x), kf)
+    close(y, exp, TOL_CONV_F32, f"direct K={K} kc={kc}")
+
+
 def test_fftconv_golden(golden):
     g = golden("fftconv")
     x = dev(g["x"])

@@ -21,6 +21,7 @@
 #include "common.h"
 #include "../../include/torchfx_hip.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -65,11 +66,14 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int FIR_NJ = 4;                       // 32x32 tiles per wave
 constexpr int FIR_WOUT = FIR_NJ * 1024;         // outputs per wave
 constexpr int FIR_NOUT = 4 * FIR_WOUT;          // outputs per workgroup
-constexpr int FIR_KC = 1024;                    // tap chunk
+constexpr int FIR_KC_MAX = 1024;                // largest tap chunk (taps are zero-padded to it)
 
 __device__ __forceinline__ int xpad33(int m) { return m + (m >> 5); }
 
-// kf_dev: [Kpad] flipped taps on device, zero-padded to a multiple of FIR_KC
+// kf_dev: [Kpad] flipped taps on device, zero-padded to a multiple of FIR_KC_MAX
+// FIR_KC: taps per chunk (128 / 512 / 1024 -- short filters do not pay for 1024-tap chunks).
+// DBG (tools/ubench/fir_probe.hip only): bit 0 drops the output stores, bit 1 the global loads.
+template <int FIR_KC, int DBG = 0>
 __global__ void __launch_bounds__(256, 2)
 fir_direct_mfma_kernel(const float *__restrict__ x, float *__restrict__ y,
                        const float *__restrict__ kf_dev, int64_t C, int64_t T, int K, int nchunks,
@@ -95,32 +99,74 @@ fir_direct_mfma_kernel(const float *__restrict__ x, float *__restrict__ y,
 
     const int li = lane & 31, kk = lane >> 5;
 
+    // Per-lane LDS bases.  With s = 32*blk + 2*q + kk the padded window index of A[i=li][s] for
+    // tile t is  (xb + xb/32 + 33*li + kk) + 1056*t + 33*blk + 2*q  and the Toeplitz tap index is
+    // (31 - li + kk) + 32*blk + 2*q : everything but `blk` is an immediate ds_read offset.
+    const int xb = wave * FIR_WOUT;
+    const float *pa0 = xw + xb + (xb >> 5) + 33 * li + kk;
+    const float *pb0 = kp + 31 - li + kk;
+    constexpr int XV = (XW + 255) / 256;                    // window loads per thread
+    constexpr int KV = (31 + FIR_KC + 33 + 255) / 256;      // tap loads per thread
+
     for (int ch = 0; ch < nchunks; ++ch) {
         const int t0 = ch * FIR_KC;
-        __syncthreads();    // previous chunk's readers are done
-        // window: xw[m] = xp[n0 + t0 + m] = x[n0 + t0 + m - (K-1)]
+        // window: xw[m] = xp[n0 + t0 + m] = x[n0 + t0 + m - (K-1)].  All loads are issued before
+        // the first LDS write (branch-free: clamped address + select), so the fill costs one
+        // memory latency instead of XV of them.
         const int64_t base = n0 + t0 - (int64_t)(K - 1);
-        for (int m = tid; m < XW; m += 256) {
-            const int64_t g = base + m;
-            xw[xpad33(m)] = (g >= 0 && g < T) ? xrow[g] : 0.0f;
+        float xv[XV], kv[KV];
+        // Buffer descriptor over the part of the window that lies inside the row: reads past
+        // its end return 0 in hardware; elements before the row start are clamped to offset 0
+        // here and zeroed at the LDS write.  32-bit offsets, no per-load address pairs.
+        const int64_t gstart = base < 0 ? 0 : (base > T ? T : base);
+        const int64_t gend0 = base + (int64_t)XV * 256;
+        const int64_t gend = gend0 < gstart ? gstart : (gend0 > T ? T : gend0);
+        const int shift = (int)(base - gstart);             // <= 0; 0 for every interior tile
+        // (the 64-bit divide that produced `c` ran on the vector ALU: tell the compiler the
+        // descriptor words are wave-uniform, or every load becomes a waterfall loop)
+        const uint64_t pw = (uint64_t)(xrow + gstart);
+        const uint64_t pu = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(pw >> 32)) << 32) |
+                            (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pw);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)pu, 0, __builtin_amdgcn_readfirstlane((int)((gend - gstart) * 4)), 0x00020000);
+#pragma unroll
+        for (int r = 0; r < XV; ++r) {
+            const int e = shift + tid + 256 * r;
+            xv[r] = (DBG & 2) ? 1.0f
+                              : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (e < 0 ? 0 : e) * 4, 0, 0));
         }
-        // taps: kp[u + 31] = kf[t0 + u] for u in [0,KC), zeros elsewhere
-        for (int u = tid; u < 31 + FIR_KC + 33; u += 256) {
-            const int v = u - 31;
-            kp[u] = (v >= 0 && v < FIR_KC) ? kf_dev[t0 + v] : 0.0f;   // kf_dev is zero-padded
+#pragma unroll
+        for (int r = 0; r < KV; ++r) {
+            const int v = tid + 256 * r - 31;               // kf_dev is zero-padded to a multiple of KC
+            const int vc = v < 0 ? 0 : (v >= FIR_KC ? FIR_KC - 1 : v);
+            kv[r] = kf_dev[t0 + vc];
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep every load above, every use below
+        __syncthreads();    // previous chunk's readers are done
+#pragma unroll
+        for (int r = 0; r < XV; ++r) {
+            const int m = tid + 256 * r;
+            if (m < XW) xw[xpad33(m)] = (shift + m >= 0) ? xv[r] : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < KV; ++r) {
+            const int u = tid + 256 * r;
+            if (u < 31 + FIR_KC + 33) kp[u] = (u >= 31 && u < 31 + FIR_KC) ? kv[r] : 0.0f;
         }
         __syncthreads();
 
-        // contraction over s in [0, KC+32): step q covers s = 2q + kk
-        const int xb = wave * FIR_WOUT;
-#pragma unroll 4
-        for (int q = 0; q < (FIR_KC + 32) / 2; ++q) {
-            const int s = 2 * q + kk;
-            const float b = kp[s - li + 31];
+        // contraction over s in [0, KC+32) in blocks of 32 (16 k-steps of 2)
+        for (int blk = 0; blk < (FIR_KC + 32) / 32; ++blk) {
+            const float *pa = pa0 + 33 * blk;
+            const float *pb = pb0 + 32 * blk;
 #pragma unroll
-            for (int t = 0; t < FIR_NJ; ++t) {
-                const float a = xw[xpad33(xb + t * 1024 + 32 * li + s)];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            for (int q = 0; q < 16; ++q) {
+                const float b = pb[2 * q];
+#pragma unroll
+                for (int t = 0; t < FIR_NJ; ++t) {
+                    const float a = pa[1056 * t + 2 * q];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                }
             }
         }
     }
@@ -133,7 +179,7 @@ fir_direct_mfma_kernel(const float *__restrict__ x, float *__restrict__ y,
         for (int r = 0; r < 16; ++r) {
             const int i = 8 * (r >> 2) + 4 * kk + (r & 3);
             const int64_t n = nb + 32 * i + li;
-            if (n < T) yrow[n] = acc[t][r];
+            if ((DBG & 1) ? (acc[t][r] == 1234.5f) : (n < T)) yrow[n] = acc[t][r];
         }
     }
 }
@@ -183,25 +229,41 @@ void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
     TFX_CHECK(K < (1 << 30), "fir_direct_forward: kernel too long");
     if (C == 0 || T == 0) return;
     const size_t esz = dtype == TFX_F32 ? 4 : 8;
-    const int64_t Kpad = ceil_div(K, FIR_KC) * FIR_KC;
+    const int64_t Kpad = ceil_div(K, FIR_KC_MAX) * FIR_KC_MAX;
     const void *kdev = cached_taps(kernel_host, (size_t)K * esz, (size_t)Kpad * esz);
     if (dtype == TFX_F32) {
         const int64_t tiles = ceil_div(T, FIR_NOUT);
         TFX_CHECK(C * tiles < (1ll << 31), "fir_direct_forward: grid too large");
-        constexpr int XW = FIR_NOUT + FIR_KC + 32;
-        constexpr int XW_PAD = XW + (XW >> 5) + 1;
-        const size_t shmem = (((XW_PAD + 3) & ~3) + 31 + FIR_KC + 33) * sizeof(float);
-        static bool attr_done = false;
-        if (!attr_done) {
-            TFX_HIP(hipFuncSetAttribute((const void *)fir_direct_mfma_kernel,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-            attr_done = true;
+        // chunk size: cost per chunk ~ (KC+32)/32 contraction blocks + ~4 blocks' worth of refill
+        int kc = 1024;
+        int64_t best = -1;
+        for (int cand : {128, 512, 1024}) {
+            const int64_t cost = ceil_div(K, cand) * ((cand + 32) / 32 + 4);
+            if (best < 0 || cost < best) best = cost, kc = cand;
         }
-        ProfScope ps("fir_direct_mfma_kernel", stream);
-        hipLaunchKernelGGL(fir_direct_mfma_kernel, dim3((unsigned)(C * tiles)), dim3(256), shmem, stream,
-                           (const float *)x, (float *)y, (const float *)kdev, C, T, (int)K,
-                           (int)(Kpad / FIR_KC), tiles);
-        TFX_HIP(hipGetLastError());
+        if (const char *e = getenv("TFX_FIR_KC")) {
+            const int v = atoi(e);
+            if (v == 128 || v == 512 || v == 1024) kc = v;
+        }
+        const int nchunks = (int)ceil_div(K, kc);
+        auto launch = [&](auto kern, int KC) {
+            const int XW = FIR_NOUT + KC + 32;
+            const int XW_PAD = XW + (XW >> 5) + 1;
+            const size_t shmem = (((XW_PAD + 3) & ~3) + 31 + KC + 33) * sizeof(float);
+            static bool attr_done[3] = {false, false, false};
+            bool &done = attr_done[KC == 128 ? 0 : (KC == 512 ? 1 : 2)];
+            if (!done) {
+                TFX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+                done = true;
+            }
+            ProfScope ps("fir_direct_mfma_kernel", stream);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(C * tiles)), dim3(256), shmem, stream, (const float *)x,
+                               (float *)y, (const float *)kdev, C, T, (int)K, nchunks, tiles);
+            TFX_HIP(hipGetLastError());
+        };
+        if (kc == 128) launch(fir_direct_mfma_kernel<128, 0>, 128);
+        else if (kc == 512) launch(fir_direct_mfma_kernel<512, 0>, 512);
+        else launch(fir_direct_mfma_kernel<1024, 0>, 1024);
     } else {
         const int64_t tiles = ceil_div(T, 1024);
         TFX_CHECK(C * tiles < (1ll << 31), "fir_direct_forward: grid too large");

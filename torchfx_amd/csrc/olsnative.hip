@@ -882,7 +882,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
         hipStream_t stream = nlanes > 1 ? lane_stream[ln] : user_stream;   // shadows the parameter
         cpx *T = Tlane[ln];
         {
-            ProfScope ps("ols_col_fwd_kernel", stream);
+            ProfScope ps(col_r4 ? "ols_col_fwd_kernel" : "ols_col_fwd16_kernel", stream);
             if (col_r4)
                 hipLaunchKernelGGL(ols_col_fwd_kernel, dim3((unsigned)(np * ncb)), dim3(256), shm_col, stream,
                                    x, T, plan->tw256, g, 2 * p0);
@@ -893,7 +893,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
         }
         {
             const int64_t nrows = np * OLS_N1;
-            ProfScope ps("ols_row_kernel", stream);
+            ProfScope ps(g.N2 == 4096 ? "ols_row4096_kernel" : (g.N2 == 1024 && envi("TFX_OLS_ROW_R4", 0) == 0 ? "ols_row1024_kernel" : "ols_row_kernel"), stream);
             if (g.N2 == 4096 && envi("TFX_OLS_ROW_PF", 0) != 0) {
                 const int64_t wgs = (int64_t)envi("TFX_OLS_ROW_WGS_PER_CU", 2) * 256;
                 hipLaunchKernelGGL(ols_row4096_kernel<true>, dim3((unsigned)(nrows < wgs ? nrows : wgs)), dim3(256),
@@ -918,7 +918,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
             TFX_HIP(hipGetLastError());
         }
         {
-            ProfScope ps("ols_col_inv_kernel", stream);
+            ProfScope ps(col_r4 ? "ols_col_inv_kernel" : "ols_col_inv16_kernel", stream);
             if (col_r4)
                 hipLaunchKernelGGL(ols_col_inv_kernel, dim3((unsigned)(np * ncb)), dim3(256), shm_col, stream,
                                    T, y, plan->tw256, g, 2 * p0);
