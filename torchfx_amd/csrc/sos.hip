@@ -62,15 +62,15 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// DPP shift of a value across lanes; lanes with no source lane receive 0.
+// DPP shift of a value across lanes; lanes with no source lane receive 0 (bound_ctrl).
 template <int CTRL> __device__ __forceinline__ float dpp_shift(float v)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
 template <int CTRL> __device__ __forceinline__ double dpp_shift(double v)
 {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ float read_lane(float v, int l)
@@ -245,32 +245,30 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
             };
 
             // input history of this lane's chunk: previous lane's last two inputs
-            TC pv1 = __shfl_up(d[LC - 1], 1);
-            TC pv2 = __shfl_up(d[LC - 2], 1);
+            TC pv1 = dpp_shift<0x138>(d[LC - 1]);     // wave_shr:1
+            TC pv2 = dpp_shift<0x138>(d[LC - 2]);
             if (lane == 0) { pv1 = cv1; pv2 = cv2; }
             TC sx1 = (TC)0, sx2 = (TC)0;
             if (final_tile) capture2(r - 1, r - 2, cv1, cv2, sx1, sx2);
             if (lane == 63) { carry[s * 4 + 0] = d[LC - 1]; carry[s * 4 + 1] = d[LC - 2]; }
 
-            // (1) feed-forward part f[n] = b0 v[n] + b1 v[n-1] + b2 v[n-2] is stored in place; the
-            //     recursion is run alongside only to get this chunk's END STATE from zero start
-            //     state (lane 0: from the carried true state) -- 5 flop/sample
+            // (1a) feed-forward part f[n] = b0 v[n] + b1 v[n-1] + b2 v[n-2], written IN PLACE by
+            //      walking n downwards (f[n] never needs v[m] for m > n): 3 flop/sample, no second
+            //      register set and no copies
+#pragma unroll
+            for (int n = LC - 1; n >= 0; --n) {
+                const TC x1 = n >= 1 ? d[n - 1] : pv1;
+                const TC x2 = n >= 2 ? d[n - 2] : (n == 1 ? pv1 : pv2);
+                d[n] = fma(b2, x2, fma(b1, x1, b0 * d[n]));
+            }
+            // (1b) the recursion over f from zero start state (lane 0: from the carried true
+            //      state), only to get this chunk's END STATE -- 2 flop/sample, nothing stored
             TC u1 = (lane == 0) ? cy1 : (TC)0;
             TC u2 = (lane == 0) ? cy2 : (TC)0;
 #pragma unroll
             for (int n = 0; n < LC; ++n) {
-                const TC v = d[n];
-                TC f = b0 * v;
-                f = fma(b1, pv1, f);
-                f = fma(b2, pv2, f);
-                d[n] = f;
-                const TC t = fma(na2, u2, f);
-                const TC u = fma(na1, u1, t);
-                pv2 = pv1; pv1 = v;
+                const TC u = fma(na1, u1, fma(na2, u2, d[n]));
                 u2 = u1;   u1 = u;
-                // keep the update in place: stop the scheduler hoisting all LC feed-forward parts
-                // ahead of the recurrence (that doubles the live registers)
-                if ((n & (SB - 1)) == SB - 1) __builtin_amdgcn_sched_barrier(0);
             }
 
             // (2) inclusive scan of chunk end-states over lanes:  S_j = sum_i P^(j-i) z_i, then the
