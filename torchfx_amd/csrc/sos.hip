@@ -37,9 +37,10 @@ namespace tfx {
 // Table layout per section (TC elements):
 //   [0..4]  b0 b1 b2 -a1 -a2      [5..7] pad
 //   [8 + 4k + {0..3}]             Cmp^(LC * 2^k) row-major, k < 6   (Cmp = [[-a1,-a2],[1,0]])
-//   [32 + 4p + {0..3}]            Cmp^(LC * (p+1)), p < 16: per-lane matrix of the scan's row step
+//   [32 + 4p + {0..3}]            Cmp^(LC * (p+1)), p < 32: per-lane matrices of the scan's two
+//                                 cross-row steps (p = lane % 16 and p = lane % 32)
 // ------------------------------------------------------------------------------------------
-__host__ __device__ constexpr int tab_stride(int) { return 32 + 64; }
+__host__ __device__ constexpr int tab_stride(int) { return 32 + 128; }
 
 struct SosParams {
     const void *x;
@@ -71,6 +72,18 @@ template <int CTRL> __device__ __forceinline__ double dpp_shift(double v)
 {
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// DPP row broadcast (row_bcast:15 = 0x142, row_bcast:31 = 0x143) into the rows of ROWMASK; all
+// other lanes receive 0.
+template <int CTRL, int ROWMASK> __device__ __forceinline__ float dpp_bcast(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false));
+}
+template <int CTRL, int ROWMASK> __device__ __forceinline__ double dpp_bcast(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xF, false);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ float read_lane(float v, int l)
@@ -217,11 +230,13 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
         for (int s = 0; s < K; ++s) {
             const ctab_t tb = tab + s * TS;
             const TC b0 = tb[0], b1 = tb[1], b2 = tb[2], na1 = tb[3], na2 = tb[4];
-            TC mq[4];
+            TC mqa[4], mqb[4];                  // P^(lane%16 + 1), P^(lane%32 + 1)
             {
-                const TC *mp = (const TC *)p.tab + (band * K + s) * TS + 32 + 4 * (lane & 15);
+                const TC *mp = (const TC *)p.tab + (band * K + s) * TS + 32;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) mq[i] = mp[i];
+                for (int i = 0; i < 4; ++i) mqa[i] = mp[4 * (lane & 15) + i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mqb[i] = mp[4 * (lane & 31) + i];
             }
             const TC cv1 = carry[s * 4 + 0], cv2 = carry[s * 4 + 1];
             const TC cy1 = carry[s * 4 + 2], cy2 = carry[s * 4 + 3];
@@ -272,14 +287,13 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
             }
 
             // (2) inclusive scan of chunk end-states over lanes:  S_j = sum_i P^(j-i) z_i, then the
-            //     exclusive shift (h1,h2) = S_{j-1}.  All cross-lane traffic is DPP (row_shr within a
-            //     16-lane row, v_readlane for the three row aggregates, wave_shr:1 for the final
-            //     shift): a few cycles of latency per step instead of an LDS round trip per
-            //     ds_bpermute -- the kernel is latency-bound, not issue-bound.
-            //       a. intra-row Kogge-Stone with P^1, P^2, P^4, P^8 (lanes without a source add 0)
-            //       b. row aggregates R_r = I at lane 16r+15; E_1 = R_0, E_r = R_{r-1} + P^16 E_{r-1}
-            //       c. effect of E_r on lane p of row r is P^(p+1) E_r: binary expansion of p with
-            //          the same P^(2^k) matrices, no shuffles
+            //     exclusive shift (h1,h2) = S_{j-1}.  All cross-lane traffic is DPP -- a few cycles of
+            //     latency per step instead of an LDS round trip per ds_bpermute:
+            //       a. intra-row Kogge-Stone with P^1, P^2, P^4, P^8 (row_shr; lanes without a
+            //          source add 0)
+            //       b. row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3, each applied with
+            //          the lane's own matrix P^(lane%16+1) / P^(lane%32+1) from the table
+            //       c. wave_shr:1 turns the inclusive scan into every lane's start state
             const ctab_t pm = tb + 8;
             TC s0 = u1, s1 = u2;
 #define TFX_KS_STEP(K_, CTRL_)                                                            \
@@ -294,21 +308,15 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
             TFX_KS_STEP(3, 0x118)   // row_shr:8
 #undef TFX_KS_STEP
             {
-                const TC r00 = read_lane(s0, 15), r01 = read_lane(s1, 15);
-                const TC r10 = read_lane(s0, 31), r11 = read_lane(s1, 31);
-                const TC r20 = read_lane(s0, 47), r21 = read_lane(s1, 47);
-                const TC p00 = pm[16], p01 = pm[17], p10 = pm[18], p11 = pm[19];      // P^16
-                const TC e20 = r10 + fma(p00, r00, p01 * r01), e21 = r11 + fma(p10, r00, p11 * r01);
-                const TC e30 = r20 + fma(p00, e20, p01 * e21), e31 = r21 + fma(p10, e20, p11 * e21);
-                const int row = lane >> 4;
-                TC e0 = row == 1 ? r00 : (row == 2 ? e20 : e30);
-                TC e1 = row == 1 ? r01 : (row == 2 ? e21 : e31);
-                if (row == 0) { e0 = (TC)0; e1 = (TC)0; }
-                // q = P^(pp+1) e with the lane's own matrix (one 4-element gather per section instead
-                // of a 4-step conditional binary expansion)
-                const TC q0 = fma(mq[0], e0, mq[1] * e1), q1 = fma(mq[2], e0, mq[3] * e1);
-                s0 += q0;
-                s1 += q1;
+                // b. rows 1 and 3 take in the aggregate of the row before them (row_bcast:15),
+                //    then rows 2 and 3 the inclusive value of lane 31 (row_bcast:31): two DPP
+                //    steps with per-lane matrices instead of readlanes + a select tree
+                const TC a0 = dpp_bcast<0x142, 0xA>(s0), a1 = dpp_bcast<0x142, 0xA>(s1);
+                s0 += fma(mqa[0], a0, mqa[1] * a1);
+                s1 += fma(mqa[2], a0, mqa[3] * a1);
+                const TC c0 = dpp_bcast<0x143, 0xC>(s0), c1 = dpp_bcast<0x143, 0xC>(s1);
+                s0 += fma(mqb[0], c0, mqb[1] * c1);
+                s1 += fma(mqb[2], c0, mqb[3] * c1);
             }
             TC h1 = dpp_shift<0x138>(s0), h2 = dpp_shift<0x138>(s1);     // wave_shr:1: state at chunk start
             if (lane == 0) { h1 = cy1; h2 = cy2; }                       // lane 0: the carried true state
@@ -506,7 +514,7 @@ static void fill_tables(const std::vector<double> &sos, int K, int LC, std::vect
         P[0] = al1; P[1] = be1; P[2] = al2; P[3] = be2;          // Cmp^LC
         {
             ld Q[4] = {P[0], P[1], P[2], P[3]};                   // Cmp^(LC (p+1))
-            for (int pp = 0; pp < 16; ++pp) {
+            for (int pp = 0; pp < 32; ++pp) {
                 for (int i = 0; i < 4; ++i) tb[32 + 4 * pp + i] = (TC)Q[i];
                 const ld q0 = Q[0] * P[0] + Q[1] * P[2], q1 = Q[0] * P[1] + Q[1] * P[3];
                 const ld q2 = Q[2] * P[0] + Q[3] * P[2], q3 = Q[2] * P[1] + Q[3] * P[3];
