@@ -370,7 +370,7 @@ def main() -> None:
             line["variants"] = {"spectral_fusion": variant}
         if gather_ms is not None:
             line["gather_ms"] = round(gather_ms, 2)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only (contract)
             try:
                 sec, ch = {"chain": (600.0, 12), "sos": (600.0, 16), "fir": (300.0, 8), "fftconv": (600.0, 16)}[args.workload]
                 line["cpu_baseline"] = cpu_baseline(args.workload, sec, ch)     # ~10-20 s of CPU work
