@@ -141,3 +141,33 @@ def test_cfg5_chain_per_gpu_64ch_600s():
     ys = ext().fft_conv_forward(ys, kf, (1023, 0))
     ys = ext().fft_conv_forward(ys, kr, (65535, 0))
     assert maxerr(ys[:, -30 * FS:], y[:2, -30 * FS:]) <= 1e-5
+
+
+def test_more_than_2_31_samples_in_one_call():
+    """80 ch x 30 M samples = 2.4e9 elements per tensor: every kernel's index math beyond 2^31
+    (the reference's CUDA kernels index C*T with `int`, parallel_scan.cu:293).  The last row sits
+    entirely past the 2^31-element mark; it is checked against the oracle, as is row 0."""
+    C, T = 80, 30_000_000
+    assert C * T > 2 ** 31 and (C - 1) * T > 2 ** 31
+    x = signal(C, T, 9)
+    rows = (0, C - 1)
+    xh = {c: x[c:c + 1].cpu().numpy() for c in rows}
+    sos = cfg2_sos()
+    y, _, sy = ext().sos_forward(x, None, sos, None, None)
+    for c in rows:
+        ey, _, esy = O.sos_forward(xh[c], sos.numpy())
+        assert np.abs(y[c].cpu().numpy() - ey[0].astype(np.float32)).max() <= 1.5e-7 * max(1, np.abs(ey).max())
+        assert np.abs(sy[:, c].cpu().numpy() - esy[:, 0]).max() <= 2e-10
+    del y
+    kf = (np.random.default_rng(3).standard_normal(48) / 7.0).astype(np.float32)
+    y = ext().fir_direct_forward(x, kf)
+    for c in rows:
+        assert np.abs(y[c].cpu().numpy() - O.fir_direct(xh[c], kf)[0]).max() <= 1e-5
+    del y
+    K = 4096
+    kf = (reverb_ir(K)[::-1]).copy()
+    y = ext().fft_conv_forward(x, kf, (K - 1, 0))
+    assert y.shape == (C, T)
+    for c in rows:
+        ey = O.fft_conv1d(xh[c], kf, (K - 1, 0))
+        assert np.abs(y[c].cpu().numpy() - ey[0]).max() <= 1e-5
