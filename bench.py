@@ -94,8 +94,8 @@ def make_step(workload: str, x: torch.Tensor):
 
 def cpu_baseline(workload: str, seconds: float, channels: int) -> dict:
     """Oracle on the host, single thread, bounded sample of the same workload."""
-    os.environ["OMP_NUM_THREADS"] = "1"
     from oracle import oracle as O
+    cores = O.set_threads(1)            # explicit: the OpenMP runtime is already up, env vars are too late
 
     f1, f2, fir, rev = build_filters()
     sos = np.vstack([f1._sos.numpy(), f2._sos.numpy()])
@@ -134,8 +134,29 @@ def cpu_baseline(workload: str, seconds: float, channels: int) -> dict:
         scipy_val = round(nsamp / sdt / 1e6, 3)
     except Exception:
         pass
-    return {"value": round(channels * T / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "scipy_value": scipy_val,
+    # the reference's own compiled CPU IIR kernel (oracle/_ref, built from the reference's sources
+    # in the build container; the prebuilt .so travels to the GPU box) on the same sample
+    ref_iir = None
+    if workload in ("sos", "chain"):
+        try:
+            import subprocess
+            import tempfile
+            with tempfile.NamedTemporaryFile(suffix=".npy") as tf:
+                np.save(tf.name, sos)
+                env = dict(os.environ, OMP_NUM_THREADS="1")
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_time.py"), str(channels),
+                                    str(seconds), tf.name], env=env, capture_output=True, text=True, timeout=300)
+            ref_iir = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:
+            ref_iir = {"error": repr(e)}
+    if workload == "sos" and ref_iir and "value" in ref_iir:
+        return {"value": ref_iir["value"], "unit": "Msamples/s", "cores": 1, "kind": "reference",
+                "port_value": round(channels * T / dt / 1e6, 3), "scipy_value": scipy_val,
+                "sample": f"{channels} ch x {seconds:g} s @ 48 kHz float32, the reference's own sos_forward_cpu "
+                          f"(oracle/_ref/torchfx_ext.so, -O3 -ffast-math as its CMakeLists) incl. its float64 casts, "
+                          f"1 thread, {ref_iir['seconds']:.2f} s; port_value = our C oracle on the same sample"}
+    return {"value": round(channels * T / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "scipy_value": scipy_val, "reference_iir_stage": ref_iir,
             "sample": f"{channels} ch x {seconds:g} s @ 48 kHz float32, oracle (C float64 DF1 + numpy overlap-save, "
                       f"reference framing N=int(5K)), 1 thread, {dt:.2f} s"}
 
@@ -372,7 +393,7 @@ def main() -> None:
             line["gather_ms"] = round(gather_ms, 2)
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only (contract)
             try:
-                sec, ch = {"chain": (600.0, 12), "sos": (600.0, 16), "fir": (300.0, 8), "fftconv": (600.0, 16)}[args.workload]
+                sec, ch = {"chain": (600.0, 12), "sos": (600.0, 16), "fir": (120.0, 4), "fftconv": (600.0, 16)}[args.workload]
                 line["cpu_baseline"] = cpu_baseline(args.workload, sec, ch)     # ~10-20 s of CPU work
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 line["cpu_baseline"] = {"error": repr(e)}

@@ -18,6 +18,23 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* Channel loops are OpenMP-parallel (tests want them fast); bench.py's cpu_baseline pins the
+ * thread count explicitly so that "cores" in its report is what actually ran. */
+int oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
 
 /* ---------------------------------------------------------------------------
  * Fused K-section Direct-Form-I SOS cascade, float64.

@@ -34,6 +34,13 @@ def _lib() -> ctypes.CDLL:
     return _LIB
 
 
+def set_threads(n: int) -> int:
+    """Pin the OpenMP thread count of the C oracle (returns the count now in force)."""
+    lib = _lib()
+    lib.oracle_set_threads.restype = ctypes.c_int
+    return int(lib.oracle_set_threads(ctypes.c_int(int(n))))
+
+
 def _p(a: np.ndarray | None):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
