@@ -114,9 +114,11 @@ def fir_direct(x, kernel):
     return y
 
 
-def fft_conv1d(x, kernel, padding=(0, 0), block_ratio=5.0):
+def fft_conv1d(x, kernel, padding=(0, 0), block_ratio=5.0, threads=1):
     """Overlap-save, restating ``_fftconv.py:70-141`` line by line in numpy
     (numpy >= 2 transforms float32 in float32, like ``torch.fft``).
+    ``threads`` > 1 only spreads the independent channels over a thread pool (bench.py's
+    all-cores CPU baseline); the arithmetic per channel is unchanged.
 
     ``x`` ``[C,T]`` (the reference's ``[B,C,T]`` with B folded into C),
     ``kernel`` ``[K]`` *flipped* taps; returns ``[C, T+l+r-K+1]``.
@@ -139,21 +141,29 @@ def fft_conv1d(x, kernel, padding=(0, 0), block_ratio=5.0):
     tgt = (n_frames - 1) * hop + block
     xp = np.pad(x, ((0, 0), (0, tgt - length)))
     out = np.empty((C, n_frames * hop), dtype=x.dtype)
-    for c in range(C):           # frame-by-frame to bound memory (same arithmetic)
+    def one(c):                  # channel by channel to bound memory (same arithmetic)
         frames = np.lib.stride_tricks.as_strided(
             xp[c], shape=(n_frames, block), strides=(xp.strides[1] * hop, xp.strides[1]))
         fz = np.fft.rfft(frames, axis=-1)                                # :130
         oz = fz * np.conj(kz)                                            # :131
         o = np.fft.irfft(oz, n=block, axis=-1)                           # :132
         out[c] = o[:, :hop].reshape(-1)                                  # :135-136
+
+    if threads > 1 and C > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=int(threads)) as ex:
+            list(ex.map(one, range(C)))
+    else:
+        for c in range(C):
+            one(c)
     return out[:, : length - K + 1]                                      # :139-140
 
 
-def fir_forward(x, kernel, conv_mode="fft"):
+def fir_forward(x, kernel, conv_mode="fft", threads=1):
     """``FIR.forward`` (``fir.py:526-579``) on ``[C,T]``."""
     K = kernel.shape[-1]
     if conv_mode in ("fft", "auto"):
-        return fft_conv1d(x, kernel, padding=(K - 1, 0))
+        return fft_conv1d(x, kernel, padding=(K - 1, 0), threads=threads)
     return fir_direct(x, kernel)
 
 
@@ -170,11 +180,11 @@ def delay_line(x, delay, decay, mix):
 
 
 # --------------------------------------------------------------------------- chain
-def chain_forward(x, sos, fir_kernels):
+def chain_forward(x, sos, fir_kernels, threads=1):
     """The BASELINE cfg-5 pipe ``wave | iir... | FIR | FIR`` as the reference
     runs it: one fused SOS cascade (``wave.py:207-239``), then each FIR in its
     default fft mode (``fir.py:552-555``), all on a float32 ``[C,T]`` signal."""
     y, _, _ = iir_module_forward(x, sos)
     for k in fir_kernels:
-        y = fir_forward(y, k, "fft")
+        y = fir_forward(y, k, "fft", threads=threads)
     return y
