@@ -173,6 +173,33 @@ int tfx_delay_line_forward(const void *x, void *y, int dtype, int64_t C, int64_t
 int tfx_sum_forward(const void *const *xs_host, int n, void *y, int dtype,
                     int64_t numel, tfx_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * Elementwise effects that sit between filters in a pipeline.
+ *
+ * tfx_gain_forward -- Gain.forward, src/torchfx/effect.py:361-383:  y = x * gain, then (clamp != 0)
+ *   clip to [-1, 1].  `gain` is the LINEAR factor (the host layer maps "db" / "power" through
+ *   10^(g/20), effect.py:132-136,372-378) and is rounded to the signal dtype like torch does for
+ *   tensor * python_float.  y may alias x (pure elementwise).
+ *
+ * tfx_stat_forward -- the reductions behind the normalization strategies (effect.py:678-790):
+ *   mode TFX_STAT_ABSMAX: max|x| ;  TFX_STAT_RMS: sqrt(mean(x^2)) (float64 accumulation, deterministic).
+ *   per_row != 0: one value per row -> out_dev[C];  else one value over all C*T -> out_dev[1].
+ *   out_dev: DEVICE float64.  NaN anywhere gives NaN (torch.max semantics).
+ *
+ * tfx_normalize_forward -- Normalize.forward with PeakNormalizationStrategy (mode ABSMAX, per_row 0,
+ *   effect.py:696-698), PerChannelNormalizationStrategy (ABSMAX, per_row 1, :775-786) or
+ *   RMSNormalizationStrategy (RMS, per_row 0, :719-721):  y = s > 0 ? (x / s) * peak : x, evaluated in
+ *   the signal dtype in that order.  The statistic never leaves the device (the reference's
+ *   `if max_val > 0` is a blocking host read).  y may alias x.
+ * ------------------------------------------------------------------------- */
+enum tfx_stat { TFX_STAT_ABSMAX = 0, TFX_STAT_RMS = 1 };
+int tfx_gain_forward(const void *x, void *y, int dtype, int64_t numel, double gain, int clamp,
+                     tfx_stream_t stream);
+int tfx_stat_forward(const void *x, int dtype, int64_t C, int64_t T, int mode, int per_row,
+                     double *out_dev, tfx_stream_t stream);
+int tfx_normalize_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, int mode, int per_row,
+                          double peak, tfx_stream_t stream);
+
 /* Timing hooks for bench.py: HIP events recorded on the SAME stream the
  * kernels are launched on (torch.cuda.Event only sees torch's current stream).
  * tfx_prof_enable(1) makes every kernel launch inside the library bracket

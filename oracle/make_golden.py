@@ -346,6 +346,47 @@ def main() -> None:
     np.savez(os.path.join(OUT, "delay.npz"), x=xd.numpy(), y=yd)
     check("delay", O.delay_line(xd.numpy(), 100, 0.5, 0.3), yd, 1e-7)
 
+    # ---------------------------------------------- effects between filters
+    from torchfx import effect as E
+    d = {}
+    xe = rnd((4, 5000), 21) * 1.7                      # peaks above 1 so that clamp does something
+    xe[3] = 0.0                                         # a silent channel (per-channel zero rule)
+    xe64 = rnd((2, 3001), 22, torch.float64)
+    d["x"], d["x64"], d["zeros"] = xe.numpy(), xe64.numpy(), np.zeros((2, 64), np.float32)
+    for tag, kw in {"amp": dict(gain=0.37, gain_type="amplitude"), "db": dict(gain=-4.5, gain_type="db"),
+                    "db0": dict(gain=0.0, gain_type="db"), "pow": dict(gain=2.5, gain_type="power"),
+                    "clamp": dict(gain=1.9, gain_type="amplitude", clamp=True)}.items():
+        d["gain_" + tag] = E.Gain(**kw)(xe).numpy()
+        check("gain." + tag, O.gain(xe.numpy(), **kw), d["gain_" + tag], 1e-7)
+    d["gain64_db"] = E.Gain(3.0, "db")(xe64).numpy()
+    check("gain.f64", O.gain(xe64.numpy(), 3.0, "db"), d["gain64_db"], 1e-15)
+    strat = {"peak": E.PeakNormalizationStrategy(), "rms": E.RMSNormalizationStrategy(),
+             "percentile": E.PercentileNormalizationStrategy(97.0), "per_channel": E.PerChannelNormalizationStrategy()}
+    for tag, st in strat.items():
+        d["norm_" + tag] = E.Normalize(peak=0.8, strategy=st)(xe).numpy()
+        d["norm64_" + tag] = E.Normalize(peak=1.25, strategy=st)(xe64).numpy()
+        d["normz_" + tag] = E.Normalize(peak=0.8, strategy=st)(torch.from_numpy(d["zeros"])).numpy()
+        check("norm." + tag, O.normalize(xe.numpy(), 0.8, tag, 97.0), d["norm_" + tag], 1e-6)
+        check("norm64." + tag, O.normalize(xe64.numpy(), 1.25, tag, 97.0), d["norm64_" + tag], 1e-14)
+        check("normz." + tag, O.normalize(d["zeros"], 0.8, tag, 97.0), d["normz_" + tag], 0.0)
+    x3 = rnd((2, 3, 700), 23)
+    d["x3"], d["norm3_per_channel"] = x3.numpy(), E.Normalize(0.5, E.PerChannelNormalizationStrategy())(x3).numpy()
+    check("norm3.per_channel", O.normalize(x3.numpy(), 0.5, "per_channel"), d["norm3_per_channel"], 1e-6)
+    # the mixed pipeline of tests/test_chain_fusion.py:102-121: IIR runs around a Gain
+    xm = rnd((2, 6000), 24)
+    fl = [F.LoButterworth(4000, order=2), F.HiButterworth(200, order=2), E.Gain(0.5),
+          F.LoButterworth(6000, order=2), F.HiButterworth(100, order=2)]
+    wv = Wave(xm, 48000)
+    for m in fl:
+        wv = wv | m
+    d["mix_x"], d["mix_y"] = xm.numpy(), wv.ys.numpy()
+    d["mix_sos_a"] = np.vstack([sos_of(fl[0]), sos_of(fl[1])])
+    d["mix_sos_b"] = np.vstack([sos_of(fl[3]), sos_of(fl[4])])
+    ya = O.iir_module_forward(xm.numpy(), d["mix_sos_a"])[0]
+    yb = O.iir_module_forward(O.gain(ya, 0.5), d["mix_sos_b"])[0]
+    check("mix.iir-gain-iir", yb, d["mix_y"], 1e-7)
+    np.savez(os.path.join(OUT, "effects.npz"), **d)
+
     print(f"{'vector':34s} {'max|oracle-ref|':>16s} {'tol':>9s}")
     for n, e, t in report:
         print(f"{n:34s} {e:16.3e} {t:9.1e}")

@@ -179,6 +179,48 @@ def delay_line(x, delay, decay, mix):
     return y
 
 
+# --------------------------------------------------------------------------- effects
+def gain_linear(gain, gain_type="amplitude"):
+    """The factor ``Gain.forward`` multiplies by (``effect.py:132-136,372-378``); None = identity."""
+    if gain_type == "amplitude":
+        return float(gain)
+    if gain_type == "db":
+        db = gain
+    elif gain_type == "power":
+        db = 10 * math.log10(gain)
+    else:
+        return None
+    return None if db == 0 else 10 ** (db / 20)
+
+
+def gain(x, gain, gain_type="amplitude", clamp=False):
+    """``Gain.forward`` (``effect.py:361-383``) in the signal dtype."""
+    x = np.asarray(x)
+    g = gain_linear(gain, gain_type)
+    y = x if g is None else x * x.dtype.type(g)
+    return np.clip(y, -1.0, 1.0).astype(x.dtype) if clamp else y
+
+
+def normalize(x, peak, strategy="peak", percentile=99.0):
+    """The built-in normalization strategies (``effect.py:696-698,719-721,750-753,775-786``),
+    signal-dtype arithmetic in the reference's order: ``x / s * peak`` when ``s > 0``."""
+    x = np.asarray(x)
+    dt = x.dtype.type
+    if strategy == "per_channel":
+        m = np.max(np.abs(x), axis=-1, keepdims=True)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return np.where(m > 0, x / m * dt(peak), x).astype(x.dtype)
+    if strategy == "peak":
+        s = np.max(np.abs(x))
+    elif strategy == "rms":
+        s = np.sqrt(np.mean(x * x, dtype=x.dtype))
+    elif strategy == "percentile":
+        s = np.quantile(np.abs(x), percentile / 100).astype(x.dtype)
+    else:
+        raise ValueError(strategy)
+    return (x / dt(s) * dt(peak)).astype(x.dtype) if s > 0 else x
+
+
 # --------------------------------------------------------------------------- chain
 def chain_forward(x, sos, fir_kernels, threads=1):
     """The BASELINE cfg-5 pipe ``wave | iir... | FIR | FIR`` as the reference

@@ -68,3 +68,24 @@ def delay_line_forward(x, delay_samples, decay, mix):
     if x.shape[-1] <= delay_samples:
         return x
     return torch.from_numpy(O.delay_line(_np(x).reshape(-1, x.shape[-1]), delay_samples, decay, mix)).reshape(x.shape)
+
+
+STAT_ABSMAX, STAT_RMS = 0, 1
+
+
+def gain_forward(x, gain, clamp=False):
+    calls.append(("gain_forward", tuple(x.shape), float(gain), bool(clamp)))
+    return torch.from_numpy(np.ascontiguousarray(O.gain(_np(x), gain, "amplitude", clamp)))
+
+
+def stat_forward(x, mode=STAT_ABSMAX, per_row=False):
+    a = _np(x).astype(np.float64)
+    a = a.reshape(-1, a.shape[-1]) if per_row else a.reshape(1, -1)
+    out = np.abs(a).max(axis=1) if mode == STAT_ABSMAX else np.sqrt((a * a).mean(axis=1))
+    return torch.from_numpy(out)
+
+
+def normalize_forward(x, peak, mode=STAT_ABSMAX, per_row=False):
+    calls.append(("normalize_forward", tuple(x.shape), int(mode), bool(per_row)))
+    strat = "per_channel" if per_row else ("peak" if mode == STAT_ABSMAX else "rms")
+    return torch.from_numpy(np.ascontiguousarray(O.normalize(_np(x), peak, strat)))

@@ -1,0 +1,126 @@
+"""Gain / Normalize without a GPU: the oracle against the reference's golden
+outputs (tests/golden/effects.npz, written by oracle/make_golden.py from the real reference), the
+module layer on the oracle backend, the reference's error behaviour, and the planner's gain folding."""
+import numpy as np
+import pytest
+import torch
+
+import torchfx_amd as fx
+from oracle import oracle as O
+from torchfx_amd import effect as E
+from torchfx_amd import filter as F
+
+GAINS = {"amp": dict(gain=0.37, gain_type="amplitude"), "db": dict(gain=-4.5, gain_type="db"),
+         "db0": dict(gain=0.0, gain_type="db"), "pow": dict(gain=2.5, gain_type="power"),
+         "clamp": dict(gain=1.9, gain_type="amplitude", clamp=True)}
+STRATS = ("peak", "rms", "percentile", "per_channel")
+
+
+def test_oracle_effects_match_reference_bit_for_bit(golden):
+    g = golden("effects")
+    for tag, kw in GAINS.items():
+        assert np.array_equal(O.gain(g["x"], **kw), g["gain_" + tag]), tag
+    assert np.array_equal(O.gain(g["x64"], 3.0, "db"), g["gain64_db"])
+    for s in STRATS:
+        assert np.allclose(O.normalize(g["x"], 0.8, s, 97.0), g["norm_" + s], rtol=0, atol=1e-6), s
+        assert np.allclose(O.normalize(g["x64"], 1.25, s, 97.0), g["norm64_" + s], rtol=0, atol=1e-14), s
+        assert np.array_equal(O.normalize(g["zeros"], 0.8, s, 97.0), g["normz_" + s]), s
+    assert np.allclose(O.normalize(g["x3"], 0.5, "per_channel"), g["norm3_per_channel"], atol=1e-6)
+
+
+def _strategy(name):
+    return {"peak": E.PeakNormalizationStrategy(), "rms": E.RMSNormalizationStrategy(),
+            "percentile": E.PercentileNormalizationStrategy(97.0), "per_channel": E.PerChannelNormalizationStrategy()}[name]
+
+
+def test_modules_on_oracle_backend(golden, oracle_backend):
+    g = golden("effects")
+    x, x64 = torch.from_numpy(g["x"]), torch.from_numpy(g["x64"])
+    for tag, kw in GAINS.items():
+        y = E.Gain(**kw)(x)
+        assert y.dtype == x.dtype and np.array_equal(y.numpy(), g["gain_" + tag]), tag
+    assert E.Gain(0.0, "db")(x) is x                                  # 0 dB returns the input itself
+    assert np.array_equal(E.Gain(3.0, "db")(x64).numpy(), g["gain64_db"])
+    for s in STRATS:
+        y = E.Normalize(0.8, _strategy(s))(x)
+        assert np.allclose(y.numpy(), g["norm_" + s], rtol=0, atol=1e-6), s
+        z = E.Normalize(0.8, _strategy(s))(torch.from_numpy(g["zeros"]))
+        assert np.array_equal(z.numpy(), g["normz_" + s]), s
+    y3 = E.Normalize(0.5, E.PerChannelNormalizationStrategy())(torch.from_numpy(g["x3"]))
+    assert y3.shape == (2, 3, 700) and np.allclose(y3.numpy(), g["norm3_per_channel"], atol=1e-6)
+    # 1-D input, callable strategy, custom strategy object (tests/test_effects.py:73-143 of the reference)
+    w = torch.tensor([0.2, -0.5, 0.4])
+    assert torch.allclose(E.Normalize(peak=1.0)(w), w / 0.5)
+    assert torch.equal(E.Normalize(5.0, strategy=lambda a, p: a + p)(w), w + 5.0)
+
+    class Dummy(E.NormalizationStrategy):
+        def __call__(self, waveform, peak):
+            return waveform * 0 + peak
+
+    assert torch.equal(E.Normalize(2.0, strategy=Dummy())(w), torch.full_like(w, 2.0))
+
+
+def test_error_behaviour_matches_the_reference():
+    with pytest.raises(ValueError, match="must be positive"):
+        E.Gain(-1.0, "amplitude")
+    with pytest.raises(ValueError):
+        E.Gain(-1.0, "power")
+    E.Gain(-6.0, "db")                                                # negative dB is fine
+    with pytest.raises(AssertionError):
+        E.Normalize(peak=0)
+    with pytest.raises(TypeError, match="NormalizationStrategy"):
+        E.Normalize(1.0, strategy="not_a_strategy")
+    for bad in (0, 101):
+        with pytest.raises(AssertionError):
+            E.PercentileNormalizationStrategy(percentile=bad)
+    with pytest.raises(AssertionError):
+        E.PerChannelNormalizationStrategy()(torch.tensor([1.0, -2.0]), 1.0)
+    with pytest.raises(ValueError, match=r"\(C, T\) or \(B, C, T\)"):
+        E.PerChannelNormalizationStrategy()(torch.zeros(1, 2, 3, 4), 1.0)
+    assert E.Gain(0.5).__or__(42) is NotImplemented
+    assert isinstance(E.Gain(0.5) | F.LoButterworth(4000, order=2, fs=48000), fx.FilterChain)
+
+
+def _mixed(fuse):
+    g = [F.LoButterworth(4000, order=2), F.HiButterworth(200, order=2), E.Gain(0.5),
+         F.LoButterworth(6000, order=2), F.HiButterworth(100, order=2)]
+    return g, fuse
+
+
+@pytest.mark.parametrize("fuse", [False, True])
+def test_mixed_pipeline_golden_and_plan(golden, oracle_backend, fuse):
+    """wave | iir | iir | Gain | iir | iir (tests/test_chain_fusion.py:102-121 of the reference):
+    staged by default -- two cascades around a gain pass -- one cascade with fuse_gain."""
+    g = golden("effects")
+    mods, _ = _mixed(fuse)
+    w = fx.Wave(torch.from_numpy(g["mix_x"]), 48000)
+    w.fuse_gain = fuse
+    for m in mods:
+        w = w | m
+    names = [type(m).__name__ for m in w.plan()]
+    assert names == (["FusedSOSCascade"] if fuse else ["FusedSOSCascade", "Gain", "FusedSOSCascade"])
+    oracle_backend.calls.clear()
+    y = w.ys.numpy()
+    assert np.abs(y - g["mix_y"]).max() <= 1e-6
+    launches = [c[0] for c in oracle_backend.calls]
+    assert launches == (["sos_forward"] if fuse else ["sos_forward", "gain_forward", "sos_forward"])
+    if fuse:
+        assert oracle_backend.calls[0][2] == 4                       # all four sections in one launch
+
+
+def test_gain_folding_rules(oracle_backend):
+    w = fx.Wave(torch.zeros(2, 64), 48000)
+    w.fuse_gain = True
+    lone = w | E.Gain(0.5) | F.LoButterworth(4000, order=2) | E.Gain(0.1)
+    assert [type(m).__name__ for m in lone.plan()] == ["Gain", "LoButterworth", "Gain"]   # stateful lone IIR: staged
+    clamp = w | F.LoButterworth(4000, order=2) | F.HiButterworth(100, order=2) | E.Gain(2.0, clamp=True)
+    assert [type(m).__name__ for m in clamp.plan()] == ["FusedSOSCascade", "Gain"]        # clamp is not linear
+    fir = w | E.Gain(2.0) | F.FIR([0.25, 0.5]) | E.Gain(3.0, "db")
+    p = fir.plan()
+    assert [type(m).__name__ for m in p] == ["FIR"]
+    taps = p[0].kernel.reshape(-1).flip(0).double().numpy()
+    assert np.allclose(taps, np.array([0.25, 0.5]) * 2.0 * 10 ** (3 / 20), rtol=1e-12)
+    two = w | F.FIR([1.0, 1.0]) | E.Gain(0.5) | F.FIR([1.0, -1.0])                      # fold, but do not merge FIRs
+    assert [type(m).__name__ for m in two.plan()] == ["FIR", "FIR"]
+    tail = w | E.Gain(0.5)
+    assert [type(m).__name__ for m in tail.plan()] == ["Gain"]

@@ -550,3 +550,88 @@ def test_random_stable_cascades_near_the_unit_circle(seed):
     scale = max(1.0, float(np.abs(ey).max()))
     close(y, ey, 1e-9 * scale / max(1.0, scale) , f"seed {seed}: K={K} T={T}")
     close(sy, esy, 1e-8 * max(1.0, float(np.abs(esy).max())))
+
+
+# ------------------------------------------------------------------- effects between filters
+GAIN_CASES = {"amp": dict(gain=0.37, gain_type="amplitude"), "db": dict(gain=-4.5, gain_type="db"),
+              "db0": dict(gain=0.0, gain_type="db"), "pow": dict(gain=2.5, gain_type="power"),
+              "clamp": dict(gain=1.9, gain_type="amplitude", clamp=True)}
+
+
+def _strategies():
+    from torchfx_amd import effect as E
+    return {"peak": E.PeakNormalizationStrategy(), "rms": E.RMSNormalizationStrategy(),
+            "percentile": E.PercentileNormalizationStrategy(97.0), "per_channel": E.PerChannelNormalizationStrategy()}
+
+
+def test_gain_and_normalize_golden(golden):
+    """Gain is bit-exact (one rounding, same as torch); the normalisations are within 1e-6 of the
+    reference (the RMS is accumulated in float64 here, in float32 there)."""
+    from torchfx_amd import effect as E
+    g = golden("effects")
+    x, x64, z = dev(g["x"]), dev(g["x64"]), dev(g["zeros"])
+    for tag, kw in GAIN_CASES.items():
+        y = E.Gain(**kw)(x)
+        assert np.array_equal(y.cpu().numpy(), g["gain_" + tag]), tag
+    assert np.array_equal(E.Gain(3.0, "db")(x64).cpu().numpy(), g["gain64_db"])
+    for name, st in _strategies().items():
+        close(E.Normalize(0.8, st)(x), g["norm_" + name], 1e-6, name)
+        close(E.Normalize(1.25, st)(x64), g["norm64_" + name], 1e-14, name + " f64")
+        assert np.array_equal(E.Normalize(0.8, st)(z).cpu().numpy(), g["normz_" + name]), name
+    close(E.Normalize(0.5, E.PerChannelNormalizationStrategy())(dev(g["x3"])), g["norm3_per_channel"], 1e-6)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("C,T", [(1, 1), (3, 17), (2, 4097), (5, 100003), (2, 1 << 20)])
+def test_effect_kernels_ragged_shapes_vs_oracle(C, T, dtype):
+    e = ext()
+    x = (rnd((C, T), 31 * C + T, dtype) * 3).astype(dtype)
+    if C > 1:
+        x[1] = 0
+    xd = dev(x)
+    assert np.array_equal(e.gain_forward(xd, 0.731, True).cpu().numpy(), O.gain(x, 0.731, "amplitude", True))
+    st = e.stat_forward(xd, e.STAT_ABSMAX, per_row=True).cpu().numpy()
+    assert np.array_equal(st, np.abs(x).max(axis=1).astype(np.float64))
+    assert e.stat_forward(xd, e.STAT_ABSMAX).item() == np.abs(x).max()
+    rms = e.stat_forward(xd, e.STAT_RMS, per_row=True).cpu().numpy()
+    assert np.allclose(rms, np.sqrt((x.astype(np.float64) ** 2).mean(axis=1)), rtol=1e-13)
+    tol = 2e-7 if dtype == np.float32 else 1e-15
+    for strat, mode, per_row in (("peak", e.STAT_ABSMAX, False), ("per_channel", e.STAT_ABSMAX, True), ("rms", e.STAT_RMS, False)):
+        y = e.normalize_forward(xd, 0.9, mode, per_row).cpu().numpy()
+        exp = O.normalize(x, 0.9, strat)
+        assert np.abs(y - exp).max() <= tol * max(1.0, np.abs(exp).max()), strat
+    # rows that are not 16-byte aligned (a view shifted by one sample) take the scalar path
+    if T > 8:
+        xs = dev(x)[:, 1:]
+        assert not xs.is_contiguous()
+        y = e.normalize_forward(xs, 0.9, e.STAT_ABSMAX, True).cpu().numpy()
+        assert np.abs(y - O.normalize(x[:, 1:], 0.9, "per_channel")).max() <= tol * 3
+
+
+def test_effect_nan_and_aliasing_rules():
+    e = ext()
+    x = rnd((2, 5000), 5)
+    x[0, 1234] = np.nan
+    xd = dev(x)
+    st = e.stat_forward(xd, e.STAT_ABSMAX, per_row=True).cpu().numpy()
+    assert np.isnan(st[0]) and st[1] == np.abs(x[1]).max()             # NaN wins, like torch.max
+    y = e.normalize_forward(xd, 1.0, e.STAT_ABSMAX, False).cpu().numpy()
+    assert np.array_equal(np.isnan(y), np.isnan(x)) and np.array_equal(y[1], x[1])   # `nan > 0` is False: unchanged
+    g = e.gain_forward(xd, 2.0, True).cpu().numpy()
+    assert np.isnan(g[0, 1234]) and np.abs(g[1]).max() <= 1.0
+    assert xd.cpu().numpy()[1].tobytes() == x[1].tobytes()              # inputs never written
+
+
+@pytest.mark.parametrize("fuse", [False, True])
+def test_wave_pipeline_with_gain_on_device(golden, fuse):
+    import torchfx_amd as fx
+    from torchfx_amd import effect as E
+    from torchfx_amd import filter as F
+    g = golden("effects")
+    w = fx.Wave(dev(g["mix_x"]), 48000, device=DEV)
+    w.fuse_gain = fuse
+    for m in (F.LoButterworth(4000, order=2), F.HiButterworth(200, order=2), E.Gain(0.5),
+              F.LoButterworth(6000, order=2), F.HiButterworth(100, order=2)):
+        w = w | m
+    assert len(w.plan()) == (1 if fuse else 3)
+    close(w.ys, g["mix_y"], 2e-7, "iir | iir | gain | iir | iir")

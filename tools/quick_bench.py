@@ -64,6 +64,20 @@ def main():
         wall, prof = timed(lambda: E.fft_conv_forward(x, k, (1023, 0)), reps=3, warm=1)
         print(f"fir fft 1024: wall {wall:.3f} ms  {C * T / wall / 1e3:.1f} Msamp/s", prof, flush=True)
         del x
+    if "efx" in which:
+        C, T = 64, 28_800_000
+        x = torch.randn(C, T, device=dev)
+        for name, fn, nbytes in (("gain", lambda: E.gain_forward(x, 0.5, False), 8), ("gain+clamp", lambda: E.gain_forward(x, 0.5, True), 8),
+                                 ("stat absmax", lambda: E.stat_forward(x, E.STAT_ABSMAX, True), 4),
+                                 ("stat rms", lambda: E.stat_forward(x, E.STAT_RMS, False), 4),
+                                 ("normalize peak", lambda: E.normalize_forward(x, 1.0, E.STAT_ABSMAX, False), 12),
+                                 ("normalize per-channel", lambda: E.normalize_forward(x, 1.0, E.STAT_ABSMAX, True), 12),
+                                 ("normalize rms", lambda: E.normalize_forward(x, 1.0, E.STAT_RMS, False), 12)):
+            wall, prof = timed(fn, reps=5, warm=2)
+            tot = sum(prof.values())
+            print(f"{name:22s}: kernels {tot:7.3f} ms wall {wall:7.3f} ms  {nbytes * C * T / tot / 1e9:5.2f} TB/s of its {nbytes} B/sample  "
+                  + " ".join(f"{n.replace('_kernel', '')}={v:.3f}" for n, v in prof.items()), flush=True)
+        del x
     if "fft" in which:
         C, T = 64, 2_880_000 * (10 if "big" in which else 1)
         x = torch.randn(C, T, device=dev)

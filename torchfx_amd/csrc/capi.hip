@@ -25,6 +25,11 @@ void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, c
 void fftconv_clear();
 void olsnative_clear();
 bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out);
+// effects.hip
+void gain_forward(const void *x, void *y, int dtype, int64_t n, double gain, int clamp, hipStream_t stream);
+void stat_forward(const void *x, int dtype, int64_t C, int64_t T, int mode, int per_row, double *out_dev, hipStream_t stream);
+void normalize_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, int mode, int per_row, double peak,
+                       hipStream_t stream);
 int64_t fftconv_block_size(int64_t K, int64_t L);
 
 // ---- errors ------------------------------------------------------------------------------------
@@ -296,6 +301,29 @@ int tfx_sum_forward(const void *const *xs_host, int n, void *y, int dtype, int64
     else
         hipLaunchKernelGGL(sum_kernel<double>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, (double *)y, numel);
     TFX_HIP(hipGetLastError());
+    TFX_API_END
+}
+
+int tfx_gain_forward(const void *x, void *y, int dtype, int64_t numel, double gain, int clamp, tfx_stream_t stream)
+{
+    TFX_API_BEGIN
+    gain_forward(x, y, dtype, numel, gain, clamp, (hipStream_t)stream);
+    TFX_API_END
+}
+
+int tfx_stat_forward(const void *x, int dtype, int64_t C, int64_t T, int mode, int per_row, double *out_dev,
+                     tfx_stream_t stream)
+{
+    TFX_API_BEGIN
+    stat_forward(x, dtype, C, T, mode, per_row, out_dev, (hipStream_t)stream);
+    TFX_API_END
+}
+
+int tfx_normalize_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, int mode, int per_row,
+                          double peak, tfx_stream_t stream)
+{
+    TFX_API_BEGIN
+    normalize_forward(x, y, dtype, C, T, mode, per_row, peak, (hipStream_t)stream);
     TFX_API_END
 }
 

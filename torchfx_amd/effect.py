@@ -1,10 +1,19 @@
-"""``FX`` base class -- the only part of the reference's ``effect.py`` on the filter hot
-path (``src/torchfx/effect.py:253-258``: the ``|`` operator that builds a ``FilterChain``).
-Gain / Normalize / Reverb / Delay are out of scope."""
+"""``FX`` base class and the elementwise effects that sit between filters in a pipeline.
+
+Reference: ``src/torchfx/effect.py`` -- ``FX.__or__`` (:253-258, builds a ``FilterChain``),
+``Gain`` (:261-383) and ``Normalize`` with its strategy objects (:386-531, :534-790).  These are
+SURVEY.md 8f rank 3: they are not filters, but a ``wave | iir | gain | fir`` pipeline passes through
+them, so they run as streaming HIP passes (``csrc/effects.hip``) and a clamp-free ``Gain`` can be
+folded into a neighbouring filter's coefficients by the ``Wave`` planner (opt-in, ``fuse_gain``).
+``Reverb`` / ``Delay`` remain out of scope.
+"""
 from __future__ import annotations
 
 import abc
+import math
+import typing as tp
 
+import torch
 from torch import Tensor, nn
 
 
@@ -24,3 +33,116 @@ class FX(nn.Module, abc.ABC):
         from torchfx_amd.chain import FilterChain
 
         return FilterChain(self, other)
+
+
+def _ext():
+    from torchfx_amd import torchfx_ext
+
+    return torchfx_ext
+
+
+class Gain(FX):
+    """Volume change: ``gain_type`` "amplitude" (factor), "db" (``10^(g/20)``) or "power"
+    (``10*log10(g)`` dB); ``clamp=True`` clips the result to [-1, 1]  (``effect.py:261-383``)."""
+
+    def __init__(self, gain: float, gain_type: str = "amplitude", clamp: bool = False) -> None:
+        super().__init__()
+        self.gain, self.gain_type, self.clamp = gain, gain_type, clamp
+        if gain_type in ("amplitude", "power") and gain < 0:
+            raise ValueError("If gain_type = amplitude or power, gain must be positive.")
+
+    def linear_gain(self) -> float | None:
+        """The factor the samples are multiplied by (None: unknown ``gain_type`` -> identity,
+        0 dB -> identity as in ``_gain_db``, ``effect.py:132-136``)."""
+        if self.gain_type == "amplitude":
+            return float(self.gain)
+        if self.gain_type == "db":
+            db = self.gain
+        elif self.gain_type == "power":
+            db = 10 * math.log10(self.gain)
+        else:
+            return None
+        return None if db == 0 else 10 ** (db / 20)
+
+    @torch.no_grad()
+    def forward(self, waveform: Tensor) -> Tensor:
+        g = self.linear_gain()
+        if g is None and not self.clamp:
+            return waveform
+        return _ext().gain_forward(waveform, 1.0 if g is None else g, self.clamp)
+
+
+# ------------------------------------------------------------------------------- Normalize
+class NormalizationStrategy(abc.ABC):
+    """``(waveform, peak) -> waveform`` (``effect.py:534-611``)."""
+
+    @abc.abstractmethod
+    def __call__(self, waveform: Tensor, peak: float) -> Tensor: ...
+
+
+class CustomNormalizationStrategy(NormalizationStrategy):
+    """Wraps a user callable (``effect.py:614-675``); runs whatever the callable does."""
+
+    def __init__(self, func: tp.Callable[[Tensor, float], Tensor]) -> None:
+        assert callable(func), "func must be callable"
+        self.func = func
+
+    def __call__(self, waveform: Tensor, peak: float) -> Tensor:
+        return self.func(waveform, peak)
+
+
+class PeakNormalizationStrategy(NormalizationStrategy):
+    """``x / max|x| * peak`` (unchanged if the signal is all zero) -- ``effect.py:678-698``."""
+
+    def __call__(self, waveform: Tensor, peak: float) -> Tensor:
+        return _ext().normalize_forward(waveform, peak, _ext().STAT_ABSMAX, per_row=False)
+
+
+class RMSNormalizationStrategy(NormalizationStrategy):
+    """``x / sqrt(mean(x^2)) * peak`` -- ``effect.py:700-721``."""
+
+    def __call__(self, waveform: Tensor, peak: float) -> Tensor:
+        return _ext().normalize_forward(waveform, peak, _ext().STAT_RMS, per_row=False)
+
+
+class PercentileNormalizationStrategy(NormalizationStrategy):
+    """``x / P_p(|x|) * peak`` (``effect.py:723-755``).  The percentile is a selection problem, not a
+    streaming pass: it runs as ``torch.quantile`` on the device (with torch's input-size limit, like
+    the reference); only the scaling uses the HIP kernel."""
+
+    def __init__(self, percentile: float = 99.0) -> None:
+        assert 0 < percentile <= 100, "Percentile must be between 0 and 100."
+        self.percentile = percentile
+
+    def __call__(self, waveform: Tensor, peak: float) -> Tensor:
+        threshold = torch.quantile(torch.abs(waveform), self.percentile / 100, interpolation="linear")
+        return waveform / threshold * peak if threshold > 0 else waveform
+
+
+class PerChannelNormalizationStrategy(NormalizationStrategy):
+    """Every channel to its own peak (``effect.py:757-786``): ``[C,T]`` or ``[B,C,T]``."""
+
+    def __call__(self, waveform: Tensor, peak: float) -> Tensor:
+        assert waveform.ndim >= 2, "Waveform must have at least 2 dimensions (channels, time)."
+        if waveform.ndim not in (2, 3):
+            raise ValueError("Waveform must have shape (C, T) or (B, C, T)")
+        return _ext().normalize_forward(waveform, peak, _ext().STAT_ABSMAX, per_row=True)
+
+
+class Normalize(FX):
+    """Normalise to ``peak`` with a pluggable strategy, default peak (``effect.py:386-531``)."""
+
+    def __init__(self, peak: float = 1.0,
+                 strategy: NormalizationStrategy | tp.Callable[[Tensor, float], Tensor] | None = None) -> None:
+        super().__init__()
+        assert peak > 0, "Peak value must be positive."
+        self.peak = peak
+        if callable(strategy) and not isinstance(strategy, NormalizationStrategy):
+            strategy = CustomNormalizationStrategy(strategy)
+        self.strategy = strategy or PeakNormalizationStrategy()
+        if not isinstance(self.strategy, NormalizationStrategy):
+            raise TypeError("Strategy must be an instance of NormalizationStrategy.")
+
+    @torch.no_grad()
+    def forward(self, waveform: Tensor) -> Tensor:
+        return self.strategy(waveform, self.peak)

@@ -240,6 +240,55 @@ def sum_forward(tensors: list[Tensor]) -> Tensor:
     return out
 
 
+STAT_ABSMAX, STAT_RMS = 0, 1
+
+
+def _rows_view(x: Tensor) -> tuple[Tensor, int, int]:
+    """``(..., T)`` -> contiguous tensor plus its ``[rows, T]`` geometry."""
+    xc = x.contiguous()
+    T = xc.shape[-1] if xc.dim() else 1
+    return xc, (xc.numel() // T if T else 0), T
+
+
+def gain_forward(x: Tensor, gain: float, clamp: bool = False) -> Tensor:
+    """``y = x * gain`` (+ clip to [-1, 1]) -- ``Gain.forward``, ``effect.py:361-383``; ``gain`` is
+    the linear factor."""
+    L.require_device(x, "x")
+    lib = L.load()
+    xc = x.contiguous()
+    y = torch.empty_like(xc)
+    with torch.cuda.device(x.device):
+        L.check(lib.tfx_gain_forward(_ptr(xc), _ptr(y), L.dtype_code(xc), xc.numel(), float(gain), int(bool(clamp)),
+                                     ctypes.c_void_p(L.stream_ptr(x))))
+    return y
+
+
+def stat_forward(x: Tensor, mode: int = STAT_ABSMAX, per_row: bool = False) -> Tensor:
+    """``max|x|`` (``STAT_ABSMAX``) or ``sqrt(mean(x^2))`` (``STAT_RMS``) over everything, or per row
+    of the ``[rows, T]`` view -- float64 on the device, no host sync."""
+    L.require_device(x, "x")
+    lib = L.load()
+    xc, rows, T = _rows_view(x)
+    out = torch.empty(rows if per_row else 1, dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(lib.tfx_stat_forward(_ptr(xc), L.dtype_code(xc), rows, T, int(mode), int(bool(per_row)), _ptr(out),
+                                     ctypes.c_void_p(L.stream_ptr(x))))
+    return out
+
+
+def normalize_forward(x: Tensor, peak: float, mode: int = STAT_ABSMAX, per_row: bool = False) -> Tensor:
+    """``s > 0 ? x / s * peak : x`` with ``s`` = abs-max or RMS, global or per row of the ``[rows, T]``
+    view (``effect.py:696-698,719-721,775-786``); two streaming passes, statistic stays on device."""
+    L.require_device(x, "x")
+    lib = L.load()
+    xc, rows, T = _rows_view(x)
+    y = torch.empty_like(xc)
+    with torch.cuda.device(x.device):
+        L.check(lib.tfx_normalize_forward(_ptr(xc), _ptr(y), L.dtype_code(xc), rows, T, int(mode),
+                                          int(bool(per_row)), float(peak), ctypes.c_void_p(L.stream_ptr(x))))
+    return y
+
+
 def sos_plan_info(sos) -> dict:
     """Host-side plan facts for an SOS matrix: warm-up halo length, the f32 worst-case
     error bound and what ``precision='auto'`` would choose.  Needs the library but no GPU."""

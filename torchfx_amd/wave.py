@@ -14,6 +14,12 @@ associative, so ``FIR(b1) | FIR(b2)`` == ``FIR(b1 * b2)``; the merged taps are c
 host in float64.  Off by default so the default results follow the reference's staged
 float32 arithmetic; ``bench.py`` turns it on for the chain workload and checks it against the
 staged oracle.
+
+``fuse_gain=True`` (env ``TORCHFX_AMD_FUSE_GAIN=1``, also opt-in) folds a clamp-free ``Gain`` into
+the coefficients of the filter run it touches -- scaling is linear, so ``iir | gain | iir`` stays one
+cascade launch (the b-row of the next section is multiplied by g) and ``gain | fir`` is one FIR
+with scaled taps; by default a ``Gain`` is its own streaming pass and splits IIR runs exactly as in
+the reference (``tests/test_chain_fusion.py:102-121``).
 """
 from __future__ import annotations
 
@@ -80,6 +86,7 @@ class Wave:
         self.metadata = metadata or {}
         self.fuse_fir = os.environ.get("TORCHFX_AMD_FUSE_FIR", "0") == "1"
         self.fuse_spectral = os.environ.get("TORCHFX_AMD_FUSE_SPECTRAL", "0") == "1"
+        self.fuse_gain = os.environ.get("TORCHFX_AMD_FUSE_GAIN", "0") == "1"
         self.to(device)
 
     # ------------------------------------------------------------------ lazy data
@@ -100,29 +107,72 @@ class Wave:
         from torchfx_amd.filter.fused import FusedSOSCascade
         from torchfx_amd.filter.iir import IIR
 
+        from torchfx_amd.effect import Gain
+
         plan: list[nn.Module] = []
-        run: list = []
+        items: list = []          # the open run in pipeline order: filters of one kind (+ folded Gains)
+        lead: list = []           # folded Gains seen while no run is open: they go into the next run
         kind = None
+        fold = getattr(self, "fuse_gain", False)
+
+        def scaled_iir(m, g):
+            if g == 1.0:
+                return m
+            sos = m._sos.detach().clone().to(torch.float64)
+            sos[0, :3] *= g       # H(g x) = g H(x): scale the first section's numerator
+            return type("ScaledSOS", (), {"_sos": sos, "fs": m.fs})()
+
+        def scaled_fir(m, g):
+            if g == 1.0:
+                return m
+            f = FIR.__new__(FIR)
+            nn.Module.__init__(f)
+            f._conv_mode, f.a = m._conv_mode, [1.0]
+            f.register_buffer("kernel", m.kernel.detach().to(torch.float64) * g)   # rounded once, at launch
+            return f
 
         def flush() -> None:
-            nonlocal run, kind
-            if kind == "iir":
-                plan.append(FusedSOSCascade(*run) if len(run) >= 2 else run[0])
-            elif kind == "fir":
-                plan.append(_merge_fir_run(run) if len(run) >= 2 else run[0])
-            run, kind = [], None
+            nonlocal items, kind
+            if kind is None:
+                return
+            filters = [m for m in items if not isinstance(m, Gain)]
+            if kind == "iir" and len(filters) == 1:
+                plan.extend(items)                   # a lone IIR is stateful across waves: keep it staged
+            else:
+                # every folded gain scales the filter that follows it (trailing ones: the last filter)
+                scales, nxt = [1.0] * len(filters), 0
+                for m in items:
+                    if isinstance(m, Gain):
+                        scales[min(nxt, len(filters) - 1)] *= m.linear_gain() or 1.0
+                    else:
+                        nxt += 1
+                if kind == "iir":
+                    plan.append(FusedSOSCascade(*[scaled_iir(m, g) for m, g in zip(filters, scales)]))
+                else:
+                    mem = [scaled_fir(m, g) for m, g in zip(filters, scales)]
+                    plan.append(_merge_fir_run(mem) if len(mem) >= 2 else mem[0])
+            items, kind = [], None
 
         for m in self._pipeline:
+            if fold and isinstance(m, Gain) and not m.clamp:
+                (items if kind is not None else lead).append(m)
+                continue
             k = "iir" if isinstance(m, (IIR, Biquad)) else (
-                "fir" if (self.fuse_fir and isinstance(m, FIR) and m._conv_mode != "direct") else None)
-            if k is None or (kind is not None and k != kind):
+                "fir" if (isinstance(m, FIR) and m._conv_mode != "direct" and (self.fuse_fir or fold)) else None)
+            if k is None or (kind is not None and k != kind) or (k == "fir" and kind == "fir" and not self.fuse_fir):
                 flush()
             if k is None:
+                plan.extend(lead)
+                lead = []
                 plan.append(m)
             else:
-                run.append(m)
+                if kind is None:
+                    items, lead = lead + [m], []
+                else:
+                    items.append(m)
                 kind = k
         flush()
+        plan.extend(lead)
         if getattr(self, "fuse_spectral", False):
             plan = self._spectral_plan(plan)
         return plan
@@ -165,10 +215,11 @@ class Wave:
 
     @classmethod
     def _deferred(cls, ys: Tensor, fs: int, device, metadata, pipeline: list[nn.Module],
-                  fuse_fir: bool = False, fuse_spectral: bool = False) -> "Wave":
+                  fuse_fir: bool = False, fuse_spectral: bool = False, fuse_gain: bool = False) -> "Wave":
         w = object.__new__(cls)
         w._ys, w.fs, w._device, w.metadata, w._pipeline, w.fuse_fir = ys, fs, device, metadata, pipeline, fuse_fir
         w.fuse_spectral = fuse_spectral
+        w.fuse_gain = fuse_gain
         return w
 
     # ------------------------------------------------------------------ device
@@ -198,7 +249,8 @@ class Wave:
                     m.compute_coefficients()
         steps = list(f.children()) if isinstance(f, nn.Sequential) else [f]
         return Wave._deferred(self._ys, self.fs, self._device, self.metadata,
-                              self._pipeline + steps, self.fuse_fir, getattr(self, "fuse_spectral", False))
+                              self._pipeline + steps, self.fuse_fir, getattr(self, "fuse_spectral", False),
+                              getattr(self, "fuse_gain", False))
 
     def transform(self, func, *args, **kwargs) -> "Wave":
         """Apply ``func`` to the (materialised) samples and wrap the result (``wave.py:334-360``)."""
