@@ -635,3 +635,24 @@ def test_wave_pipeline_with_gain_on_device(golden, fuse):
         w = w | m
     assert len(w.plan()) == (1 if fuse else 3)
     close(w.ys, g["mix_y"], 2e-7, "iir | iir | gain | iir | iir")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n,shape", [(1, (3, 1001)), (2, (1, 5)), (5, (4, 100003)), (16, (2, 4096)), (17, (2, 5000)), (33, (1, 777))])
+def test_branch_sum_bit_exact(n, shape, dtype):
+    """`+` accumulates zeros_like + in-place adds in branch order (__base.py:1022-1026): the one-pass
+    kernel (groups of <= 16 inputs) must give exactly that, also for odd sizes and unaligned views."""
+    g = torch.Generator().manual_seed(n * 131 + shape[1])
+    ts = [torch.randn(shape, generator=g, dtype=dtype) for _ in range(n)]
+    exp = torch.zeros(shape, dtype=dtype)
+    for t in ts:
+        exp += t
+    got = ext().sum_forward([t.to(DEV) for t in ts])
+    assert torch.equal(got.cpu(), exp)
+    if shape[1] > 16:                                     # views starting one element in: scalar path
+        wide = [torch.randn((shape[0], shape[1] + 1), generator=g, dtype=dtype) for _ in range(n)]
+        exp = torch.zeros(shape, dtype=dtype)
+        for t in wide:
+            exp += t[:, 1:]
+        got = ext().sum_forward([t.to(DEV)[:, 1:] for t in wide])
+        assert torch.equal(got.cpu(), exp)

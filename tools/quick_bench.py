@@ -77,7 +77,11 @@ def main():
             tot = sum(prof.values())
             print(f"{name:22s}: kernels {tot:7.3f} ms wall {wall:7.3f} ms  {nbytes * C * T / tot / 1e9:5.2f} TB/s of its {nbytes} B/sample  "
                   + " ".join(f"{n.replace('_kernel', '')}={v:.3f}" for n, v in prof.items()), flush=True)
-        del x
+        xs = [torch.randn(C, T // 4, device=dev) for _ in range(8)]
+        wall, prof = timed(lambda: E.sum_forward(xs), reps=5, warm=2)
+        tot = sum(prof.values())
+        print(f"sum of 8 branches     : kernels {tot:7.3f} ms  {9 * 4 * C * (T // 4) / tot / 1e9:5.2f} TB/s (8 reads + 1 write)", flush=True)
+        del x, xs
     if "fft" in which:
         C, T = 64, 2_880_000 * (10 if "big" in which else 1)
         x = torch.randn(C, T, device=dev)

@@ -1,6 +1,6 @@
 // capi.hip -- extern "C" surface of libtorchfx_hip.so (see include/torchfx_hip.h) plus the
 // small shared services: thread-local error text, per-kernel HIP-event timing, device scratch,
-// and the two elementwise kernels (delay line, branch sum).
+// and the delay-line kernel.
 #include "common.h"
 #include "../../include/torchfx_hip.h"
 
@@ -30,6 +30,7 @@ void gain_forward(const void *x, void *y, int dtype, int64_t n, double gain, int
 void stat_forward(const void *x, int dtype, int64_t C, int64_t T, int mode, int per_row, double *out_dev, hipStream_t stream);
 void normalize_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, int mode, int per_row, double peak,
                        hipStream_t stream);
+void sum_forward(const void *const *xs_host, int n, void *y, int dtype, int64_t numel, hipStream_t stream);
 int64_t fftconv_block_size(int64_t K, int64_t L);
 
 // ---- errors ------------------------------------------------------------------------------------
@@ -133,23 +134,6 @@ delay_line_kernel(const T *__restrict__ x, T *__restrict__ y, int64_t Tn, int64_
         T v = x[g];
         if (n >= D) v += coeff * x[g - D];
         y[g] = v;
-    }
-}
-
-constexpr int SUM_MAX = 16;
-struct SumArgs {
-    const void *p[SUM_MAX];
-    int n;
-};
-template <typename T>
-__global__ void __launch_bounds__(256) sum_kernel(SumArgs a, T *__restrict__ y, int64_t total)
-{
-    int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (; g < total; g += stride) {
-        T acc = (T)0;                    // zeros_like + in-place adds, in branch order (__base.py:1022-1026)
-        for (int i = 0; i < a.n; ++i) acc += ((const T *)a.p[i])[g];
-        y[g] = acc;
     }
 }
 
@@ -288,19 +272,7 @@ int tfx_delay_line_forward(const void *x, void *y, int dtype, int64_t C, int64_t
 int tfx_sum_forward(const void *const *xs_host, int n, void *y, int dtype, int64_t numel, tfx_stream_t stream)
 {
     TFX_API_BEGIN
-    TFX_CHECK(n >= 1 && n <= SUM_MAX, "sum_forward: between 1 and %d inputs", SUM_MAX);
-    TFX_CHECK(dtype == TFX_F32 || dtype == TFX_F64, "sum_forward: bad dtype");
-    if (numel == 0) return 0;
-    SumArgs a;
-    a.n = n;
-    for (int i = 0; i < n; ++i) a.p[i] = xs_host[i];
-    const unsigned grid = (unsigned)(ceil_div(numel, 256) < 8192 ? ceil_div(numel, 256) : 8192);
-    ProfScope ps("sum_kernel", (hipStream_t)stream);
-    if (dtype == TFX_F32)
-        hipLaunchKernelGGL(sum_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, (float *)y, numel);
-    else
-        hipLaunchKernelGGL(sum_kernel<double>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, (double *)y, numel);
-    TFX_HIP(hipGetLastError());
+    sum_forward(xs_host, n, y, dtype, numel, (hipStream_t)stream);
     TFX_API_END
 }
 

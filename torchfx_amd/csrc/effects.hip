@@ -189,6 +189,72 @@ normalize_apply_kernel(const T *__restrict__ x, T *__restrict__ y, int64_t T_, i
     }
 }
 
+// ---- branch sum (`+`) -----------------------------------------------------------------------------
+// y = sum_i x_i in list order (zeros_like + in-place adds, __base.py:1022-1026): one pass over the N
+// branch outputs, one 16-byte load per input in flight per thread, one-shot grid.
+constexpr int SUM_MAX = 16;
+struct SumArgs {
+    const void *p[SUM_MAX];
+    int n;
+};
+template <typename T>
+__global__ void __launch_bounds__(EFX_THREADS) sum_kernel(SumArgs a, T *__restrict__ y, int64_t total, int aligned)
+{
+    typedef typename Vec16<T>::type V;
+    constexpr int N = Vec16<T>::N;
+    const int64_t base = ((int64_t)blockIdx.x * EFX_THREADS + threadIdx.x) * N;
+    if (base >= total) return;
+    if (aligned && base + N <= total) {
+        V v[SUM_MAX];
+#pragma unroll
+        for (int i = 0; i < SUM_MAX; ++i)
+            if (i < a.n) v[i] = *(const V *)((const T *)a.p[i] + base);
+        V acc;
+        T *ac = (T *)&acc;
+#pragma unroll
+        for (int e = 0; e < N; ++e) ac[e] = (T)0;
+#pragma unroll
+        for (int i = 0; i < SUM_MAX; ++i)
+            if (i < a.n) {
+                const T *e = (const T *)&v[i];
+#pragma unroll
+                for (int k = 0; k < N; ++k) ac[k] += e[k];
+            }
+        *(V *)(y + base) = acc;
+    } else {
+        for (int k = 0; k < N && base + k < total; ++k) {
+            T acc = (T)0;
+            for (int i = 0; i < a.n; ++i) acc += ((const T *)a.p[i])[base + k];
+            y[base + k] = acc;
+        }
+    }
+}
+
+void sum_forward(const void *const *xs_host, int n, void *y, int dtype, int64_t numel, hipStream_t stream)
+{
+    TFX_CHECK(n >= 1 && n <= SUM_MAX, "sum_forward: between 1 and %d inputs", SUM_MAX);
+    TFX_CHECK(dtype == TFX_F32 || dtype == TFX_F64, "sum_forward: bad dtype");
+    if (numel == 0) return;
+    SumArgs a;
+    a.n = n;
+    uintptr_t bits = (uintptr_t)y;
+    for (int i = 0; i < n; ++i) {
+        a.p[i] = xs_host[i];
+        bits |= (uintptr_t)xs_host[i];
+    }
+    const int per_thread = dtype == TFX_F32 ? 4 : 2;
+    const int64_t grid = ceil_div(numel, (int64_t)EFX_THREADS * per_thread);
+    TFX_CHECK(grid < (1ll << 31), "sum_forward: grid too large");
+    ProfScope ps("sum_kernel", stream);
+    if (dtype == TFX_F32)
+        hipLaunchKernelGGL(sum_kernel<float>, dim3((unsigned)grid), dim3(EFX_THREADS), 0, stream, a, (float *)y, numel,
+                           (int)((bits & 15) == 0));
+    else
+        hipLaunchKernelGGL(sum_kernel<double>, dim3((unsigned)grid), dim3(EFX_THREADS), 0, stream, a, (double *)y, numel,
+                           (int)((bits & 15) == 0));
+    TFX_HIP(hipGetLastError());
+}
+
 // ---- host ---------------------------------------------------------------------------------------
 static inline int64_t efx_tiles(int64_t T, int esz) { return ceil_div(T, (int64_t)EFX_U * EFX_THREADS * (16 / esz)); }
 
