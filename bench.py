@@ -207,11 +207,18 @@ def main() -> None:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     import torch.distributed as dist
 
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    # TFX_BENCH_SHARE_DEVICE=1 (development only): every rank uses cuda:0 and the collectives go over
+    # gloo, so the N > 1 control flow can be exercised on a one-GPU box; never set by the driver
+    share = os.environ.get("TFX_BENCH_SHARE_DEVICE", "0") == "1"
+    local_dev = 0 if share else local
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from torchfx_amd import _lib
     lib = _lib.load()                      # fails loudly if the HIP extension is missing
@@ -244,7 +251,7 @@ def main() -> None:
     prof = json.loads(lib.tfx_prof_collect().decode())
     lib.tfx_prof_enable(0)
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if share else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
