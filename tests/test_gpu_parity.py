@@ -265,6 +265,7 @@ def test_fir_direct_chunk_sizes_vs_oracle(C, T, K, kc, monkeypatch):
     oracle's float32 direct form: tile edges, rows shorter than the filter, K on chunk borders."""
     if kc is not None:
         monkeypatch.setenv("TFX_FIR_KC", str(kc))
+        monkeypatch.setenv("TFX_FIR_MFMA_MIN_T", "0")      # short rows too go through the MFMA kernel here
     rng = np.random.default_rng(1000 * K + T)
     kf = (rng.standard_normal(K) / np.sqrt(K)).astype(np.float32)
     x = rnd((C, T), K * 7 + T)

@@ -221,6 +221,12 @@ fir_direct_simple_kernel(const T *__restrict__ x, T *__restrict__ y, const T *__
     }
 }
 
+static int64_t envi_fir(const char *name, int64_t dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoll(e) : dflt;
+}
+
 void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
                         const void *kernel_host, int64_t K, hipStream_t stream)
 {
@@ -231,7 +237,10 @@ void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
     const size_t esz = dtype == TFX_F32 ? 4 : 8;
     const int64_t Kpad = ceil_div(K, FIR_KC_MAX) * FIR_KC_MAX;
     const void *kdev = cached_taps(kernel_host, (size_t)K * esz, (size_t)Kpad * esz);
-    if (dtype == TFX_F32) {
+    // rows much shorter than one 16384-sample MFMA tile (streaming chunks): the plain LDS-tiled kernel
+    // has 1024-sample tiles and finishes in a few microseconds instead of a full tile's ~60
+    const bool short_rows = dtype == TFX_F32 && T < envi_fir("TFX_FIR_MFMA_MIN_T", FIR_NOUT / 4);
+    if (dtype == TFX_F32 && !short_rows) {
         const int64_t tiles = ceil_div(T, FIR_NOUT);
         TFX_CHECK(C * tiles < (1ll << 31), "fir_direct_forward: grid too large");
         // chunk size: cost per chunk ~ (KC+32)/32 contraction blocks + ~4 blocks' worth of refill
@@ -267,9 +276,15 @@ void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
     } else {
         const int64_t tiles = ceil_div(T, 1024);
         TFX_CHECK(C * tiles < (1ll << 31), "fir_direct_forward: grid too large");
-        ProfScope ps("fir_direct_simple_kernel<f64>", stream);
-        hipLaunchKernelGGL(fir_direct_simple_kernel<double>, dim3((unsigned)(C * tiles)), dim3(256), 0, stream,
-                           (const double *)x, (double *)y, (const double *)kdev, C, T, (int)K, tiles);
+        if (dtype == TFX_F32) {
+            ProfScope ps("fir_direct_simple_kernel<f32>", stream);
+            hipLaunchKernelGGL(fir_direct_simple_kernel<float>, dim3((unsigned)(C * tiles)), dim3(256), 0, stream,
+                               (const float *)x, (float *)y, (const float *)kdev, C, T, (int)K, tiles);
+        } else {
+            ProfScope ps("fir_direct_simple_kernel<f64>", stream);
+            hipLaunchKernelGGL(fir_direct_simple_kernel<double>, dim3((unsigned)(C * tiles)), dim3(256), 0, stream,
+                               (const double *)x, (double *)y, (const double *)kdev, C, T, (int)K, tiles);
+        }
         TFX_HIP(hipGetLastError());
     }
 }
