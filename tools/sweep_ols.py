@@ -10,6 +10,6 @@ k = (ir / np.abs(ir).sum()).astype(np.float32)[::-1].copy()
 for lg in (18, 20):
     for r4 in (0, 1):
         os.environ["TFX_FFT_LOG2N"] = str(lg)
-        os.environ["TFX_OLS_COL_R4"] = str(r4)
+        os.environ["TFX_OLS_ROW_R4"] = str(r4)
         wall, prof = timed(lambda: E.fft_conv_forward(x, k, (K - 1, 0)), reps=3, warm=1)
         print(f"log2N={lg} col_r4={r4}: wall {wall:7.3f} ms  {C*T/wall/1e3:9.1f} Msamp/s  " + " ".join(f"{n.replace('_kernel','')}={v:.2f}" for n, v in prof.items()), flush=True)

@@ -101,142 +101,9 @@ __device__ __forceinline__ void dft16(cpx (&v)[16])
 
 
 // ---------------------------------------------------------------------------------------------
-// Column pass (A: forward from the signal, C: inverse to the output).  256 threads:
-// col = tid & 31, q = tid >> 5; thread owns butterflies j = q + 8 i (i < 8) of its column.
-// LDS: one [256][32] complex buffer (64 KB); stage inputs are read into registers, barrier,
-// outputs written, barrier.
-// ---------------------------------------------------------------------------------------------
-template <bool INV>
-__device__ __forceinline__ void col_stages(cpx (&v)[8][4], cpx *lds, const cpx *tw256, int col, int q)
-{
-    // stage 0 (Ns = 1): no twiddle
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dft4<INV>(v[i][0], v[i][1], v[i][2], v[i][3]);
-#pragma unroll
-    for (int s = 1; s < 4; ++s) {
-        const int Ns_prev = 1 << (2 * (s - 1));
-        const int Ns = Ns_prev * 4;
-        // write outputs of stage s-1:  rows j0 + r*Ns_prev,  j0 = (j / Ns_prev) * 4 Ns_prev + j % Ns_prev
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int j = q + 8 * i;
-            const int j0 = (j / Ns_prev) * (4 * Ns_prev) + (j % Ns_prev);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) lds[(j0 + r * Ns_prev) * OLS_CB + col] = v[i][r];
-        }
-        __syncthreads();
-        // read inputs of stage s: rows j + 64 r, twiddle W_{4Ns}^{r k}, k = j % Ns
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int j = q + 8 * i;
-            const int k = j % Ns;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                cpx x = lds[(j + 64 * r) * OLS_CB + col];
-                if (r > 0) {
-                    const cpx w = tw256[(r * k * (64 / Ns)) & 255];
-                    x = INV ? cmulc(x, w) : cmul(x, w);
-                }
-                v[i][r] = x;
-            }
-            dft4<INV>(v[i][0], v[i][1], v[i][2], v[i][3]);
-        }
-        __syncthreads();
-    }
-    // after the last stage (Ns = 64): thread holds rows j + 64 r in natural order
-}
-
-__global__ void __launch_bounds__(256, 2)
-ols_col_fwd_kernel(const float *__restrict__ x, cpx *__restrict__ T, const cpx *__restrict__ tw256g,
-                   OlsGeom g, int64_t frame0)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    cpx *lds = (cpx *)smem;                    // [256][32]
-    cpx *tw256 = lds + OLS_N1 * OLS_CB;        // [256]
-    const int tid = threadIdx.x, col = tid & 31, q = tid >> 5;
-    tw256[tid] = tw256g[tid];
-    const int ncb = g.N2 / OLS_CB;
-    const int64_t pair = blockIdx.x / ncb;
-    const int cb = blockIdx.x % ncb;
-    const int n2 = cb * OLS_CB + col;
-    const int64_t fa = frame0 + 2 * pair, fb = fa + 1;
-    // frame -> (channel, frame-in-channel) -> first sample index in x
-    const int64_t ca = fa / g.F, ia0 = (fa % g.F) * g.S - g.pad_left;
-    const bool has_b = fb < g.nframes;
-    const int64_t cb_ = has_b ? fb / g.F : 0, ib0 = has_b ? (fb % g.F) * g.S - g.pad_left : 0;
-    const float *xa = x + ca * g.Tn, *xb = x + cb_ * g.Tn;
-
-    cpx v[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int j = q + 8 * i;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t n = (int64_t)(j + 64 * r) * g.N2 + n2;
-            const int64_t ia = ia0 + n, ib = ib0 + n;
-            const float re = (ia >= 0 && ia < g.Tn) ? xa[ia] : 0.0f;
-            const float im = (has_b && ib >= 0 && ib < g.Tn) ? xb[ib] : 0.0f;
-            v[i][r] = make_float2(re, im);
-        }
-    }
-    __syncthreads();      // tw256 visible
-    col_stages<false>(v, lds, tw256, col, q);
-    cpx *Tp = T + pair * ((int64_t)OLS_N1 * g.P2);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int j = q + 8 * i;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Tp[(int64_t)(j + 64 * r) * g.P2 + n2] = v[i][r];
-    }
-}
-
-__global__ void __launch_bounds__(256, 2)
-ols_col_inv_kernel(const cpx *__restrict__ T, float *__restrict__ y, const cpx *__restrict__ tw256g,
-                   OlsGeom g, int64_t frame0)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    cpx *lds = (cpx *)smem;
-    cpx *tw256 = lds + OLS_N1 * OLS_CB;
-    const int tid = threadIdx.x, col = tid & 31, q = tid >> 5;
-    tw256[tid] = tw256g[tid];
-    const int ncb = g.N2 / OLS_CB;
-    const int64_t pair = blockIdx.x / ncb;
-    const int cb = blockIdx.x % ncb;
-    const int n2 = cb * OLS_CB + col;
-    const cpx *Tp = T + pair * ((int64_t)OLS_N1 * g.P2);
-    cpx v[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int j = q + 8 * i;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[i][r] = Tp[(int64_t)(j + 64 * r) * g.P2 + n2];
-    }
-    __syncthreads();
-    col_stages<true>(v, lds, tw256, col, q);
-
-    const int64_t fa = frame0 + 2 * pair, fb = fa + 1;
-    const int64_t ca = fa / g.F, oa0 = (fa % g.F) * g.S;
-    const bool has_b = fb < g.nframes;
-    const int64_t cb_ = has_b ? fb / g.F : 0, ob0 = has_b ? (fb % g.F) * g.S : 0;
-    float *ya = y + ca * g.Tout, *yb = y + cb_ * g.Tout;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int j = q + 8 * i;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t n = (int64_t)(j + 64 * r) * g.N2 + n2;
-            if (n < g.S) {                                   // valid part of the block
-                const int64_t oa = oa0 + n - g.out_shift, ob = ob0 + n - g.out_shift;
-                if (oa >= 0 && oa < g.Tout) ya[oa] = v[i][r].x;
-                if (has_b && ob >= 0 && ob < g.Tout) yb[ob] = v[i][r].y;
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Column pass, radix (16, 16): thread (col = tid & 31, q = tid >> 5) owns butterflies j = q + 8 i
-// (i < 2) of its column, 16 rows each (rows j + 16 t).  One LDS exchange instead of three.
+// Column pass (A: forward from the signal, C: inverse to the output), radix (16, 16).  256 threads:
+// thread (col = tid & 31, q = tid >> 5) owns butterflies j = q + 8 i (i < 2) of its column, 16 rows
+// each (rows j + 16 t).  LDS: one [256][32] complex buffer (64 KB), one exchange per direction.
 // ---------------------------------------------------------------------------------------------
 template <bool INV>
 __device__ __forceinline__ void col_stages16(cpx (&v)[2][16], cpx *lds, const cpx *tw256, int col, int q)
@@ -595,13 +462,14 @@ __device__ __forceinline__ void row_fft4096(cpx (&v)[16], cpx *lds, const cpx *t
 
 // PF = persistent workgroups with the next row's loads in flight during the current row's FFTs
 // (the plain version leaves the memory system idle while a workgroup is in its six FFT stages)
-template <bool PF>
-__global__ void __launch_bounds__(256, PF ? 2 : 3)
+__global__ void __launch_bounds__(256, 3)
 ols_row4096_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *__restrict__ tw256g,
                    const cpx *__restrict__ t4log, const cpx *__restrict__ t4hig,
                    const cpx *__restrict__ tlo, const cpx *__restrict__ thi, const cpx *__restrict__ tu,
                    int64_t Nmask, int P2, int64_t nrows)
 {
+    // one workgroup per row (a persistent variant that prefetched the next row into registers ran at
+    // 2 waves/SIMD and was slower: DESIGN.md 6.1)
     constexpr int N2 = 4096;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cpx *lds = (cpx *)smem;                      // [4096 + 256]
@@ -613,52 +481,38 @@ ols_row4096_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *_
     typedef const float __attribute__((address_space(4))) *cfp;
     const cfp tuc = (cfp)(uintptr_t)tu;          // uniform per row: W_N^(256 k1 t)
     const unsigned umask = (unsigned)(Nmask >> 8);
-    cpx nv[PF ? 16 : 1];
-    int64_t row = blockIdx.x;
-    if (PF) {
-#pragma unroll
-        for (int t = 0; t < 16; ++t) nv[t] = T[row * P2 + j + 256 * t];
-    }
+    const int64_t row = blockIdx.x;
+    if (row >= nrows) return;
     __syncthreads();                             // tables visible
-    for (; row < nrows; row += gridDim.x) {
-        const int k1 = (int)(row % OLS_N1);
-        cpx *base = T + row * P2;
-        const cpx *hrow = Hp + (int64_t)k1 * N2;
-        const unsigned ml = (unsigned)(k1 * j);
-        const cpx wl = cmul(tlo[ml & 511], thi[ml >> 9]);
-        cpx v[16];
+    const int k1 = (int)(row % OLS_N1);
+    cpx *base = T + row * P2;
+    const cpx *hrow = Hp + (int64_t)k1 * N2;
+    const unsigned ml = (unsigned)(k1 * j);
+    const cpx wl = cmul(tlo[ml & 511], thi[ml >> 9]);
+    cpx v[16];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const unsigned iu = 2u * ((unsigned)(k1 * t) & umask);
-            const cpx ut = make_float2(tuc[iu], tuc[iu + 1]);
-            v[t] = cmul(PF ? nv[t] : base[j + 256 * t], cmul(wl, ut));
-        }
-        if (PF) {
-            const int64_t nrow = row + gridDim.x;
-            if (nrow < nrows) {
+    for (int t = 0; t < 16; ++t) {
+        const unsigned iu = 2u * ((unsigned)(k1 * t) & umask);
+        const cpx ut = make_float2(tuc[iu], tuc[iu + 1]);
+        v[t] = cmul(base[j + 256 * t], cmul(wl, ut));
+    }
+    row_fft4096<false>(v, lds, twB, twA, j);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < 16; ++t) nv[t] = T[nrow * P2 + j + 256 * t];
-            }
-        }
-        row_fft4096<false>(v, lds, twB, twA, j);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int t = 0; t < 16; ++t) v[t] = cmul(v[t], hrow[j + 256 * t]);
+    __builtin_amdgcn_sched_barrier(0);
+    row_fft4096<true>(v, lds, twB, twA, j);
+    float wlx = wl.x, wly = wl.y;
+    asm volatile("" : "+v"(wlx), "+v"(wly));     // recompute, do not keep 16 twiddles live (see row1024)
+    const cpx wl2 = make_float2(wlx, wly);
 #pragma unroll
-        for (int t = 0; t < 16; ++t) v[t] = cmul(v[t], hrow[j + 256 * t]);
-        __builtin_amdgcn_sched_barrier(0);
-        row_fft4096<true>(v, lds, twB, twA, j);
-        float wlx = wl.x, wly = wl.y;
-        asm volatile("" : "+v"(wlx), "+v"(wly));     // recompute, do not keep 16 twiddles live (see row1024)
-        const cpx wl2 = make_float2(wlx, wly);
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const unsigned iu = 2u * ((unsigned)(k1 * t) & umask);
-            const cpx ut = make_float2(tuc[iu], tuc[iu + 1]);
-            base[j + 256 * t] = cmulc(v[t], cmul(wl2, ut));
-        }
-        if (!PF) break;
-        __syncthreads();                         // LDS reuse by the next row
+    for (int t = 0; t < 16; ++t) {
+        const unsigned iu = 2u * ((unsigned)(k1 * t) & umask);
+        const cpx ut = make_float2(tuc[iu], tuc[iu + 1]);
+        base[j + 256 * t] = cmulc(v[t], cmul(wl2, ut));
     }
 }
+
 
 // ---------------------------------------------------------------------------------------------
 // Host: plan (tables + permuted spectrum) cache and orchestration
@@ -839,16 +693,12 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     const size_t shm_row = (size_t)(g.N2 * 5) * sizeof(cpx);
     static bool attr = false;
     if (!attr) {
-        TFX_HIP(hipFuncSetAttribute((const void *)ols_row4096_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
-        TFX_HIP(hipFuncSetAttribute((const void *)ols_row4096_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
-        TFX_HIP(hipFuncSetAttribute((const void *)ols_col_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_col));
+        TFX_HIP(hipFuncSetAttribute((const void *)ols_row4096_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
         TFX_HIP(hipFuncSetAttribute((const void *)ols_col_fwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_col));
         TFX_HIP(hipFuncSetAttribute((const void *)ols_col_inv16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_col));
-        TFX_HIP(hipFuncSetAttribute((const void *)ols_col_inv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_col));
         attr = true;
     }
     const int ncb = g.N2 / OLS_CB;
-    const bool col_r4 = envi("TFX_OLS_COL_R4", 0) != 0;
     // Two internal streams, slabs alternate between them: while one slab drains the tail of a pass
     // (the last, partially filled round of workgroups) the other slab's pass fills the idle CUs.
     // Fork/join with events on the caller's stream; each lane has its own workspace.
@@ -882,26 +732,16 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
         hipStream_t stream = nlanes > 1 ? lane_stream[ln] : user_stream;   // shadows the parameter
         cpx *T = Tlane[ln];
         {
-            ProfScope ps(col_r4 ? "ols_col_fwd_kernel" : "ols_col_fwd16_kernel", stream);
-            if (col_r4)
-                hipLaunchKernelGGL(ols_col_fwd_kernel, dim3((unsigned)(np * ncb)), dim3(256), shm_col, stream,
-                                   x, T, plan->tw256, g, 2 * p0);
-            else
-                hipLaunchKernelGGL(ols_col_fwd16_kernel, dim3((unsigned)(np * ncb)), dim3(256), shm_col, stream,
-                                   x, T, plan->tw256, g, 2 * p0);
+            ProfScope ps("ols_col_fwd16_kernel", stream);
+            hipLaunchKernelGGL(ols_col_fwd16_kernel, dim3((unsigned)(np * ncb)), dim3(256), shm_col, stream,
+                               x, T, plan->tw256, g, 2 * p0);
             TFX_HIP(hipGetLastError());
         }
         {
             const int64_t nrows = np * OLS_N1;
             ProfScope ps(g.N2 == 4096 ? "ols_row4096_kernel" : (g.N2 == 1024 && envi("TFX_OLS_ROW_R4", 0) == 0 ? "ols_row1024_kernel" : "ols_row_kernel"), stream);
-            if (g.N2 == 4096 && envi("TFX_OLS_ROW_PF", 0) != 0) {
-                const int64_t wgs = (int64_t)envi("TFX_OLS_ROW_WGS_PER_CU", 2) * 256;
-                hipLaunchKernelGGL(ols_row4096_kernel<true>, dim3((unsigned)(nrows < wgs ? nrows : wgs)), dim3(256),
-                                   (size_t)(4096 + 256 + 512) * sizeof(cpx), stream,
-                                   T, plan->Hp, plan->tw256, plan->t4lo, plan->t4hi, plan->tlo, plan->thi, plan->tu,
-                                   N - 1, g.P2, nrows);
-            } else if (g.N2 == 4096)
-                hipLaunchKernelGGL(ols_row4096_kernel<false>, dim3((unsigned)nrows), dim3(256),
+            if (g.N2 == 4096)
+                hipLaunchKernelGGL(ols_row4096_kernel, dim3((unsigned)nrows), dim3(256),
                                    (size_t)(4096 + 256 + 512) * sizeof(cpx), stream,
                                    T, plan->Hp, plan->tw256, plan->t4lo, plan->t4hi, plan->tlo, plan->thi, plan->tu,
                                    N - 1, g.P2, nrows);
@@ -918,13 +758,9 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
             TFX_HIP(hipGetLastError());
         }
         {
-            ProfScope ps(col_r4 ? "ols_col_inv_kernel" : "ols_col_inv16_kernel", stream);
-            if (col_r4)
-                hipLaunchKernelGGL(ols_col_inv_kernel, dim3((unsigned)(np * ncb)), dim3(256), shm_col, stream,
-                                   T, y, plan->tw256, g, 2 * p0);
-            else
-                hipLaunchKernelGGL(ols_col_inv16_kernel, dim3((unsigned)(np * ncb)), dim3(256), shm_col, stream,
-                                   T, y, plan->tw256, g, 2 * p0);
+            ProfScope ps("ols_col_inv16_kernel", stream);
+            hipLaunchKernelGGL(ols_col_inv16_kernel, dim3((unsigned)(np * ncb)), dim3(256), shm_col, stream,
+                               T, y, plan->tw256, g, 2 * p0);
             TFX_HIP(hipGetLastError());
         }
     }
