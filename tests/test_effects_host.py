@@ -124,3 +124,17 @@ def test_gain_folding_rules(oracle_backend):
     assert [type(m).__name__ for m in two.plan()] == ["FIR", "FIR"]
     tail = w | E.Gain(0.5)
     assert [type(m).__name__ for m in tail.plan()] == ["Gain"]
+
+
+def test_reverb_is_the_delay_line(golden, oracle_backend):
+    g = golden("delay")
+    x = torch.from_numpy(g["x"])
+    y = E.Reverb(delay=100, decay=0.5, mix=0.3)(x)
+    assert np.abs(y.numpy() - g["y"]).max() <= 1e-7
+    short = torch.zeros(2, 50)
+    assert E.Reverb(delay=100)(short) is short                       # not longer than the delay: same tensor
+    y3 = E.Reverb(delay=100, decay=0.5, mix=0.3)(x.reshape(1, 2, -1))
+    assert y3.shape == (1, 2, 1000) and np.abs(y3.numpy()[0] - g["y"]).max() <= 1e-7
+    for kw in (dict(delay=0), dict(decay=1.0), dict(decay=0.0), dict(mix=1.5)):
+        with pytest.raises(AssertionError):
+            E.Reverb(**kw)

@@ -657,3 +657,14 @@ def test_branch_sum_bit_exact(n, shape, dtype):
             exp += t[:, 1:]
         got = ext().sum_forward([t.to(DEV)[:, 1:] for t in wide])
         assert torch.equal(got.cpu(), exp)
+
+
+def test_reverb_on_device(golden):
+    from torchfx_amd import effect as E
+    g = golden("delay")
+    rv = E.Reverb(delay=100, decay=0.5, mix=0.3)
+    close(rv(dev(g["x"])), g["y"], 1e-7, "reverb")
+    close(rv(dev(g["x"]).reshape(1, 2, -1))[0], g["y"], 1e-7, "reverb 3-D")
+    close(rv(dev(g["x"][0])), g["y"][0], 1e-7, "reverb 1-D")
+    s = dev(np.zeros((2, 50), np.float32))
+    assert rv(s) is s

@@ -5,7 +5,8 @@ Reference: ``src/torchfx/effect.py`` -- ``FX.__or__`` (:253-258, builds a ``Filt
 SURVEY.md 8f rank 3: they are not filters, but a ``wave | iir | gain | fir`` pipeline passes through
 them, so they run as streaming HIP passes (``csrc/effects.hip``) and a clamp-free ``Gain`` can be
 folded into a neighbouring filter's coefficients by the ``Wave`` planner (opt-in, ``fuse_gain``).
-``Reverb`` / ``Delay`` remain out of scope.
+``Reverb`` is the reference's one-tap feed-forward comb over ``delay_line_forward``; the BPM-synced
+multi-tap ``Delay`` remains out of scope.
 """
 from __future__ import annotations
 
@@ -146,3 +147,24 @@ class Normalize(FX):
     @torch.no_grad()
     def forward(self, waveform: Tensor) -> Tensor:
         return self.strategy(waveform, self.peak)
+
+
+class Reverb(FX):
+    """``y[n] = x[n] + mix * decay * x[n - delay]`` -- the reference's "reverb" is one feed-forward
+    tap (``effect.py:789-931`` over ``delay_line_forward``, ``_csrc/cpu/delay_cpu.cpp:17-41``); a
+    signal not longer than the delay is returned unchanged (the same tensor)."""
+
+    def __init__(self, delay: int = 4410, decay: float = 0.5, mix: float = 0.5) -> None:
+        super().__init__()
+        assert delay > 0, "Delay must be positive."
+        assert 0 < decay < 1, "Decay must be between 0 and 1."
+        assert 0 <= mix <= 1, "Mix must be between 0 and 1."
+        self.delay, self.decay, self.mix = delay, decay, mix
+
+    @torch.no_grad()
+    def forward(self, waveform: Tensor) -> Tensor:
+        if waveform.size(-1) <= self.delay:
+            return waveform
+        from torchfx_amd._ops import delay_line_forward
+
+        return delay_line_forward(waveform, self.delay, self.decay, self.mix)

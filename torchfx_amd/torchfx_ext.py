@@ -157,18 +157,16 @@ def delay_line_forward(x: Tensor, delay_samples: int, decay: float, mix: float) 
     input tensor itself when the signal is not longer than the delay."""
     L.require_device(x, "x")
     lib = L.load()
-    orig_dim = x.dim()
     xc = x.contiguous()
-    if orig_dim == 1:
-        xc = xc.unsqueeze(0)
-    C, T = xc.shape
+    T = xc.shape[-1] if xc.dim() else 1
     if T <= delay_samples:
         return x
+    C = xc.numel() // T                       # any (..., T) layout is rows x T
     y = torch.empty_like(xc)
     with torch.cuda.device(x.device):
         L.check(lib.tfx_delay_line_forward(_ptr(xc), _ptr(y), L.dtype_code(xc), C, T, int(delay_samples),
                                            float(decay), float(mix), ctypes.c_void_p(L.stream_ptr(x))))
-    return y.squeeze(0) if orig_dim == 1 else y
+    return y
 
 
 def _kernel_host(kernel, dtype: torch.dtype) -> np.ndarray:
