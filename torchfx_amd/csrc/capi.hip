@@ -1,6 +1,6 @@
 // capi.hip -- extern "C" surface of libtorchfx_hip.so (see include/torchfx_hip.h) plus the
 // small shared services: thread-local error text, per-kernel HIP-event timing, device scratch,
-// and the delay-line kernel.
+// (the elementwise kernels live in effects.hip).
 #include "common.h"
 #include "../../include/torchfx_hip.h"
 
@@ -31,6 +31,8 @@ void stat_forward(const void *x, int dtype, int64_t C, int64_t T, int mode, int 
 void normalize_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, int mode, int per_row, double peak,
                        hipStream_t stream);
 void sum_forward(const void *const *xs_host, int n, void *y, int dtype, int64_t numel, hipStream_t stream);
+void delay_line_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, int64_t delay, double coeff,
+                        hipStream_t stream);
 int64_t fftconv_block_size(int64_t K, int64_t L);
 
 // ---- errors ------------------------------------------------------------------------------------
@@ -122,21 +124,6 @@ void scratch_clear()
 }
 
 // ---- elementwise kernels ----------------------------------------------------------------------------
-// y = x + coeff * x[n - D]   (src/torchfx/_csrc/cpu/delay_cpu.cpp:17-41)
-template <typename T>
-__global__ void __launch_bounds__(256)
-delay_line_kernel(const T *__restrict__ x, T *__restrict__ y, int64_t Tn, int64_t total, int64_t D, T coeff)
-{
-    int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (; g < total; g += stride) {
-        const int64_t n = g % Tn;
-        T v = x[g];
-        if (n >= D) v += coeff * x[g - D];
-        y[g] = v;
-    }
-}
-
 }  // namespace tfx
 
 using namespace tfx;
@@ -255,17 +242,7 @@ int tfx_delay_line_forward(const void *x, void *y, int dtype, int64_t C, int64_t
     TFX_API_BEGIN
     TFX_CHECK(dtype == TFX_F32 || dtype == TFX_F64, "delay_line_forward: bad dtype");
     TFX_CHECK(delay >= 0, "delay_line_forward: negative delay");
-    const int64_t total = C * T;
-    if (total == 0) return 0;
-    const unsigned grid = (unsigned)(ceil_div(total, 256) < 8192 ? ceil_div(total, 256) : 8192);
-    ProfScope ps("delay_line_kernel", (hipStream_t)stream);
-    if (dtype == TFX_F32)
-        hipLaunchKernelGGL(delay_line_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float *)x,
-                           (float *)y, T, total, delay, (float)(mix * decay));
-    else
-        hipLaunchKernelGGL(delay_line_kernel<double>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                           (const double *)x, (double *)y, T, total, delay, mix * decay);
-    TFX_HIP(hipGetLastError());
+    delay_line_forward(x, y, dtype, C, T, delay, mix * decay, (hipStream_t)stream);
     TFX_API_END
 }
 

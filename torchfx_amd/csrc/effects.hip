@@ -255,6 +255,59 @@ void sum_forward(const void *const *xs_host, int n, void *y, int dtype, int64_t 
     TFX_HIP(hipGetLastError());
 }
 
+// ---- delay line -----------------------------------------------------------------------------------
+// y[n] = x[n] + coeff * x[n - D]  (src/torchfx/_csrc/cpu/delay_cpu.cpp:17-41), row-tiled one-shot grid;
+// the delayed tap is a second, shifted read of the same row (served by the caches).
+template <typename T>
+__global__ void __launch_bounds__(EFX_THREADS)
+delay_line_kernel(const T *__restrict__ x, T *__restrict__ y, int64_t T_, int64_t tiles, int64_t D, T coeff)
+{
+    typedef typename Vec16<T>::type V;
+    constexpr int N = Vec16<T>::N;
+    const int64_t row = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const T *xr = x + row * T_;
+    T *yr = y + row * T_;
+    const int64_t base = (tile * EFX_U * EFX_THREADS + threadIdx.x) * N;
+    const bool vec = (((uintptr_t)xr | (uintptr_t)yr) & 15) == 0;
+#pragma unroll
+    for (int u = 0; u < EFX_U; ++u) {
+        const int64_t n0 = base + (int64_t)u * EFX_THREADS * N;
+        if (n0 >= T_) break;
+        if (vec && n0 + N <= T_) {
+            V v = *(const V *)(xr + n0);
+            T *e = (T *)&v;
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                if (n0 + i >= D) e[i] += coeff * xr[n0 + i - D];
+            *(V *)(yr + n0) = v;
+        } else {
+            for (int i = 0; i < N && n0 + i < T_; ++i) {
+                T v = xr[n0 + i];
+                if (n0 + i >= D) v += coeff * xr[n0 + i - D];
+                yr[n0 + i] = v;
+            }
+        }
+    }
+}
+
+void delay_line_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, int64_t delay, double coeff,
+                        hipStream_t stream)
+{
+    TFX_CHECK(dtype == TFX_F32 || dtype == TFX_F64, "delay_line_forward: bad dtype %d", dtype);
+    if (C == 0 || T == 0) return;
+    const int esz = dtype == TFX_F32 ? 4 : 8;
+    const int64_t tiles = ceil_div(T, (int64_t)EFX_U * EFX_THREADS * (16 / esz));
+    TFX_CHECK(C * tiles < (1ll << 31), "delay_line_forward: grid too large");
+    ProfScope ps("delay_line_kernel", stream);
+    if (dtype == TFX_F32)
+        hipLaunchKernelGGL(delay_line_kernel<float>, dim3((unsigned)(C * tiles)), dim3(EFX_THREADS), 0, stream,
+                           (const float *)x, (float *)y, T, tiles, delay, (float)coeff);
+    else
+        hipLaunchKernelGGL(delay_line_kernel<double>, dim3((unsigned)(C * tiles)), dim3(EFX_THREADS), 0, stream,
+                           (const double *)x, (double *)y, T, tiles, delay, coeff);
+    TFX_HIP(hipGetLastError());
+}
+
 // ---- host ---------------------------------------------------------------------------------------
 static inline int64_t efx_tiles(int64_t T, int esz) { return ceil_div(T, (int64_t)EFX_U * EFX_THREADS * (16 / esz)); }
 
