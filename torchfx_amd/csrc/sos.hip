@@ -15,11 +15,14 @@
 //   * a TILE = 64 lanes x LC consecutive samples.  Coalesced 16-byte global loads are
 //     transposed through a padded (bank-conflict-free) LDS stage so that lane j owns samples
 //     [j*LC, (j+1)*LC) in registers.  The next tile's loads are issued before computing.
-//   * per section, entirely in registers:  (1) each lane runs the DF1 recurrence over its LC
-//     samples from zero state (lane 0: from the carried true state);  (2) the 2-vector end
-//     states are combined across lanes by a Kogge-Stone scan with the constant 2x2 matrices
-//     C^(LC*2^k) (host-computed in long double);  (3) each lane adds the homogeneous response
-//     g[n] * (state at its chunk start).  Section s+1 then consumes the exact output of s.
+//   * per section, entirely in registers (7 flop per sample):  (1a) the feed-forward part
+//     f[n] = b0 v[n] + b1 v[n-1] + b2 v[n-2] overwrites v in place, walking n downwards;  (1b) the
+//     recursion runs over f from zero state (lane 0: from the carried true state) only to get the
+//     lane's 2-vector end state;  (2) the end states are combined across lanes by a DPP-only scan
+//     (row_shr Kogge-Stone inside 16-lane rows, row_bcast:15 / row_bcast:31 across rows, wave_shr:1)
+//     with constant 2x2 matrices C^(LC*m) computed on the host in long double;  (3) the recursion
+//     runs once more over f from the true start state and leaves the section output in place.
+//     Section s+1 then consumes the exact output of s.
 //   * arithmetic type TC is float64 by default -- the reference computes in float64
 //     (_ops.py:149) -- or float32 (TFX_PREC_F32).
 #include "common.h"
@@ -86,16 +89,6 @@ template <int CTRL, int ROWMASK> __device__ __forceinline__ double dpp_bcast(dou
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xF, false);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ float read_lane(float v, int l)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
-__device__ __forceinline__ double read_lane(double v, int l)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
-                            __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-
 template <typename T> struct U16 {               // 16 bytes of T
     static constexpr int N = 16 / sizeof(T);
     union { uint4 u; T e[N]; };
