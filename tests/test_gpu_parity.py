@@ -668,3 +668,26 @@ def test_reverb_on_device(golden):
     close(rv(dev(g["x"][0])), g["y"][0], 1e-7, "reverb 1-D")
     s = dev(np.zeros((2, 50), np.float32))
     assert rv(s) is s
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fft_conv_random_geometry_vs_float64(seed):
+    """Random (C, T, K, left/right padding) through every overlap-save geometry decision (native vs
+    rocFFT path, block size, aligned / unaligned frames, ragged last block) against a float64
+    correlation computed with SciPy."""
+    from scipy.signal import fftconvolve
+    rng = np.random.default_rng(7000 + seed)
+    C = int(rng.integers(1, 5))
+    K = int(rng.choice([1, 2, 15, 16, 17, 100, 1000, 4097, 20000, 70000]))
+    T = int(rng.integers(max(1, K // 3), 400_000))
+    pl = int(rng.choice([0, K - 1, int(rng.integers(0, K + 40))]))
+    pr = int(rng.choice([0, 0, int(rng.integers(0, 50))]))
+    if T + pl + pr < K:
+        pl = K - T
+    x = rnd((C, T), seed)
+    kf = (rng.standard_normal(K) / np.sqrt(K)).astype(np.float32)
+    y = ext().fft_conv_forward(dev(x), kf, (pl, pr))
+    xp = np.pad(x.astype(np.float64), ((0, 0), (pl, pr)))
+    exp = fftconvolve(xp, kf[::-1].astype(np.float64)[None], mode="valid", axes=-1)
+    assert y.shape == exp.shape == (C, T + pl + pr - K + 1)
+    close(y, exp.astype(np.float32), TOL_CONV_F32, f"C={C} T={T} K={K} pad=({pl},{pr})")
