@@ -200,6 +200,24 @@ int tfx_stat_forward(const void *x, int dtype, int64_t C, int64_t T, int mode, i
 int tfx_normalize_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, int mode, int per_row,
                           double peak, tfx_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * The data-format edge: decoded audio is INTERLEAVED frames [F, C]; the filter
+ * path works on PLANAR rows [C, F].  The reference transposes on the host (`data_np.T.copy()`,
+ * src/torchfx/wave.py:448-452, and `.numpy().T` before writing, :566-573); these do it on the device so
+ * the host buffer can be uploaded as it is, in chunks, and 16-bit PCM can cross PCIe as 2-byte samples.
+ *
+ * tfx_deinterleave_forward: in DEVICE [F, C] of float32 (in_kind TFX_PCM_F32) or int16 (TFX_PCM_S16,
+ *   converted as v * scale; scale = 1/32768 is libsndfile's normalisation);
+ *   out DEVICE float32 rows of pitch ld_out: out[c * ld_out + f_base + f] = in[f * C + c].
+ *   f_base / ld_out let a file be uploaded chunk by chunk into one [C, F_total] tensor.
+ * tfx_interleave_forward: the inverse, out[f * C + c] = in[c * ld_in + f_base + f], float32.
+ * ------------------------------------------------------------------------- */
+enum tfx_pcm { TFX_PCM_F32 = 0, TFX_PCM_S16 = 1 };
+int tfx_deinterleave_forward(const void *in, int in_kind, void *out, int64_t F, int64_t C, int64_t ld_out,
+                             int64_t f_base, double scale, tfx_stream_t stream);
+int tfx_interleave_forward(const void *in, void *out, int64_t F, int64_t C, int64_t ld_in, int64_t f_base,
+                           tfx_stream_t stream);
+
 /* Timing hooks for bench.py: HIP events recorded on the SAME stream the
  * kernels are launched on (torch.cuda.Event only sees torch's current stream).
  * tfx_prof_enable(1) makes every kernel launch inside the library bracket

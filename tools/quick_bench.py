@@ -82,6 +82,35 @@ def main():
         tot = sum(prof.values())
         print(f"sum of 8 branches     : kernels {tot:7.3f} ms  {9 * 4 * C * (T // 4) / tot / 1e9:5.2f} TB/s (8 reads + 1 write)", flush=True)
         del x, xs
+    if "io" in which:
+        from torchfx_amd import io as tio
+        for C, F in ((2, 28_800_000 * 4), (8, 28_800_000), (64, 28_800_000 // 4)):
+            fr = torch.randn(F, C, device=dev)
+            wall, prof = timed(lambda: E.deinterleave_forward(fr), reps=5, warm=2)
+            t1 = sum(prof.values())
+            pl = E.deinterleave_forward(fr)
+            wall, prof = timed(lambda: E.interleave_forward(pl), reps=5, warm=2)
+            t2 = sum(prof.values())
+            pcm = torch.randint(-30000, 30000, (F, C), device=dev, dtype=torch.int16)
+            wall, prof = timed(lambda: E.deinterleave_forward(pcm), reps=5, warm=2)
+            t3 = sum(prof.values())
+            print(f"layout C={C:3d} F={F}: deinterleave {t1:.3f} ms = {8 * C * F / t1 / 1e9:.2f} TB/s | interleave {t2:.3f} ms = "
+                  f"{8 * C * F / t2 / 1e9:.2f} TB/s | pcm16->f32 {t3:.3f} ms = {6 * C * F / t3 / 1e9:.2f} TB/s", flush=True)
+            del fr, pl, pcm
+        host = np.random.default_rng(0).standard_normal((28_800_000, 2)).astype(np.float32)
+        for dt in (np.float32, np.int16):
+            h = host if dt == np.float32 else (host * 3000).astype(np.int16)
+            tio.upload_interleaved(h, dev)
+            t0 = time.perf_counter()
+            tio.upload_interleaved(h, dev)
+            torch.cuda.synchronize()
+            dtm = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            torch.from_numpy(np.ascontiguousarray(h.T)).to(dev)
+            torch.cuda.synchronize()
+            dtr = time.perf_counter() - t0
+            print(f"upload 2 ch x 600 s {np.dtype(dt).name}: pipelined {dtm * 1e3:.1f} ms ({h.nbytes / dtm / 1e9:.1f} GB/s host->dev) "
+                  f"vs host transpose + copy {dtr * 1e3:.1f} ms", flush=True)
     if "fft" in which:
         C, T = 64, 2_880_000 * (10 if "big" in which else 1)
         x = torch.randn(C, T, device=dev)

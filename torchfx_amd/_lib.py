@@ -45,6 +45,8 @@ SIGNATURES = {
     "tfx_gain_forward": (_int, [_vp, _vp, _int, _i64, _dbl, _int, _vp]),
     "tfx_stat_forward": (_int, [_vp, _int, _i64, _i64, _int, _int, _vp, _vp]),
     "tfx_normalize_forward": (_int, [_vp, _vp, _int, _i64, _i64, _int, _int, _dbl, _vp]),
+    "tfx_deinterleave_forward": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _i64, _dbl, _vp]),
+    "tfx_interleave_forward": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "tfx_prof_enable": (_int, [_int]),
     "tfx_prof_collect": (ctypes.c_char_p, []),
     "tfx_clear_caches": (_int, []),

@@ -33,6 +33,11 @@ void normalize_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, 
 void sum_forward(const void *const *xs_host, int n, void *y, int dtype, int64_t numel, hipStream_t stream);
 void delay_line_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, int64_t delay, double coeff,
                         hipStream_t stream);
+// layout.hip
+void deinterleave_forward(const void *in, int in_kind, float *out, int64_t F, int64_t C, int64_t ld_out, int64_t f_base,
+                          double scale, hipStream_t stream);
+void interleave_forward(const float *in, float *out, int64_t F, int64_t C, int64_t ld_in, int64_t f_base,
+                        hipStream_t stream);
 int64_t fftconv_block_size(int64_t K, int64_t L);
 
 // ---- errors ------------------------------------------------------------------------------------
@@ -273,6 +278,22 @@ int tfx_normalize_forward(const void *x, void *y, int dtype, int64_t C, int64_t 
 {
     TFX_API_BEGIN
     normalize_forward(x, y, dtype, C, T, mode, per_row, peak, (hipStream_t)stream);
+    TFX_API_END
+}
+
+int tfx_deinterleave_forward(const void *in, int in_kind, void *out, int64_t F, int64_t C, int64_t ld_out,
+                             int64_t f_base, double scale, tfx_stream_t stream)
+{
+    TFX_API_BEGIN
+    deinterleave_forward(in, in_kind, (float *)out, F, C, ld_out, f_base, scale, (hipStream_t)stream);
+    TFX_API_END
+}
+
+int tfx_interleave_forward(const void *in, void *out, int64_t F, int64_t C, int64_t ld_in, int64_t f_base,
+                           tfx_stream_t stream)
+{
+    TFX_API_BEGIN
+    interleave_forward((const float *)in, (float *)out, F, C, ld_in, f_base, (hipStream_t)stream);
     TFX_API_END
 }
 

@@ -1,0 +1,77 @@
+"""The file edge of the path: decoded audio <-> device tensors.
+
+Reference: ``Wave.from_file`` / ``Wave.save`` (``src/torchfx/wave.py:406-576``) read and write through
+``soundfile`` and transpose ``[frames, channels] <-> [channels, frames]`` on the host.  Here the
+decoder's interleaved buffer is uploaded as it is -- in chunks, through two pinned staging buffers, on a
+copy stream that runs ahead of the de-interleave kernel -- and the transposition (and, for 16-bit
+PCM, the int16 -> float conversion, which halves the PCIe bytes) happens on the GPU.  The way back
+interleaves on the device and downloads chunk by chunk.  No decoding is done here: ``soundfile`` stays
+the codec, exactly as in the reference.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import Tensor
+
+PCM16_SCALE = 1.0 / 32768.0          # libsndfile's normalisation of 16-bit PCM read as float
+
+
+def upload_interleaved(frames: np.ndarray, device, chunk_frames: int = 1 << 22) -> Tensor:
+    """Host ``[F, C]`` float32 or int16 -> device planar float32 ``[C, F]``.
+
+    H2D copies go through two pinned staging buffers on a side stream; chunk *i+1* is being copied
+    while chunk *i* is de-interleaved on the caller's stream."""
+    from torchfx_amd import torchfx_ext
+
+    if frames.ndim != 2 or frames.dtype not in (np.float32, np.int16):
+        raise ValueError(f"expected [frames, channels] float32 or int16, got {frames.shape} {frames.dtype}")
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("upload_interleaved: target must be a ROCm device")
+    F, C = frames.shape
+    tdt = torch.float32 if frames.dtype == np.float32 else torch.int16
+    out = torch.empty((C, F), dtype=torch.float32, device=dev)
+    if F == 0:
+        return out
+    chunk = max(1, min(int(chunk_frames), F))
+    src = torch.from_numpy(np.ascontiguousarray(frames))
+    pinned = [torch.empty((chunk, C), dtype=tdt).pin_memory() for _ in range(2)]
+    staged = [torch.empty((chunk, C), dtype=tdt, device=dev) for _ in range(2)]
+    compute = torch.cuda.current_stream(dev)
+    copy = torch.cuda.Stream(dev)
+    done_copy = [torch.cuda.Event() for _ in range(2)]
+    done_use = [torch.cuda.Event() for _ in range(2)]
+    for i, f0 in enumerate(range(0, F, chunk)):
+        b = i & 1
+        n = min(chunk, F - f0)
+        if i >= 2:
+            done_use[b].synchronize()                    # the kernel that read staged[b] has finished
+        pinned[b][:n].copy_(src[f0:f0 + n])              # host memcpy into pinned memory
+        with torch.cuda.stream(copy):
+            staged[b][:n].copy_(pinned[b][:n], non_blocking=True)
+            done_copy[b].record(copy)
+        compute.wait_event(done_copy[b])
+        torchfx_ext.deinterleave_forward(staged[b][:n], out, frame_base=f0, scale=PCM16_SCALE)
+        done_use[b].record(compute)
+    for e in done_use:
+        e.synchronize()                                  # staging buffers may be freed after this
+    return out
+
+
+def download_interleaved(x: Tensor, chunk_frames: int = 1 << 22) -> np.ndarray:
+    """Device planar float32 ``[C, F]`` -> host interleaved ``[F, C]`` (what ``soundfile.write`` takes)."""
+    from torchfx_amd import torchfx_ext
+
+    if x.dim() != 2:
+        raise ValueError(f"expected [channels, frames], got {tuple(x.shape)}")
+    C, F = x.shape
+    out = np.empty((F, C), dtype=np.float32)
+    if F == 0:
+        return out
+    xf = x if x.dtype == torch.float32 else x.to(torch.float32)
+    chunk = max(1, min(int(chunk_frames), F))
+    for f0 in range(0, F, chunk):
+        n = min(chunk, F - f0)
+        out[f0:f0 + n] = torchfx_ext.interleave_forward(xf, f0, n).cpu().numpy()
+    return out

@@ -287,6 +287,45 @@ def normalize_forward(x: Tensor, peak: float, mode: int = STAT_ABSMAX, per_row: 
     return y
 
 
+def deinterleave_forward(frames: Tensor, out: Tensor | None = None, frame_base: int = 0,
+                         scale: float = 1.0 / 32768.0) -> Tensor:
+    """Interleaved ``[F, C]`` (float32, or int16 PCM scaled by ``scale``) -> planar float32 ``[C, F]``
+    (the device-side ``data_np.T.copy()`` of ``wave.py:448-452``).  With ``out`` ``[C, F_total]`` the
+    chunk lands at frames ``[frame_base, frame_base + F)`` of every row."""
+    L.require_device(frames, "frames")
+    if frames.dim() != 2 or frames.dtype not in (torch.float32, torch.int16):
+        raise RuntimeError(f"deinterleave_forward: expected [F, C] float32 or int16, got {tuple(frames.shape)} {frames.dtype}")
+    lib = L.load()
+    fr = frames.contiguous()
+    F, C = fr.shape
+    if out is None:
+        out = torch.empty((C, F), dtype=torch.float32, device=fr.device)
+    if out.dim() != 2 or out.shape[0] != C or out.dtype != torch.float32 or not out.is_contiguous() or out.device != fr.device:
+        raise RuntimeError("deinterleave_forward: out must be a contiguous float32 [C, F_total] tensor on the same device")
+    with torch.cuda.device(fr.device):
+        L.check(lib.tfx_deinterleave_forward(_ptr(fr), 0 if fr.dtype == torch.float32 else 1, _ptr(out), F, C,
+                                             out.shape[1], int(frame_base), float(scale),
+                                             ctypes.c_void_p(L.stream_ptr(fr))))
+    return out
+
+
+def interleave_forward(x: Tensor, frame_base: int = 0, frames: int | None = None) -> Tensor:
+    """Planar float32 ``[C, F_total]`` -> interleaved ``[F, C]`` of frames ``[frame_base, frame_base+F)``
+    (the device-side ``.numpy().T`` of ``wave.py:566-573``)."""
+    L.require_device(x, "x")
+    if x.dim() != 2 or x.dtype != torch.float32:
+        raise RuntimeError(f"interleave_forward: expected float32 [C, F], got {tuple(x.shape)} {x.dtype}")
+    lib = L.load()
+    xc = x.contiguous()
+    C, Ft = xc.shape
+    F = Ft - int(frame_base) if frames is None else int(frames)
+    out = torch.empty((max(F, 0), C), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(lib.tfx_interleave_forward(_ptr(xc), _ptr(out), F, C, Ft, int(frame_base),
+                                           ctypes.c_void_p(L.stream_ptr(x))))
+    return out
+
+
 def sos_plan_info(sos) -> dict:
     """Host-side plan facts for an SOS matrix: warm-up halo length, the f32 worst-case
     error bound and what ``precision='auto'`` would choose.  Needs the library but no GPU."""

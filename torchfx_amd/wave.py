@@ -5,8 +5,9 @@ Reference: ``src/torchfx/wave.py`` -- only the hot-path part is mirrored: constr
 become one ``FusedSOSCascade``; a *single* IIR step runs the module itself and therefore
 keeps its state across waves), ``_deferred`` (:241-257), ``to`` (:275-332), ``__or__``
 (:578-695: fs propagation + eager coefficient design, ``nn.Sequential`` flattened into
-steps), ``__len__`` / ``channels``.  File I/O (``from_file`` / ``save``) is out of scope
-(SURVEY.md 8f rank 4).
+steps), ``__len__`` / ``channels``.  ``from_file`` / ``save`` (:406-576) keep ``soundfile`` as the codec
+(imported lazily, as there) but, for a ROCm target, hand the decoder's interleaved buffer to
+``torchfx_amd.io`` -- chunked pinned upload + device-side de-interleave.
 
 Beyond the reference, the planner can also merge consecutive ``FIR`` steps into one
 overlap-save pass (``fuse_fir=True`` or env ``TORCHFX_AMD_FUSE_FIR=1``): convolution is
@@ -251,6 +252,72 @@ class Wave:
         return Wave._deferred(self._ys, self.fs, self._device, self.metadata,
                               self._pipeline + steps, self.fuse_fir, getattr(self, "fuse_spectral", False),
                               getattr(self, "fuse_gain", False))
+
+    # ------------------------------------------------------------------ files
+    _SUBTYPE_BY_ENCODING = {"PCM_S": lambda b: f"PCM_{b}", "PCM_U": lambda b: "PCM_U8" if b == 8 else f"PCM_{b}",
+                            "PCM_F": lambda b: "FLOAT" if b == 32 else "DOUBLE"}
+
+    @classmethod
+    def from_file(cls, path, frame_offset: int = 0, num_frames: int = -1, device="cpu",
+                  pcm16_on_device: bool = False) -> "Wave":
+        """Read an audio file through ``soundfile`` (``wave.py:406-462``): float32 ``[channels, frames]``,
+        ``fs`` and the ``num_frames / num_channels / subtype / format`` metadata.  With a ROCm ``device``
+        the transposition runs on the GPU behind a chunked pinned upload; ``pcm16_on_device`` additionally
+        reads 16-bit PCM files as int16 and converts on the GPU (same values, half the PCIe bytes)."""
+        import soundfile as _sf
+
+        stop = None if num_frames == -1 else frame_offset + num_frames
+        try:
+            info = _sf.info(str(path))
+            metadata = {"num_frames": info.frames, "num_channels": info.channels,
+                        "subtype": info.subtype, "format": info.format}
+        except Exception:
+            metadata = {}
+        on_gpu = torch.device(device).type == "cuda"
+        as_i16 = on_gpu and pcm16_on_device and metadata.get("subtype") == "PCM_16"
+        data_np, fs = _sf.read(str(path), start=frame_offset, stop=stop, dtype="int16" if as_i16 else "float32",
+                               always_2d=True)
+        if on_gpu:
+            from torchfx_amd import io as _io
+
+            w = object.__new__(cls)
+            w._ys = _io.upload_interleaved(data_np, device)
+            w.fs, w._device, w.metadata, w._pipeline = fs, device, metadata, []
+            w.fuse_fir = os.environ.get("TORCHFX_AMD_FUSE_FIR", "0") == "1"
+            w.fuse_spectral = os.environ.get("TORCHFX_AMD_FUSE_SPECTRAL", "0") == "1"
+            w.fuse_gain = os.environ.get("TORCHFX_AMD_FUSE_GAIN", "0") == "1"
+            return w
+        return cls(torch.from_numpy(np.ascontiguousarray(data_np.T)), fs, metadata=metadata)
+
+    def save(self, path, format: str | None = None, encoding: str | None = None,  # noqa: A002
+             bits_per_sample: int | None = None) -> None:
+        """Write through ``soundfile.write`` (``wave.py:481-576``): format from the extension (WAV when
+        unknown), ``encoding`` / ``bits_per_sample`` mapped to a libsndfile subtype, parent directories
+        created.  Device tensors are interleaved on the GPU and downloaded in chunks."""
+        import pathlib
+
+        import soundfile as _sf
+
+        out = pathlib.Path(path)
+        out.parent.mkdir(parents=True, exist_ok=True)
+        if format is None:
+            format = {".wav": "WAV", ".flac": "FLAC", ".ogg": "OGG"}.get(out.suffix.lower(), "WAV")  # noqa: A001
+        subtype = None
+        if encoding is not None and bits_per_sample is not None:
+            rule = self._SUBTYPE_BY_ENCODING.get(encoding)
+            subtype = rule(bits_per_sample) if rule else f"{encoding}{bits_per_sample}"
+        elif bits_per_sample is not None:
+            subtype = f"PCM_{bits_per_sample}"
+        elif encoding == "PCM_F":
+            subtype = "FLOAT"
+        ys = self.ys
+        if ys.is_cuda and ys.dim() == 2 and ys.dtype == torch.float32:
+            from torchfx_amd import io as _io
+
+            frames = _io.download_interleaved(ys)
+        else:
+            frames = ys.cpu().numpy().T
+        _sf.write(str(out), frames, self.fs, format=format, subtype=subtype)
 
     def transform(self, func, *args, **kwargs) -> "Wave":
         """Apply ``func`` to the (materialised) samples and wrap the result (``wave.py:334-360``)."""
