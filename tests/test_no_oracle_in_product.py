@@ -37,6 +37,6 @@ def test_no_cpu_fallback_branches():
             mods.add(node.module or "")
     assert not any(m.startswith(("scipy", "torch.nn", "torch.fft", "oracle")) for m in mods), mods
     ops = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name.endswith("_forward") and n.name != "sum_forward"]
-    assert len(ops) == 9
+    assert len(ops) >= 11                # every device op of the boundary; each must check the device first
     for fn in ops:
         assert "require_device" in ast.unparse(fn), fn.name
