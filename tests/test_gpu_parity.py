@@ -778,3 +778,22 @@ def test_chunked_upload_download_and_file_round_trip(tmp_path, monkeypatch):
     w.save(tmp_path / "out" / "copy.wav", encoding="PCM_S", bits_per_sample=16)
     rec = sf.written[-1]
     assert rec["subtype"] == "PCM_16" and np.array_equal(rec["data"], ref.T)
+
+
+def test_very_long_cascades_and_the_section_limit():
+    """100 all-pass sections (|H| = 1, so nothing decays): above 96 sections the host skips the O(K^3)
+    warm-up analysis and runs one sequential segment per row -- still exact; above 512 sections the call
+    is refused with a clear message."""
+    rng = np.random.default_rng(5)
+    K = 100
+    r, th = rng.uniform(0.3, 0.9, K), rng.uniform(0.2, 2.9, K)
+    a1, a2 = -2 * r * np.cos(th), r * r
+    sos = np.stack([a2, a1, np.ones(K), np.ones(K), a1, a2], axis=1)
+    assert ext().sos_plan_info(sos)["warmup"] == -1
+    x = rnd((2, 20000), 9, np.float64)
+    y, _, sy = ext().sos_forward(dev(x), None, torch.from_numpy(sos), None, None)
+    ey, _, esy = O.sos_forward(x, sos)
+    close(y, ey, 1e-10, "100 all-pass sections")
+    close(sy, esy, 1e-9, "states")
+    with pytest.raises(RuntimeError, match="at most 512 sections"):
+        ext().sos_forward(dev(x), None, torch.from_numpy(np.tile(sos, (6, 1))), None, None)

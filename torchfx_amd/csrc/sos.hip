@@ -454,6 +454,9 @@ static ld maxabs(const std::vector<ld> &a)
 // smallest W (with margin) such that max|A^W| < tol; -1 if not reached within 2^26 samples
 static int64_t warmup_length(const std::vector<double> &sos, int K)
 {
+    // O(K^3) long-double matrix squarings: beyond ~100 sections the analysis would cost seconds of host
+    // time, so such cascades run as one sequential segment per row (exact, just less parallel)
+    if (K > 96) return -1;
     const int D = 2 * K + 2;
     std::vector<ld> A((size_t)D * D, 0.0L);
     for (int j = 0; j < D; ++j) {
@@ -781,6 +784,8 @@ void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C_in,
     TFX_CHECK(NB >= 1, "sos_forward: need at least one band");
     const int64_t C = C_in * NB;
     TFX_CHECK(C >= 0 && T >= 0 && K >= 0, "sos_forward: negative size");
+    // the per-wave carry (4 values per section) lives in LDS next to the transposition stage
+    TFX_CHECK(K <= 512, "sos_forward: at most 512 sections per cascade (got %lld); split the cascade", (long long)K);
     TFX_CHECK(x_dtype == TFX_F32 || x_dtype == TFX_F64, "sos_forward: bad x dtype %d", x_dtype);
     TFX_CHECK(y_dtype == TFX_F32 || y_dtype == TFX_F64, "sos_forward: bad y dtype %d", y_dtype);
     if (C == 0) return;
