@@ -97,6 +97,23 @@ int tfx_sos_bank_forward(const void *x, int x_dtype, void *y, int y_dtype,
                          double *state_x_out, double *state_y_out,
                          int precision, tfx_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * tfx_sos_bank_sum_forward -- `f1 + f2 + ...` of IIR branches in ONE launch: n_bands independent
+ * K-section cascades applied to the same input rows and their outputs accumulated,
+ *   y[C,T] = sum_b cascade_b(x[C,T]),
+ * each branch rounded to the output dtype and added in branch order, exactly like
+ * ParallelFilterCombination.forward (src/torchfx/filter/__base.py:1019-1026: zeros_like + in-place
+ * adds of the branch outputs) -- 8 B/sample instead of n x 8 + (n + 1) x 4.  Shorter branches are
+ * padded by the caller with identity sections [1,0,0,1,0,0].  x and y must have the same dtype.
+ *   sos_host HOST [n_bands, K, 6];  states DEVICE [K, n_bands*C, 2] float64 (band-major rows).
+ * ------------------------------------------------------------------------- */
+int tfx_sos_bank_sum_forward(const void *x, int x_dtype, void *y, int y_dtype,
+                             int64_t C, int64_t T,
+                             const double *sos_host, int64_t n_bands, int64_t K,
+                             const double *state_x_in, const double *state_y_in,
+                             double *state_x_out, double *state_y_out,
+                             int precision, tfx_stream_t stream);
+
 /* What AUTO would pick for this SOS, and the plan facts (for DESIGN/bench
  * reporting and tests): *precision (TFX_PREC_F32/F64), *warmup (samples of
  * warm-up halo per time segment; -1 = filter memory too long, sequential

@@ -37,6 +37,21 @@ def sos_bank_forward(x, sos_banks, state_x, state_y, *, out_dtype=None, precisio
             torch.from_numpy(np.concatenate(sys_, axis=1)))
 
 
+def sos_bank_sum_forward(x, sos_banks, state_x, state_y, *, precision=None):
+    banks = _np(sos_banks) if hasattr(sos_banks, "detach") else np.asarray(sos_banks)
+    nb, c = banks.shape[0], x.shape[0]
+    calls.append(("sos_bank_sum_forward", tuple(x.shape), nb))
+    acc = torch.zeros_like(x)
+    sxs, sys_ = [], []
+    for b in range(nb):
+        sx = None if state_x is None else _np(state_x)[:, b * c:(b + 1) * c]
+        sy = None if state_y is None else _np(state_y)[:, b * c:(b + 1) * c]
+        y, nx, ny = O.sos_forward(_np(x), banks[b], sx, sy)
+        acc += torch.from_numpy(y).to(x.dtype)
+        sxs.append(nx), sys_.append(ny)
+    return acc, torch.from_numpy(np.concatenate(sxs, axis=1)), torch.from_numpy(np.concatenate(sys_, axis=1))
+
+
 def biquad_forward(x, b, a1, a2, state_x, state_y, *, out_dtype=None, precision=None):
     calls.append(("biquad_forward", tuple(x.shape)))
     y, sx, sy = O.biquad_forward(_np(x), _np(b), a1, a2, _np(state_x), _np(state_y))

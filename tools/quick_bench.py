@@ -82,6 +82,20 @@ def main():
         tot = sum(prof.values())
         print(f"sum of 8 branches     : kernels {tot:7.3f} ms  {9 * 4 * C * (T // 4) / tot / 1e9:5.2f} TB/s (8 reads + 1 write)", flush=True)
         del x, xs
+    if "plus" in which:
+        from torchfx_amd import filter as F
+        C, T = 64, 2_880_000
+        x = torch.randn(C, T, device=dev)
+        mk = lambda: [F.LoButterworth(800, order=4, fs=48000), F.HiButterworth(3000, order=4, fs=48000),
+                      F.ParametricEQ(frequency=1000, q=2.0, gain=4.0, fs=48000)]
+        a, b, c = mk()
+        comb = a + b + c
+        wall, prof = timed(lambda: comb(x), reps=5, warm=2)
+        print(f"f1+f2+f3 one launch : wall {wall:7.3f} ms  {8 * C * T / wall / 1e9:5.2f} TB/s of 8 B/sample", prof, flush=True)
+        fs_ = mk()
+        wall, prof = timed(lambda: E.sum_forward([f(x) for f in fs_]), reps=5, warm=2)
+        print(f"f1+f2+f3 staged     : wall {wall:7.3f} ms", prof, flush=True)
+        del x
     if "io" in which:
         from torchfx_amd import io as tio
         for C, F in ((2, 28_800_000 * 4), (8, 28_800_000), (64, 28_800_000 // 4)):

@@ -34,6 +34,7 @@ SIGNATURES = {
     "tfx_device_info": (_int, [ctypes.c_char_p, _int, ctypes.POINTER(_int)]),
     "tfx_sos_forward": (_int, [_vp, _int, _vp, _int, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
     "tfx_sos_bank_forward": (_int, [_vp, _int, _vp, _int, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _int, _vp]),
+    "tfx_sos_bank_sum_forward": (_int, [_vp, _int, _vp, _int, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _int, _vp]),
     "tfx_sos_plan_info": (_int, [_vp, _i64, ctypes.POINTER(_int), ctypes.POINTER(_i64), ctypes.POINTER(_dbl)]),
     "tfx_biquad_forward": (_int, [_vp, _int, _vp, _int, _i64, _i64, _vp, _dbl, _dbl, _vp, _vp, _vp, _vp, _int, _vp]),
     "tfx_fir_direct_forward": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _i64, _vp]),

@@ -14,7 +14,8 @@ namespace tfx {
 // implemented in sos.hip / fir.hip / fftconv.hip
 void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C, int64_t T,
                  const double *sos_host, int64_t K, const double *sx_in, const double *sy_in,
-                 double *sx_out, double *sy_out, void *y_sections, int precision, hipStream_t stream, int64_t NB = 1);
+                 double *sx_out, double *sy_out, void *y_sections, int precision, hipStream_t stream, int64_t NB = 1,
+                 bool sum_bands = false);
 void sos_plan_info(const double *sos_host, int64_t K, int *precision, int64_t *warmup, double *err_bound);
 void sos_clear_plans();
 void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
@@ -176,6 +177,17 @@ int tfx_sos_bank_forward(const void *x, int x_dtype, void *y, int y_dtype, int64
     TFX_API_BEGIN
     sos_forward(x, x_dtype, y, y_dtype, C, T, sos_host, K, state_x_in, state_y_in, state_x_out, state_y_out,
                 nullptr, precision, (hipStream_t)stream, n_bands);
+    TFX_API_END
+}
+
+int tfx_sos_bank_sum_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C, int64_t T,
+                             const double *sos_host, int64_t n_bands, int64_t K, const double *state_x_in,
+                             const double *state_y_in, double *state_x_out, double *state_y_out, int precision,
+                             tfx_stream_t stream)
+{
+    TFX_API_BEGIN
+    sos_forward(x, x_dtype, y, y_dtype, C, T, sos_host, K, state_x_in, state_y_in, state_x_out, state_y_out,
+                nullptr, precision, (hipStream_t)stream, n_bands, true);
     TFX_API_END
 }
 

@@ -57,6 +57,7 @@ struct SosParams {
     int64_t seg_len;     // multiple of 4 (VEC alignment)
     int64_t warm;        // multiple of 4
     int K, nseg, nsteps;
+    int nsum;            // > 0: sum mode -- every stream runs `nsum` bands over its input row and accumulates them
 };
 
 __device__ __forceinline__ void wave_sync()
@@ -97,9 +98,14 @@ template <typename T> struct U16 {               // 16 bytes of T
 // LC   samples per lane per tile          VEC  16-byte global accesses (aligned rows)
 // TAPS also store every section's output  PF   keep the next tile's loads in flight in registers
 // MINW waves per SIMD the register allocator must leave room for
-template <typename TIn, typename TOut, typename TC, int LC, bool VEC, bool TAPS, bool PF, int MINW>
+// SUMB sum mode (`+` of IIR branches, __base.py:1019-1026): the stream applies p.nsum independent
+//      cascades ("bands") to its input tile, which stays in the LDS stage, and accumulates their
+//      outputs -- rounded to TOut per band and added in branch order, exactly like the reference's
+//      zeros_like + in-place adds -- so N branches cost 8 B/sample instead of N x 8 + (N + 1) x 4
+template <typename TIn, typename TOut, typename TC, int LC, bool VEC, bool TAPS, bool PF, int MINW, bool SUMB = false>
 __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p)
 {
+    static_assert(!(TAPS && SUMB), "section taps are not available in sum mode");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int IOB = sizeof(TIn) > sizeof(TOut) ? sizeof(TIn) : sizeof(TOut);
     constexpr int CHUNK_B = LC * IOB + 16;   // per-lane chunk, padded: conflict-free b128 access
@@ -120,13 +126,15 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
     if (sid >= p.C * p.nseg) return;                       // wave-uniform
     const int64_t c = sid / p.nseg;
     const int g = (int)(sid - c * p.nseg);
-    const int carry_b = (((K * 4 + 2 * LC) * (int)sizeof(TC)) + 15) & ~15;
+    const int nbl = SUMB ? p.nsum : 1;                     // bands handled inside this stream
+    const int carry_b = (((nbl * K * 4 + 2 * LC) * (int)sizeof(TC)) + 15) & ~15;
     char *stage = smem + wave * (STAGE_B + carry_b);
-    TC *carry = (TC *)(stage + STAGE_B);                   // [K][4] = vin1 vin2 y1 y2
-    TC *cap = carry + K * 4;                               // [2][LC] final-state capture scratch
+    TC *carry = (TC *)(stage + STAGE_B);                   // [nbl][K][4] = vin1 vin2 y1 y2
+    TC *cap = carry + nbl * K * 4;                         // [2][LC] final-state capture scratch
 
     const int64_t T = p.T;
-    const int64_t band = c / p.C_in;
+    const int64_t band = SUMB ? 0 : c / p.C_in;
+    const int64_t st_rows = SUMB ? p.C_in * nbl : p.C;     // rows of the [K, rows, 2] state tensors
     const TIn *__restrict__ xrow = (const TIn *)p.x + (c - band * p.C_in) * T;
     TOut *__restrict__ yrow = (TOut *)p.y + c * T;
     // Coefficient tables live in the CONSTANT address space: wave-uniform indices then lower to
@@ -144,12 +152,13 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
 
     // ---- initial carry: the caller's state for the stream that starts at n = 0, zeros for a
     //      warm-up start.  Layout of state tensors: [K, C, 2] (iir_cpu.cpp:125-130).
-    for (int i = lane; i < K * 4; i += 64) {
-        const int s = i >> 2, f = i & 3;
+    for (int i = lane; i < nbl * K * 4; i += 64) {
+        const int b = i / (K * 4), rem = i - b * K * 4;
+        const int s = rem >> 2, f = rem & 3;
         TC v = (TC)0;
         if (start == 0) {
             const double *src = (f < 2) ? p.sx_in : p.sy_in;
-            if (src) v = (TC)src[((int64_t)s * p.C + c) * 2 + (f & 1)];
+            if (src) v = (TC)src[((int64_t)s * st_rows + (SUMB ? b * p.C_in + c : c)) * 2 + (f & 1)];
         }
         carry[i] = v;
     }
@@ -205,14 +214,19 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
             for (int i = 0; i < LC; ++i) *(TIn *)(st_in_s + i * (64 / LC) * CHUNK_B) = raws[i];
         }
         wave_sync();
+        auto read_own = [&]() {
 #pragma unroll
-        for (int i = 0; i < NUI; ++i) {
-            U16<TIn> v;
-            v.u = *(const uint4 *)(st_own + i * 16);
+            for (int i = 0; i < NUI; ++i) {
+                U16<TIn> v;
+                v.u = *(const uint4 *)(st_own + i * 16);
 #pragma unroll
-            for (int e = 0; e < EI; ++e) d[i * EI + e] = (TC)v.e[e];
+                for (int e = 0; e < EI; ++e) d[i * EI + e] = (TC)v.e[e];
+            }
+        };
+        if constexpr (!SUMB) {
+            read_own();
+            wave_sync();
         }
-        wave_sync();
 
         // ---- prefetch the next tile while this one is computed
         if constexpr (PF) { if (ts + TILE < out_end) load_tile(ts + TILE); }
@@ -220,19 +234,24 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
         const bool final_tile = last_seg && (ts + TILE >= T);
         const int r = (int)(T - ts);   // valid samples in the final tile (1..TILE)
 
+        TOut acc[SUMB ? LC : 1];
+        for (int bnd = 0; bnd < nbl; ++bnd) {
+        if constexpr (SUMB) read_own();          // the input tile is still in this lane's LDS chunk
+        const int64_t tband = SUMB ? bnd : band;
+        TC *const carry_s = carry + bnd * K * 4;
         for (int s = 0; s < K; ++s) {
-            const ctab_t tb = tab + s * TS;
+            const ctab_t tb = tab + (SUMB ? (int64_t)bnd * K * TS : 0) + s * TS;
             const TC b0 = tb[0], b1 = tb[1], b2 = tb[2], na1 = tb[3], na2 = tb[4];
             TC mqa[4], mqb[4];                  // P^(lane%16 + 1), P^(lane%32 + 1)
             {
-                const TC *mp = (const TC *)p.tab + (band * K + s) * TS + 32;
+                const TC *mp = (const TC *)p.tab + (tband * K + s) * TS + 32;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) mqa[i] = mp[4 * (lane & 15) + i];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) mqb[i] = mp[4 * (lane & 31) + i];
             }
-            const TC cv1 = carry[s * 4 + 0], cv2 = carry[s * 4 + 1];
-            const TC cy1 = carry[s * 4 + 2], cy2 = carry[s * 4 + 3];
+            const TC cv1 = carry_s[s * 4 + 0], cv2 = carry_s[s * 4 + 1];
+            const TC cy1 = carry_s[s * 4 + 2], cy2 = carry_s[s * 4 + 3];
 
             // final tile only: read the section's sequence at tile-local index idx (-1/-2 = the
             // carried history) through a 2 x LC scratch in LDS
@@ -258,7 +277,7 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
             if (lane == 0) { pv1 = cv1; pv2 = cv2; }
             TC sx1 = (TC)0, sx2 = (TC)0;
             if (final_tile) capture2(r - 1, r - 2, cv1, cv2, sx1, sx2);
-            if (lane == 63) { carry[s * 4 + 0] = d[LC - 1]; carry[s * 4 + 1] = d[LC - 2]; }
+            if (lane == 63) { carry_s[s * 4 + 0] = d[LC - 1]; carry_s[s * 4 + 1] = d[LC - 2]; }
 
             // (1a) feed-forward part f[n] = b0 v[n] + b1 v[n-1] + b2 v[n-2], written IN PLACE by
             //      walking n downwards (f[n] never needs v[m] for m > n): 3 flop/sample, no second
@@ -326,13 +345,13 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
                 if ((n & (SB - 1)) == SB - 1) __builtin_amdgcn_sched_barrier(0);
             }
 
-            if (lane == 63) { carry[s * 4 + 2] = d[LC - 1]; carry[s * 4 + 3] = d[LC - 2]; }
+            if (lane == 63) { carry_s[s * 4 + 2] = d[LC - 1]; carry_s[s * 4 + 3] = d[LC - 2]; }
 
             if (final_tile) {
                 TC sy1, sy2;
                 capture2(r - 1, r - 2, cy1, cy2, sy1, sy2);
                 if (lane == 0) {
-                    const int64_t o = ((int64_t)s * p.C + c) * 2;
+                    const int64_t o = ((int64_t)s * st_rows + (SUMB ? bnd * p.C_in + c : c)) * 2;
                     if (p.sx_out) { p.sx_out[o] = (double)sx1; p.sx_out[o + 1] = (double)sx2; }
                     if (p.sy_out) { p.sy_out[o] = (double)sy1; p.sy_out[o + 1] = (double)sy2; }
                 }
@@ -349,6 +368,16 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
             }
             wave_sync();   // carry[] written by lane 63 is read by all lanes next tile/section
         }
+        if constexpr (SUMB) {
+#pragma unroll
+            for (int n = 0; n < LC; ++n) acc[n] = (bnd == 0 ? (TOut)0 : acc[n]) + (TOut)d[n];
+        }
+        }   // bands
+        if constexpr (SUMB) {
+#pragma unroll
+            for (int n = 0; n < LC; ++n) d[n] = (TC)acc[n];
+        }
+
 
         // ---- store (skipped entirely while still inside the warm-up halo)
         if (ts + TILE > out_begin) {
@@ -714,15 +743,16 @@ static void plan_segments(SosParams &p, int64_t plan_warm, int TILE, int residen
     p.nseg = (int)nseg; p.seg_len = seg_len; p.warm = warm;
 }
 
-template <typename TIn, typename TOut, typename TC, int LC, bool VEC, bool TAPS, bool PF, int MINW>
+template <typename TIn, typename TOut, typename TC, int LC, bool VEC, bool TAPS, bool PF, int MINW, bool SUMB = false>
 static void launch_one(SosParams p, int64_t plan_warm, hipStream_t stream)
 {
     constexpr int IOB = sizeof(TIn) > sizeof(TOut) ? sizeof(TIn) : sizeof(TOut);
     constexpr int STAGE_B = 64 * (LC * IOB + 16);
-    const int carry_b = (((p.K * 4 + 2 * LC) * (int)sizeof(TC)) + 15) & ~15;
+    const int nbl = SUMB ? p.nsum : 1;
+    const int carry_b = (((nbl * p.K * 4 + 2 * LC) * (int)sizeof(TC)) + 15) & ~15;
     const size_t shmem = 4 * (size_t)(STAGE_B + carry_b);
-    TFX_CHECK(shmem <= 160 * 1024, "sos_forward: K=%d needs %zu B of LDS (max 163840)", p.K, shmem);
-    auto kern = sos_stream_kernel<TIn, TOut, TC, LC, VEC, TAPS, PF, MINW>;
+    TFX_CHECK(shmem <= 160 * 1024, "sos_forward: %d band(s) x K=%d need %zu B of LDS (max 163840)", nbl, p.K, shmem);
+    auto kern = sos_stream_kernel<TIn, TOut, TC, LC, VEC, TAPS, PF, MINW, SUMB>;
     if (shmem > 64 * 1024)
         TFX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     static int blocks_per_cu = 0;          // per template instance
@@ -773,23 +803,34 @@ static void launch_rare(const SosParams &p, bool vec, int64_t nstreams, hipStrea
     else launch_one<TIn, TOut, TC, 16, false, false, false, 3>(p, nstreams, stream);
 }
 
+// sum mode: one configuration per dtype mix (LC = 16: the accumulator costs registers)
+template <typename TIn, typename TOut, typename TC>
+static void launch_sum(const SosParams &p, bool vec, int64_t plan_warm, hipStream_t stream)
+{
+    if (vec) launch_one<TIn, TOut, TC, 16, true, false, false, 3, true>(p, plan_warm, stream);
+    else launch_one<TIn, TOut, TC, 16, false, false, false, 3, true>(p, plan_warm, stream);
+}
+
 // NB > 1 = filter-bank mode: NB independent K-section cascades applied to the same C_in input
 // rows; output rows (and state rows) are band-major: row = band * C_in + c.  C is the number of
-// INPUT rows.
+// INPUT rows.  sum_bands: the bands' outputs are accumulated into C_in output rows (`+`); the state
+// tensors keep the band-major [K, NB * C_in, 2] layout.
 void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C_in, int64_t T,
                  const double *sos_host, int64_t K,
                  const double *sx_in, const double *sy_in, double *sx_out, double *sy_out,
-                 void *y_sections, int precision, hipStream_t stream, int64_t NB)
+                 void *y_sections, int precision, hipStream_t stream, int64_t NB, bool sum_bands)
 {
     TFX_CHECK(NB >= 1, "sos_forward: need at least one band");
-    const int64_t C = C_in * NB;
+    TFX_CHECK(!(sum_bands && y_sections), "sos_forward: no section taps in sum mode");
+    const int64_t C = sum_bands ? C_in : C_in * NB;
     TFX_CHECK(C >= 0 && T >= 0 && K >= 0, "sos_forward: negative size");
     // the per-wave carry (4 values per section) lives in LDS next to the transposition stage
     TFX_CHECK(K <= 512, "sos_forward: at most 512 sections per cascade (got %lld); split the cascade", (long long)K);
     TFX_CHECK(x_dtype == TFX_F32 || x_dtype == TFX_F64, "sos_forward: bad x dtype %d", x_dtype);
     TFX_CHECK(y_dtype == TFX_F32 || y_dtype == TFX_F64, "sos_forward: bad y dtype %d", y_dtype);
     if (C == 0) return;
-    const size_t st_bytes = (size_t)K * C * 2 * sizeof(double);
+    const size_t st_bytes = (size_t)K * C_in * NB * 2 * sizeof(double);   // [K, NB * C_in, 2] in every mode
+    TFX_CHECK(!(sum_bands && K == 0), "sos_forward: sum mode needs at least one section");
     if (T == 0 || K == 0) {
         // no samples: state passes through (iir_cpu.cpp writes back what it loaded);
         // no sections: y = x
@@ -812,12 +853,13 @@ void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C_in,
     if (x_dtype == TFX_F64 || y_dtype == TFX_F64) prec = TFX_PREC_F64;   // f64 signals: always f64 math
     const bool rare = !(x_dtype == TFX_F32 && y_dtype == TFX_F32);
 
-    const int variant = rare ? 1 : env_int("TFX_SOS_VARIANT", 2);   // 2 = LC32 + register prefetch: measured best
+    const int variant = (rare || sum_bands) ? 1 : env_int("TFX_SOS_VARIANT", 2);   // 2 = LC32 + register prefetch: measured best
     const int LC = (variant & 1) ? 16 : 32;
     SosParams p{};
     p.x = x; p.y = y; p.taps = y_sections;
     p.sx_in = sx_in; p.sy_in = sy_in; p.sx_out = sx_out; p.sy_out = sy_out;
     p.C = C; p.C_in = C_in; p.T = T; p.K = (int)K;
+    p.nsum = sum_bands ? (int)NB : 0;
 
     const int64_t nstreams = pl->warm;     // segmentation is decided per kernel instance (launch_one)
 
@@ -829,12 +871,17 @@ void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C_in,
         p.tab = ensure_table<float>(pl, LC == 32 ? &pl->tab_f32_lc32 : &pl->tab_f32_lc16, LC,
                                     LC == 32 ? &pl->nsteps32 : &pl->nsteps16, stream);
         p.nsteps = LC == 32 ? pl->nsteps32 : pl->nsteps16;
-        launch_main<float, float, float>(p, vec, variant, nstreams, stream);
+        if (sum_bands) launch_sum<float, float, float>(p, vec, nstreams, stream);
+        else launch_main<float, float, float>(p, vec, variant, nstreams, stream);
     } else {
         p.tab = ensure_table<double>(pl, LC == 32 ? &pl->tab_f64_lc32 : &pl->tab_f64_lc16, LC,
                                      LC == 32 ? &pl->nsteps32 : &pl->nsteps16, stream);
         p.nsteps = LC == 32 ? pl->nsteps32 : pl->nsteps16;
-        if (x_dtype == TFX_F32 && y_dtype == TFX_F32) launch_main<float, float, double>(p, vec, variant, nstreams, stream);
+        if (sum_bands) {
+            if (x_dtype == TFX_F32 && y_dtype == TFX_F32) launch_sum<float, float, double>(p, vec, nstreams, stream);
+            else if (x_dtype == TFX_F64 && y_dtype == TFX_F64) launch_sum<double, double, double>(p, vec, nstreams, stream);
+            else TFX_CHECK(false, "sos_forward: sum mode needs equal input and output dtypes");
+        } else if (x_dtype == TFX_F32 && y_dtype == TFX_F32) launch_main<float, float, double>(p, vec, variant, nstreams, stream);
         else if (x_dtype == TFX_F32) launch_rare<float, double, double>(p, vec, nstreams, stream);
         else if (y_dtype == TFX_F32) launch_rare<double, float, double>(p, vec, nstreams, stream);
         else launch_rare<double, double, double>(p, vec, nstreams, stream);

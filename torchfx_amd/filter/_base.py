@@ -2,8 +2,11 @@
 
 Reference: ``src/torchfx/filter/__base.py`` -- ``AbstractFilter`` (:22-739, the parts with
 behaviour: ``_has_computed_coeff``, ``__add__``/``__radd__``) and
-``ParallelFilterCombination`` (:742-1026).  The sum of the branches is done by one HIP
-kernel (``tfx_sum_forward``) instead of ``zeros_like`` + N in-place adds.
+``ParallelFilterCombination`` (:742-1026).  When every branch is an SOS filter the whole sum is ONE
+launch of the cascade kernel in sum mode (``tfx_sos_bank_sum_forward``: the input tile is read once,
+every branch runs on it and the outputs are accumulated in registers -- 8 B/sample instead of
+N x 8 + (N + 1) x 4); otherwise the branches run one by one and one HIP kernel (``tfx_sum_forward``)
+adds them instead of ``zeros_like`` + N in-place adds.  Both keep the reference's accumulation order.
 """
 from __future__ import annotations
 
@@ -77,9 +80,54 @@ class ParallelFilterCombination(AbstractFilter):
         for f in self.filters:
             f.compute_coefficients()
 
+    def _leaves(self) -> list:
+        """Branches with a left-nested combination flattened: ``f1 + f2 + f3`` builds
+        ``(f1 + f2) + f3``, whose float accumulation 0 + y1 + y2 + y3 is the same sequence of additions
+        as the flat sum (a combination in any other position is kept as one branch)."""
+        first = self.filters[0]
+        head = first._leaves() if isinstance(first, ParallelFilterCombination) else [first]
+        return head + list(self.filters[1:])
+
+    def _sos_branches(self):
+        """``(filters, SOS matrices)`` if ALL leaves are plain stateful SOS filters, else None."""
+        leaves = self._leaves()
+        if len(leaves) < 2 or len(leaves) > 32:
+            return None
+        soses = []
+        for f in leaves:
+            if not hasattr(f, "_sos") or not hasattr(f, "_state_x") or getattr(f, "fs", None) is None:
+                return None
+            if f._sos is None:
+                f.compute_coefficients()
+            soses.append(f._sos.detach().to("cpu", torch.float64))
+        return leaves, soses
+
     @torch.no_grad()
     def forward(self, x: Tensor) -> Tensor:
         from torchfx_amd import torchfx_ext
 
-        branches = [f.forward(x) for f in self.filters]
-        return torchfx_ext.sum_forward(branches)
+        found = self._sos_branches() if x.dim() >= 1 and x.dtype in (torch.float32, torch.float64) else None
+        if found is None:
+            branches = [f.forward(x) for f in self.filters]
+            return torchfx_ext.sum_forward(branches)
+        filters, soses = found
+        # one launch: pad the shorter cascades with identity sections, gather / scatter the branch states
+        rows = x.reshape(-1, x.shape[-1])
+        c, kmax = rows.shape[0], max(s.shape[0] for s in soses)
+        ident = torch.tensor([[1.0, 0.0, 0.0, 1.0, 0.0, 0.0]], dtype=torch.float64)
+        banks = torch.stack([torch.cat([s, ident.expand(kmax - s.shape[0], 6)]) for s in soses])
+        sx = sy = None
+        if any(f._state_x is not None and f._state_x.shape[1] == c for f in filters):
+            sx = torch.zeros((kmax, len(soses) * c, 2), dtype=torch.float64, device=rows.device)
+            sy = torch.zeros_like(sx)
+            for i, (f, s) in enumerate(zip(filters, soses)):
+                if f._state_x is not None and f._state_x.shape[1] == c:     # else: fresh zeros (iir.py:136-138)
+                    sx[: s.shape[0], i * c:(i + 1) * c] = f._state_x.to(rows.device)
+                    sy[: s.shape[0], i * c:(i + 1) * c] = f._state_y.to(rows.device)
+        y, nsx, nsy = torchfx_ext.sos_bank_sum_forward(rows, banks, sx, sy)
+        for i, (f, s) in enumerate(zip(filters, soses)):
+            f._state_x = nsx[: s.shape[0], i * c:(i + 1) * c]
+            f._state_y = nsy[: s.shape[0], i * c:(i + 1) * c]
+            if hasattr(f, "_stateful"):
+                f._stateful = True
+        return y.reshape(x.shape)

@@ -126,6 +126,34 @@ def sos_bank_forward(x: Tensor, sos_banks, state_x: Tensor | None, state_y: Tens
     return y, nsx, nsy
 
 
+def sos_bank_sum_forward(x: Tensor, sos_banks, state_x: Tensor | None, state_y: Tensor | None, *, precision=None):
+    """``f1 + f2 + ...`` of IIR branches in one launch: ``sos_banks [NB,K,6]`` (host), ``x [C,T]`` ->
+    ``y [C,T] = sum_b cascade_b(x)`` with the reference's accumulation order and rounding
+    (``__base.py:1019-1026``); states ``[K, NB*C, 2]`` (band-major rows) or ``None``."""
+    if x.dim() != 2:
+        raise RuntimeError(f"sos_bank_sum_forward: x must be [C, T], got {tuple(x.shape)}")
+    L.require_device(x, "x")
+    lib = L.load()
+    x = x.contiguous()
+    C, T = x.shape
+    sos_h = _host_f64(sos_banks, 6)
+    if sos_h.ndim != 3:
+        raise RuntimeError("sos_bank_sum_forward: sos_banks must be [NB, K, 6]")
+    NB, K = sos_h.shape[0], sos_h.shape[1]
+    sx = _state(state_x, (K, NB * C, 2), x.device, "state_x")
+    sy = _state(state_y, (K, NB * C, 2), x.device, "state_y")
+    y = torch.empty_like(x)
+    nsx = torch.empty((K, NB * C, 2), dtype=torch.float64, device=x.device)
+    nsy = torch.empty_like(nsx)
+    with torch.cuda.device(x.device):
+        L.check(lib.tfx_sos_bank_sum_forward(
+            _ptr(x), L.dtype_code(x), _ptr(y), L.dtype_code(y), C, T,
+            sos_h.ctypes.data_as(ctypes.c_void_p), NB, K,
+            _ptr(sx), _ptr(sy), _ptr(nsx), _ptr(nsy),
+            L.precision_code(precision), ctypes.c_void_p(L.stream_ptr(x))))
+    return y, nsx, nsy
+
+
 def biquad_forward(x: Tensor, b: Tensor, a1: float, a2: float, state_x: Tensor | None,
                    state_y: Tensor | None, *, out_dtype: torch.dtype | None = None, precision=None):
     """Single biquad forward -- ``binding.cpp:30-50``: ``b [3]`` tensor, ``a1``/``a2``
