@@ -695,7 +695,7 @@ def test_fft_conv_random_geometry_vs_float64(seed):
 
 @pytest.mark.parametrize("C,T,K", [(2, 4096, 1024), (16, 1 << 21, 65536)])
 def test_pipeline_is_hip_graph_capturable(C, T, K):
-    """No host sync, no allocation and no plan work after warm-up: a whole step (IIR cascade ->
+    """No host sync, no allocation and no plan work after warm-up on a stream: a whole step (IIR cascade ->
     overlap-save on the internal two-stream fork/join -> gain+clamp -> per-channel normalise) can be
     captured into a HIP graph and replayed on new input with bit-identical results."""
     from scipy.signal import butter
@@ -719,7 +719,7 @@ def test_pipeline_is_hip_graph_capturable(C, T, K):
         step(static_x)
     torch.cuda.current_stream().wait_stream(side)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with torch.cuda.graph(graph, stream=side):           # workspaces are per stream: capture where it warmed up
         out = step(static_x)
     for seed in (78, 79):
         x2 = dev(rnd((C, T), seed))
@@ -853,3 +853,44 @@ def test_parallel_combination_runs_as_one_launch_and_keeps_branch_state():
     y2 = comb(x)                                                            # second call continues from it
     exp2 = e.sum_forward([f(x) for f in ref])
     close(y2, exp2.cpu().numpy(), 3e-7, "stateful second call")
+
+
+def test_two_host_threads_on_two_streams():
+    """ctypes releases the GIL, so two Python threads can be inside the library at once: enqueueing
+    is serialised by the API lock and every stream has its own workspaces, so concurrent pipelines on
+    different streams do not disturb each other."""
+    import threading
+    from scipy.signal import butter
+    e = ext()
+    sos = torch.from_numpy(butter(4, 0.1, output="sos"))
+    K = 4097
+    kf = (np.random.default_rng(1).standard_normal(K) / 64).astype(np.float32)
+    xs = [dev(rnd((6, 300_000), 100 + i)) for i in range(2)]
+
+    def run(x):
+        y, _, _ = e.sos_forward(x, None, sos, None, None)
+        y = e.fft_conv_forward(y, kf, (K - 1, 0))
+        return e.normalize_forward(y, 0.5, e.STAT_RMS, False)
+
+    refs = [run(x) for x in xs]
+    torch.cuda.synchronize()
+    outs, errs = [None, None], []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(10):
+                    outs[i] = run(xs[i])
+            st.synchronize()
+        except Exception as ex:  # pragma: no cover
+            errs.append(ex)
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        assert torch.equal(outs[i], refs[i]), i

@@ -34,7 +34,7 @@ for C, T in ((2, 4096), (8, 1 << 20)):
     with torch.cuda.stream(s):
         step(static_x)
     torch.cuda.current_stream().wait_stream(s)
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, stream=s):
         out = step(static_x)
     g.replay()
     torch.cuda.synchronize()

@@ -103,10 +103,12 @@ struct Scratch {
 };
 static std::mutex g_scr_mu;
 static std::map<std::string, Scratch> g_scr;
-void *scratch(const char *tag, size_t bytes)
+void *scratch(const char *tag, size_t bytes, hipStream_t stream)
 {
     std::lock_guard<std::mutex> lk(g_scr_mu);
-    Scratch &s = g_scr[tag];
+    char key[96];
+    snprintf(key, sizeof(key), "%s@%p", tag, (void *)stream);
+    Scratch &s = g_scr[key];
     if (s.bytes < bytes) {
         if (s.p) {
             // the old buffer may still be in use by queued work: drain before freeing
@@ -134,7 +136,10 @@ void scratch_clear()
 
 using namespace tfx;
 
-#define TFX_API_BEGIN try { prof_break_chain();
+// every compute entry point enqueues under one lock: the internal fork/join events, lane streams and
+// plan caches are process-wide, and ctypes releases the GIL, so two Python threads may be in here
+static std::recursive_mutex g_api_mu;
+#define TFX_API_BEGIN try { std::lock_guard<std::recursive_mutex> _api_lock(g_api_mu); prof_break_chain();
 #define TFX_API_END                                                                           \
     return 0;                                                                                 \
     }                                                                                         \

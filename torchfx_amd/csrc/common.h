@@ -55,9 +55,11 @@ struct ProfScope {
 };
 
 // ---- stream-ordered device scratch ------------------------------------------------
-// A tiny cache of device buffers keyed by (tag); grown on demand, reused across calls
-// on the same stream order (callers use them only inside one call's stream work).
-void *scratch(const char *tag, size_t bytes);
+// A tiny cache of device buffers keyed by (tag, stream): grown on demand and reused by later calls
+// on the SAME stream (stream order makes the reuse safe); calls on different streams never share a
+// buffer.  Host-side enqueueing is serialised by the API lock (capi.hip), so two threads can drive
+// two streams concurrently.
+void *scratch(const char *tag, size_t bytes, hipStream_t stream);
 void scratch_clear();
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

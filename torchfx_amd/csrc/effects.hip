@@ -335,7 +335,7 @@ static void stat_launch(const void *x, int dtype, int64_t rows, int64_t T, int m
     const int esz = dtype == TFX_F32 ? 4 : 8;
     const int64_t groups = ceil_div(efx_tiles(T, esz), (int64_t)EFX_RT);
     TFX_CHECK(rows * groups < (1ll << 31), "stat_forward: grid too large");
-    double *partial = (double *)scratch("efx_partial", (size_t)(rows * groups) * sizeof(double));
+    double *partial = (double *)scratch("efx_partial", (size_t)(rows * groups) * sizeof(double), stream);
 #define TFX_RED_LAUNCH(TT, MODE_)                                                                              \
     {                                                                                                          \
         {                                                                                                      \
@@ -370,7 +370,7 @@ void stat_forward(const void *x, int dtype, int64_t C, int64_t T, int mode, int 
     TFX_CHECK(mode == 0 || mode == 1, "stat_forward: bad mode %d", mode);
     const int64_t rows = per_row ? C : 1, len = per_row ? T : C * T;
     if (rows == 0) return;
-    double *stat = (double *)scratch("efx_stat", (size_t)rows * 8);
+    double *stat = (double *)scratch("efx_stat", (size_t)rows * 8, stream);
     if (len == 0) {
         TFX_HIP(hipMemsetAsync(out_dev, 0, (size_t)rows * 8, stream));
         return;
@@ -388,7 +388,7 @@ void normalize_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, 
     TFX_CHECK(mode == 0 || mode == 1, "normalize_forward: bad mode %d", mode);
     if (C == 0 || T == 0) return;
     const int64_t rows = per_row ? C : 1, len = per_row ? T : C * T;
-    double *stat = (double *)scratch("efx_stat", (size_t)rows * 8);
+    double *stat = (double *)scratch("efx_stat", (size_t)rows * 8, stream);
     stat_launch(x, dtype, rows, len, mode, stat, stream);
     const int esz = dtype == TFX_F32 ? 4 : 8;
     // the apply pass walks the same (rows, len) view, so per-row statistics line up with blockIdx

@@ -247,14 +247,14 @@ static void fft_conv_typed(const T *x, T *y, int dtype, int64_t C, int64_t Tn, c
     if (cps < 1) cps = 1;
     if (cps > C) cps = C;
 
-    T *fr = (T *)scratch(dtype == TFX_F32 ? "ols_frames32" : "ols_frames64", (size_t)(cps * F * N) * sizeof(T));
-    T2 *zs = (T2 *)scratch(dtype == TFX_F32 ? "ols_spec32" : "ols_spec64", (size_t)(cps * F * bins) * sizeof(T2));
+    T *fr = (T *)scratch(dtype == TFX_F32 ? "ols_frames32" : "ols_frames64", (size_t)(cps * F * N) * sizeof(T), stream);
+    T2 *zs = (T2 *)scratch(dtype == TFX_F32 ? "ols_spec32" : "ols_spec64", (size_t)(cps * F * bins) * sizeof(T2), stream);
 
     for (int64_t c0 = 0; c0 < C; c0 += cps) {
         const int64_t nc = (C - c0 < cps) ? (C - c0) : cps;
         const int64_t nb = nc * F;
         FftPlan &plan = get_fft_plan(dtype, N, nb);
-        void *work = plan.work_bytes ? scratch("ols_work", plan.work_bytes) : nullptr;
+        void *work = plan.work_bytes ? scratch("ols_work", plan.work_bytes, stream) : nullptr;
         {
             const int64_t total4 = nb * (N / 4);
             ProfScope ps("ols_frame_kernel", stream);

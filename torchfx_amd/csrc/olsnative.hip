@@ -688,7 +688,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     if (slab <= 0) slab = (envi("TFX_OLS_SLAB_MB", 64) << 20) / ((int64_t)OLS_N1 * g.P2 * (int64_t)sizeof(cpx));
     if (slab < 1) slab = 1;
     if (slab > npairs) slab = npairs;
-    cpx *T = (cpx *)scratch("olsn_T", (size_t)slab * (size_t)OLS_N1 * (size_t)g.P2 * sizeof(cpx));
+    cpx *T = (cpx *)scratch("olsn_T", (size_t)slab * (size_t)OLS_N1 * (size_t)g.P2 * sizeof(cpx), stream);
     const size_t shm_col = (size_t)(OLS_N1 * OLS_CB + 256) * sizeof(cpx);
     const size_t shm_row = (size_t)(g.N2 * 5) * sizeof(cpx);
     static bool attr = false;
@@ -721,7 +721,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
         }
         static const char *tags[MAXL] = {"olsn_T", "olsn_T2", "olsn_T3", "olsn_T4"};
         for (int i = 1; i < nlanes; ++i)
-            Tlane[i] = (cpx *)scratch(tags[i], (size_t)slab * (size_t)OLS_N1 * (size_t)g.P2 * sizeof(cpx));
+            Tlane[i] = (cpx *)scratch(tags[i], (size_t)slab * (size_t)OLS_N1 * (size_t)g.P2 * sizeof(cpx), user_stream);
         TFX_HIP(hipEventRecord(ev_fork, user_stream));
         for (int i = 0; i < nlanes; ++i) TFX_HIP(hipStreamWaitEvent(lane_stream[i], ev_fork, 0));
     }
