@@ -7,6 +7,11 @@ seams are only right with ``overlap >= K-1``.  File I/O is out of scope here (ho
 ``soundfile``), so this mirror works on tensors already on the device, with the same chunk /
 overlap arithmetic, plus what the reference lacks: :class:`StatefulFIR`, an FIR that carries its
 last K-1 input samples so that ``overlap = 0`` streaming is exact for FIR stages too.
+
+Small chunks are launch-bound (a 2 x 4096 step is ~60 us of host + launch overhead for a few us of
+GPU work), so ``StreamProcessor(..., use_graph=True)`` captures one full-size chunk step -- every
+effect's kernels plus the copies that carry the IIR states / FIR histories into persistent buffers --
+into a HIP graph and replays it per chunk (the ragged last chunk runs eagerly).
 """
 from __future__ import annotations
 
@@ -59,7 +64,7 @@ class StreamProcessor:
     """Run a list of effects over a long ``[C, T]`` tensor chunk by chunk."""
 
     def __init__(self, effects: Sequence[FX] | nn.Sequential, chunk_size: int = 65536, overlap: int = 0,
-                 device: str = "cuda") -> None:
+                 device: str = "cuda", use_graph: bool = False) -> None:
         if chunk_size <= 0:
             raise ValueError(f"chunk_size must be positive, got {chunk_size}")
         if overlap < 0:
@@ -71,6 +76,8 @@ class StreamProcessor:
             if not isinstance(e, FX):
                 raise TypeError("All effects must inherit from FX when used in StreamProcessor")
         self._chunk_size, self._overlap, self._device = chunk_size, overlap, device
+        self._use_graph = use_graph
+        self._graph = None            # (CUDAGraph, static in, static out, stream, signature, state slots, homes)
 
     chunk_size = property(lambda self: self._chunk_size)
     overlap = property(lambda self: self._overlap)
@@ -100,6 +107,72 @@ class StreamProcessor:
             if isinstance(e, AbstractFilter) and not e._has_computed_coeff:
                 e.compute_coefficients()
 
+    # ---- HIP-graph replay of the per-chunk step ------------------------------------------------
+    _STATE_ATTRS = ("_state_x", "_state_y", "_hist")
+
+    def _stateful_slots(self) -> list[tuple[object, str]]:
+        """(module, attribute) of every carried-state tensor reachable from the effects."""
+        slots = []
+        for e in self._effects:
+            for m in (e.modules() if isinstance(e, nn.Module) else [e]):
+                for a in self._STATE_ATTRS:
+                    if isinstance(getattr(m, a, None), Tensor):
+                        slots.append((m, a))
+                for f in getattr(m, "filters", ()) or ():       # combinations / banks hold plain lists
+                    for a in self._STATE_ATTRS:
+                        if isinstance(getattr(f, a, None), Tensor):
+                            slots.append((f, a))
+        return slots
+
+    def _run(self, w: Tensor) -> Tensor:
+        for e in self._effects:
+            w = e(w)
+        return w
+
+    def _graph_step(self, w: Tensor) -> Tensor:
+        """Replay the captured step on ``w`` (capturing it first; the carried states must exist)."""
+        sig = (tuple(w.shape), w.dtype, tuple(tuple(getattr(m, a).shape) for m, a in self._stateful_slots()))
+        if self._graph is None or self._graph[4] != sig:
+            dev = w.device
+            slots = self._stateful_slots()
+            # persistent homes for the carried state: the captured step reads them and its last nodes
+            # copy the new state back, so consecutive replays chain exactly like eager calls do
+            homes = [getattr(m, a).clone() for m, a in slots]
+            saved = [h.clone() for h in homes]
+            static_in = w.clone()
+
+            def rehome() -> None:
+                for (m, a), h in zip(slots, homes):
+                    setattr(m, a, h)
+
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                rehome()
+                self._run(static_in)                      # warms this stream's workspaces; not captured
+                for h, s0 in zip(homes, saved):           # undo what it did to the state
+                    h.copy_(s0)
+                rehome()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    static_out = self._run(static_in)
+                    for (m, a), h in zip(slots, homes):
+                        new = getattr(m, a)
+                        if new is not h:
+                            h.copy_(new)
+                    rehome()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            self._graph = (graph, static_in, static_out, side, sig, slots, homes)
+        graph, static_in, static_out, _, _, slots, homes = self._graph
+        for (m, a), h in zip(slots, homes):           # an eager step in between left the state elsewhere
+            cur = getattr(m, a)
+            if cur is not h:
+                h.copy_(cur)
+                setattr(m, a, h)
+        static_in.copy_(w)
+        graph.replay()
+        return static_out.clone()
+
     @torch.no_grad()
     def process_chunks(self, x: Tensor, fs: int) -> Generator[Tensor, None, None]:
         """Yield processed chunks; with overlap the first ``overlap`` samples of every chunk but the
@@ -108,10 +181,15 @@ class StreamProcessor:
         n = x.shape[-1]
         hop = self._chunk_size - self._overlap
         offset = 0
+        primed = False
         while offset < n:
             w = x[..., offset:offset + self._chunk_size].to(self._device)
-            for e in self._effects:
-                w = e(w)
+            full = w.shape[-1] == self._chunk_size
+            if self._use_graph and full and primed and w.is_cuda:
+                w = self._graph_step(w)
+            else:
+                w = self._run(w)            # first chunk creates the states; ragged tail runs eagerly
+                primed = True
             yield w[..., self._overlap:] if (self._overlap > 0 and offset > 0) else w
             offset += hop
 
