@@ -922,3 +922,16 @@ def test_stream_processor_graph_replay_equals_eager(chunk, overlap):
     eager2 = StreamProcessor(make(), chunk_size=chunk, overlap=overlap, device=DEV)
     eager2.process_tensor(x, 48000)
     assert torch.equal(again, eager2.process_tensor(x, 48000))
+
+
+def test_fft_conv_kernel_longer_than_the_native_limit():
+    """600 001 taps is beyond the hand-written path (K <= 2^19): the rocFFT path takes over."""
+    from scipy.signal import fftconvolve
+    K, T = 600_001, 1_500_000
+    assert not ext().ols_plan_info(K, T, (K - 1, 0))["native"]
+    rng = np.random.default_rng(8)
+    kf = (rng.standard_normal(K) * np.exp(-np.arange(K) / 90000.0) / 300).astype(np.float32)
+    x = rnd((2, T), 4)
+    y = ext().fft_conv_forward(dev(x), kf, (K - 1, 0))
+    exp = fftconvolve(np.pad(x.astype(np.float64), ((0, 0), (K - 1, 0))), kf[::-1].astype(np.float64)[None], mode="valid", axes=-1)
+    close(y, exp.astype(np.float32), TOL_CONV_F32, "600k taps")
