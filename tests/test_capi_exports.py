@@ -77,3 +77,35 @@ def test_custom_ops_registered_with_meta_and_no_cpu_kernel():
     assert torch.ops.torchfx_hip.fft_conv_forward(x, torch.empty(8), 7, 0).shape == (3, 100)
     with pytest.raises(NotImplementedError):          # there is deliberately no CPU implementation
         torch.ops.torchfx_hip.fir_direct_forward(torch.zeros(1, 8), torch.ones(3))
+
+
+def test_bad_arguments_are_errors_not_crashes():
+    """Null pointers / negative sizes come back as rc != 0 with a message (host-side checks, no GPU
+    needed: every entry point validates before it touches the device)."""
+    import ctypes
+
+    from torchfx_amd import _lib
+    lib = _lib.load()
+    sos = (ctypes.c_double * 6)(1, 0, 0, 1, 0, 0)
+    cases = [
+        lib.tfx_sos_forward(None, 0, None, 0, 2, 100, sos, 1, None, None, None, None, None, 2, None),
+        lib.tfx_sos_forward(None, 0, None, 0, -1, 100, sos, 1, None, None, None, None, None, 2, None),
+        lib.tfx_sos_forward(None, 7, None, 0, 2, 100, sos, 1, None, None, None, None, None, 2, None),
+        lib.tfx_fir_direct_forward(None, None, 0, 2, 100, None, 5, None),
+        lib.tfx_fft_conv_forward(None, None, 0, 2, 100, None, 5, 4, 0, None),
+        lib.tfx_fft_conv_forward(None, None, 0, 2, 3, None, 50, 0, 0, None),
+        lib.tfx_gain_forward(None, None, 0, 10, 1.0, 0, None),
+        lib.tfx_stat_forward(None, 0, 2, 10, 0, 0, None, None),
+        lib.tfx_normalize_forward(None, None, 0, 2, 10, 3, 0, 1.0, None),
+        lib.tfx_delay_line_forward(None, None, 0, 2, 10, 3, 0.5, 0.5, None),
+        lib.tfx_deinterleave_forward(None, 0, None, 10, 2, 10, 0, 1.0, None),
+        lib.tfx_deinterleave_forward(None, 5, None, 10, 2, 10, 0, 1.0, None),
+        lib.tfx_interleave_forward(None, None, 10, 0, 10, 0, None),
+        lib.tfx_sum_forward(None, 2, None, 0, 10, None),
+    ]
+    assert all(rc != 0 for rc in cases), cases
+    assert lib.tfx_fft_conv_forward(None, None, 0, 2, 3, None, 50, 0, 0, None) != 0
+    assert "kernel size" in lib.tfx_last_error().decode()                 # the reference's wording, _fftconv.py:111-115
+    # empty work is fine and touches nothing
+    assert lib.tfx_gain_forward(None, None, 0, 0, 1.0, 0, None) == 0
+    assert lib.tfx_sos_forward(None, 0, None, 0, 0, 100, sos, 1, None, None, None, None, None, 2, None) == 0

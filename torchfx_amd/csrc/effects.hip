@@ -235,6 +235,8 @@ void sum_forward(const void *const *xs_host, int n, void *y, int dtype, int64_t 
     TFX_CHECK(n >= 1 && n <= SUM_MAX, "sum_forward: between 1 and %d inputs", SUM_MAX);
     TFX_CHECK(dtype == TFX_F32 || dtype == TFX_F64, "sum_forward: bad dtype");
     if (numel == 0) return;
+    TFX_CHECK(numel > 0 && xs_host && y, "sum_forward: null pointer or negative size");
+    for (int i = 0; i < n; ++i) TFX_CHECK(xs_host[i], "sum_forward: null input %d", i);
     SumArgs a;
     a.n = n;
     uintptr_t bits = (uintptr_t)y;
@@ -295,6 +297,7 @@ void delay_line_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
 {
     TFX_CHECK(dtype == TFX_F32 || dtype == TFX_F64, "delay_line_forward: bad dtype %d", dtype);
     if (C == 0 || T == 0) return;
+    TFX_CHECK(C > 0 && T > 0 && x && y, "delay_line_forward: null pointer or negative size");
     const int esz = dtype == TFX_F32 ? 4 : 8;
     const int64_t tiles = ceil_div(T, (int64_t)EFX_U * EFX_THREADS * (16 / esz));
     TFX_CHECK(C * tiles < (1ll << 31), "delay_line_forward: grid too large");
@@ -315,6 +318,7 @@ void gain_forward(const void *x, void *y, int dtype, int64_t n, double gain, int
 {
     TFX_CHECK(dtype == TFX_F32 || dtype == TFX_F64, "gain_forward: bad dtype %d", dtype);
     if (n == 0) return;
+    TFX_CHECK(n > 0 && x && y, "gain_forward: null pointer or negative size");
     const int esz = dtype == TFX_F32 ? 4 : 8;
     const int64_t tiles = efx_tiles(n, esz);
     TFX_CHECK(tiles < (1ll << 31), "gain_forward: grid too large");
@@ -368,6 +372,7 @@ void stat_forward(const void *x, int dtype, int64_t C, int64_t T, int mode, int 
 {
     TFX_CHECK(dtype == TFX_F32 || dtype == TFX_F64, "stat_forward: bad dtype %d", dtype);
     TFX_CHECK(mode == 0 || mode == 1, "stat_forward: bad mode %d", mode);
+    TFX_CHECK(C >= 0 && T >= 0 && out_dev && (x || C * T == 0), "stat_forward: null pointer or negative size");
     const int64_t rows = per_row ? C : 1, len = per_row ? T : C * T;
     if (rows == 0) return;
     double *stat = (double *)scratch("efx_stat", (size_t)rows * 8, stream);
@@ -387,6 +392,7 @@ void normalize_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, 
     TFX_CHECK(dtype == TFX_F32 || dtype == TFX_F64, "normalize_forward: bad dtype %d", dtype);
     TFX_CHECK(mode == 0 || mode == 1, "normalize_forward: bad mode %d", mode);
     if (C == 0 || T == 0) return;
+    TFX_CHECK(C > 0 && T > 0 && x && y && peak == peak, "normalize_forward: null pointer, negative size or NaN peak");
     const int64_t rows = per_row ? C : 1, len = per_row ? T : C * T;
     double *stat = (double *)scratch("efx_stat", (size_t)rows * 8, stream);
     stat_launch(x, dtype, rows, len, mode, stat, stream);

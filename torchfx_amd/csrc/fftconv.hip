@@ -297,6 +297,8 @@ void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, c
     TFX_CHECK(L >= K, "Input should be at least as large as the kernel size %lld, but it is only %lld samples long.",
               (long long)K, (long long)L);
     if (C == 0) return;
+    TFX_CHECK(C > 0 && T >= 0, "fft_conv_forward: negative size");
+    TFX_CHECK(y && kernel_host && (x || T == 0), "fft_conv_forward: null pointer");
     int64_t Nn = 0;
     if (dtype == TFX_F32 && olsnative_supported(K, L, &Nn)) {
         olsnative_forward((const float *)x, (float *)y, C, T, (const float *)kernel_host, K, pad_left, pad_right, Nn, stream);

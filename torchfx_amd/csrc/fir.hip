@@ -234,6 +234,8 @@ void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
     TFX_CHECK(K >= 1, "fir_direct_forward: empty kernel");
     TFX_CHECK(K < (1 << 30), "fir_direct_forward: kernel too long");
     if (C == 0 || T == 0) return;
+    TFX_CHECK(x && y && kernel_host, "fir_direct_forward: null pointer");
+    TFX_CHECK(C > 0 && T > 0, "fir_direct_forward: negative size");
     const size_t esz = dtype == TFX_F32 ? 4 : 8;
     const int64_t Kpad = ceil_div(K, FIR_KC_MAX) * FIR_KC_MAX;
     const void *kdev = cached_taps(kernel_host, (size_t)K * esz, (size_t)Kpad * esz);

@@ -76,8 +76,9 @@ void deinterleave_forward(const void *in, int in_kind, float *out, int64_t F, in
 {
     TFX_CHECK(in_kind == 0 || in_kind == 1, "deinterleave_forward: input kind must be 0 (float32) or 1 (int16)");
     TFX_CHECK(C >= 1 && C <= 4096, "deinterleave_forward: 1..4096 channels, got %lld", (long long)C);
-    TFX_CHECK(ld_out >= f_base + F && f_base >= 0, "deinterleave_forward: output rows too short");
+    TFX_CHECK(F >= 0 && ld_out >= f_base + F && f_base >= 0, "deinterleave_forward: output rows too short");
     if (F == 0) return;
+    TFX_CHECK(in && out, "deinterleave_forward: null pointer");
     const int ft = frames_per_tile(C);
     const int64_t grid = ceil_div(F, (int64_t)ft);
     TFX_CHECK(grid < (1ll << 31), "deinterleave_forward: grid too large");
@@ -96,8 +97,9 @@ void interleave_forward(const float *in, float *out, int64_t F, int64_t C, int64
                         hipStream_t stream)
 {
     TFX_CHECK(C >= 1 && C <= 4096, "interleave_forward: 1..4096 channels, got %lld", (long long)C);
-    TFX_CHECK(ld_in >= f_base + F && f_base >= 0, "interleave_forward: input rows too short");
+    TFX_CHECK(F >= 0 && ld_in >= f_base + F && f_base >= 0, "interleave_forward: input rows too short");
     if (F == 0) return;
+    TFX_CHECK(in && out, "interleave_forward: null pointer");
     const int ft = frames_per_tile(C);
     const int64_t grid = ceil_div(F, (int64_t)ft);
     TFX_CHECK(grid < (1ll << 31), "interleave_forward: grid too large");
