@@ -2,22 +2,28 @@
 //
 // Why: with rocFFT the 65536-tap case costs 5 launches per slab (frame, r2c, cmul, c2r, un-frame)
 // and ~95 B of HBM traffic per output sample.  Here the whole block pipeline is three kernels and
-// ~31 B/sample, with the framing, zero padding, spectrum multiply, 1/N scaling and the
+// 26-31 B/sample (N = 2^20 / 2^18), with the framing, zero padding, spectrum multiply, 1/N scaling and the
 // "keep the first S samples" selection all fused into them:
 //
 //   * two real frames ride one complex transform:  z = frame_a + i frame_b.  The taps are real, so
 //     conv(z) = conv(a) + i conv(b): no real-FFT untangling pass, the spectrum multiply stays local.
-//   * N = N1 * N2 (N1 = 256) four-step decomposition, n = n1*N2 + n2, k = k1 + N1*k2:
+//   * N = N1 * N2 (N1 = 256, N2 = 256 / 1024 / 4096) four-step decomposition, n = n1*N2 + n2,
+//     k = k1 + N1*k2:
 //       A  column FFTs over n1 (256-point, 32 adjacent columns per workgroup, data gathered
 //          straight from the signal with zero fill)                          -> T[k1][n2]
-//       B  per row k1: * W_N^(n2 k1), 1024-point FFT over n2, * Hp[k1][k2], inverse FFT,
-//          * conj(W_N^(n2 k1)); one wavefront per row, in place                -> T[k1][n2]
+//       B  per row k1: * W_N^(n2 k1), N2-point FFT over n2, * Hp[k1][k2], inverse FFT,
+//          * conj(W_N^(n2 k1)), in place; one wavefront per row (N2 <= 1024) or one workgroup per
+//          row (N2 = 4096)                                                     -> T[k1][n2]
 //       C  column inverse FFTs over k1; real part -> frame_a's output samples, imaginary part ->
 //          frame_b's, only the first S = N-K+1 (valid) samples are stored      -> y
 //     Hp[k1][k2] = conj(FFT(kf_pad))[k1 + N1 k2] / N is precomputed once per filter on the host
 //     in float64.
-//   * every FFT is a radix-4 Stockham autosort in LDS; layouts are chosen so all LDS accesses of
-//     the column passes are conflict-free ([row][col] with the column on the lane index).
+//   * every FFT is a Stockham autosort in registers + LDS -- radix 16 x 16 in the column passes (one
+//     LDS exchange), radix 16 x 16 x 4 / 16 x 16 x 16 in the row passes (two exchanges per direction),
+//     radix 4 for N2 = 256; layouts are chosen so all LDS accesses of the column passes are
+//     conflict-free ([row][col] with the column on the lane index).
+//   * frames start on 128-byte lines (zero taps prepended to the flipped kernel, hop rounded to 32),
+//     slabs of frame pairs alternate over two internal streams.
 //
 // Semantics = fft_conv1d (src/torchfx/filter/_fftconv.py:70-141): causal correlation with the
 // stored flipped kernel, output length T + l + r - K + 1.
