@@ -425,6 +425,16 @@ def test_custom_ops_on_device(golden):
     f = golden("fir")
     close(torch.ops.torchfx_hip.fir_direct_forward(dev(f["x"]), torch.from_numpy(f["k32"])), f["direct32"], TOL_CONV_F32)
     close(torch.ops.torchfx_hip.fft_conv_forward(dev(f["x"]), torch.from_numpy(f["k32"]), 31, 0), f["fft32"], TOL_CONV_F32)
+    e = golden("effects")
+    x = dev(e["x"])
+    assert np.array_equal(torch.ops.torchfx_hip.gain_forward(x, 1.9, True).cpu().numpy(), e["gain_clamp"])
+    close(torch.ops.torchfx_hip.normalize_forward(x, 0.8, 0, True), e["norm_per_channel"], 1e-6)
+    banks = torch.from_numpy(np.stack([g["sos"], g["sos"][::-1].copy()]))
+    yb, _, _ = torch.ops.torchfx_hip.sos_bank_forward(dev(g["x"]), banks, None, None)
+    ys, _, _ = torch.ops.torchfx_hip.sos_bank_sum_forward(dev(g["x"]), banks, None, None)
+    assert yb.shape == (2, *g["x"].shape) and torch.equal(ys, yb[0] + yb[1])
+    m = torch.ops.torchfx_hip.sos_bank_sum_forward(torch.empty(3, 50, device="meta"), banks, None, None)
+    assert m[0].shape == (3, 50) and m[1].shape == (banks.shape[1], 6, 2)
 
 
 # ------------------------------------------------------------------ filter bank (8f rank 2)
