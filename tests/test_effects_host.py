@@ -110,7 +110,7 @@ def test_mixed_pipeline_golden_and_plan(golden, oracle_backend, fuse):
 
 def test_gain_folding_rules(oracle_backend):
     w = fx.Wave(torch.zeros(2, 64), 48000)
-    w.fuse_gain = True
+    w.fuse_gain, w.fuse_fir, w.fuse_spectral = True, False, False
     lone = w | E.Gain(0.5) | F.LoButterworth(4000, order=2) | E.Gain(0.1)
     assert [type(m).__name__ for m in lone.plan()] == ["Gain", "LoButterworth", "Gain"]   # stateful lone IIR: staged
     clamp = w | F.LoButterworth(4000, order=2) | F.HiButterworth(100, order=2) | E.Gain(2.0, clamp=True)

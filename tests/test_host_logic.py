@@ -159,10 +159,30 @@ def test_fused_cascade_validation():
         F.FusedSOSCascade(F.FIR([1.0]))
     fz = F.FusedSOSCascade.from_chain(nn.Sequential(F.LoButterworth(100, order=2, fs=8000), F.FIR([1.0]),
                                                     F.BiquadNotch(50, 5, fs=8000)))
-    assert fz._num_sections == 2
+    assert fz._sos.shape == (2, 6) and fz.fs == 8000
 
 
-def test_fir_run_merge_is_opt_in(oracle_backend, golden):
+def test_fusion_policy_defaults(monkeypatch):
+    """auto (default): FIR-run merge and spectral folding on, gain folding opt-in; reference: all off;
+    the per-feature variables override either way."""
+    for k in ("TORCHFX_AMD_FUSION", "TORCHFX_AMD_FUSE_FIR", "TORCHFX_AMD_FUSE_SPECTRAL", "TORCHFX_AMD_FUSE_GAIN"):
+        monkeypatch.delenv(k, raising=False)
+    w = fx.Wave(torch.zeros(1, 8), 48000)
+    assert (w.fuse_fir, w.fuse_spectral, w.fuse_gain) == (True, True, False)
+    monkeypatch.setenv("TORCHFX_AMD_FUSION", "reference")
+    w = fx.Wave(torch.zeros(1, 8), 48000)
+    assert (w.fuse_fir, w.fuse_spectral, w.fuse_gain) == (False, False, False)
+    chain = w | F.LoButterworth(2000, order=2) | F.HiButterworth(100, order=2) | F.FIR([0.5, 0.5]) | F.FIR([1.0, -1.0])
+    assert [type(m).__name__ for m in chain.plan()] == ["FusedSOSCascade", "FIR", "FIR"]     # wave.py:207-239 staging
+    monkeypatch.setenv("TORCHFX_AMD_FUSE_FIR", "1")
+    assert fx.Wave(torch.zeros(1, 8), 48000).fuse_fir is True
+    monkeypatch.setenv("TORCHFX_AMD_FUSION", "auto")
+    monkeypatch.setenv("TORCHFX_AMD_FUSE_SPECTRAL", "0")
+    w = fx.Wave(torch.zeros(1, 8), 48000)
+    assert (w.fuse_fir, w.fuse_spectral) == (True, False)
+
+
+def test_fir_run_merge(oracle_backend, golden):
     g = golden("chain")
     from scipy.signal import firwin
     irs = np.random.default_rng(1).standard_normal(4097) * np.exp(-np.arange(4097) / 500.0)
@@ -170,7 +190,7 @@ def test_fir_run_merge_is_opt_in(oracle_backend, golden):
 
     def pipe(fuse):
         w = fx.Wave(g["xc"], 48000)
-        w.fuse_fir = fuse
+        w.fuse_fir, w.fuse_spectral = fuse, False
         return (w | F.LoButterworth(2000, order=6) | F.ParametricEQ(frequency=1000, q=2.0, gain=3.0)
                 | F.FIR(firwin(1024, 5000, fs=48000)) | F.FIR(irs))
     assert len(pipe(False).plan()) == 3
@@ -285,7 +305,7 @@ def test_stream_processor_chunked_equals_contiguous(oracle_backend):
         StreamProcessor([nn.Identity()])
 
 
-def test_spectral_fusion_is_opt_in_and_matches_staged(oracle_backend, golden):
+def test_spectral_fusion_matches_staged(oracle_backend, golden):
     g = golden("chain")
     from scipy.signal import firwin
     irs = np.random.default_rng(1).standard_normal(4097) * np.exp(-np.arange(4097) / 500.0)

@@ -107,7 +107,7 @@ void *scratch(const char *tag, size_t bytes, hipStream_t stream)
 {
     std::lock_guard<std::mutex> lk(g_scr_mu);
     char key[96];
-    snprintf(key, sizeof(key), "%s@%p", tag, (void *)stream);
+    snprintf(key, sizeof(key), "%s@%p#%d", tag, (void *)stream, current_device());
     Scratch &s = g_scr[key];
     if (s.bytes < bytes) {
         if (s.p) {
@@ -199,6 +199,7 @@ int tfx_sos_bank_sum_forward(const void *x, int x_dtype, void *y, int y_dtype, i
 int tfx_sos_plan_info(const double *sos_host, int64_t K, int *precision, int64_t *warmup, double *err_bound)
 {
     TFX_API_BEGIN
+    TFX_CHECK(sos_host && K >= 1 && K <= 512, "sos_plan_info: null coefficients or bad section count %lld", (long long)K);
     sos_plan_info(sos_host, K, precision, warmup, err_bound);
     TFX_API_END
 }
@@ -210,6 +211,7 @@ int tfx_biquad_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t
 {
     TFX_API_BEGIN
     // a biquad is the K = 1 cascade; [C,2] states are the [1,C,2] layout
+    TFX_CHECK(b_host, "biquad_forward: null numerator pointer");
     const double sos[6] = {b_host[0], b_host[1], b_host[2], 1.0, a1, a2};
     sos_forward(x, x_dtype, y, y_dtype, C, T, sos, 1, state_x_in, state_y_in, state_x_out, state_y_out, nullptr,
                 precision, (hipStream_t)stream);

@@ -64,4 +64,16 @@ void scratch_clear();
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Every device-side cache (plans, taps, spectra, scratch, internal streams, occupancy answers) is
+// keyed by the ordinal of the device that is current at the call: one process may drive several GPUs
+// (the Python layer wraps each op in torch.cuda.device(x.device)).
+constexpr int TFX_MAX_DEVICES = 64;
+inline int current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;      // host-only planning calls work without a device
+    TFX_CHECK(dev >= 0 && dev < TFX_MAX_DEVICES, "device ordinal %d out of range", dev);
+    return dev;
+}
+
 }  // namespace tfx

@@ -93,10 +93,11 @@ ols_unframe_kernel(const T *__restrict__ fr, T *__restrict__ y, int64_t Tout, in
 
 // ---- plans -------------------------------------------------------------------------------------
 struct FftKey {
-    int dtype;
+    int dev, dtype;
     int64_t N, batch;
     bool operator<(const FftKey &o) const
     {
+        if (dev != o.dev) return dev < o.dev;
         if (dtype != o.dtype) return dtype < o.dtype;
         if (N != o.N) return N < o.N;
         return batch < o.batch;
@@ -107,11 +108,12 @@ struct FftPlan {
     size_t work_bytes = 0;
 };
 struct SpecKey {
-    int dtype;
+    int dev, dtype;
     int64_t N;
     std::vector<char> taps;
     bool operator<(const SpecKey &o) const
     {
+        if (dev != o.dev) return dev < o.dev;
         if (dtype != o.dtype) return dtype < o.dtype;
         if (N != o.N) return N < o.N;
         return taps < o.taps;
@@ -129,7 +131,7 @@ static FftPlan &get_fft_plan(int dtype, int64_t N, int64_t batch)
         TFX_ROCFFT(rocfft_setup());
         g_rocfft_up = true;
     }
-    FftKey key{dtype, N, batch};
+    FftKey key{current_device(), dtype, N, batch};
     auto it = g_fft_plans.find(key);
     if (it != g_fft_plans.end()) return it->second;
     FftPlan pl;
@@ -161,7 +163,7 @@ static void exec_fft(rocfft_plan plan, void *in, void *out, void *work, size_t w
 template <typename T, typename T2>
 static void *get_spectrum(int dtype, const void *kernel_host, int64_t K, int64_t N, hipStream_t stream)
 {
-    SpecKey key{dtype, N, std::vector<char>((const char *)kernel_host, (const char *)kernel_host + K * sizeof(T))};
+    SpecKey key{current_device(), dtype, N, std::vector<char>((const char *)kernel_host, (const char *)kernel_host + K * sizeof(T))};
     auto it = g_specs.find(key);
     if (it != g_specs.end()) return it->second;
     if (g_specs.size() > 64) {

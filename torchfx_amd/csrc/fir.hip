@@ -37,6 +37,7 @@ static const void *cached_taps(const void *host, size_t bytes, size_t padded)
 {
     std::vector<char> key((const char *)host, (const char *)host + bytes);
     key.push_back((char)(padded & 0xff));
+    key.push_back((char)current_device());
     std::lock_guard<std::mutex> lk(g_taps_mu);
     auto it = g_taps.find(key);
     if (it != g_taps.end()) return it->second;
@@ -261,8 +262,8 @@ void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
             const int XW = FIR_NOUT + KC + 32;
             const int XW_PAD = XW + (XW >> 5) + 1;
             const size_t shmem = (((XW_PAD + 3) & ~3) + 31 + KC + 33) * sizeof(float);
-            static bool attr_done[3] = {false, false, false};
-            bool &done = attr_done[KC == 128 ? 0 : (KC == 512 ? 1 : 2)];
+            static bool attr_done[TFX_MAX_DEVICES][3] = {};
+            bool &done = attr_done[current_device()][KC == 128 ? 0 : (KC == 512 ? 1 : 2)];
             if (!done) {
                 TFX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
                 done = true;

@@ -30,6 +30,7 @@
 #include "common.h"
 #include "../../include/torchfx_hip.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -111,20 +112,21 @@ __device__ __forceinline__ void dft16(cpx (&v)[16])
 // thread (col = tid & 31, q = tid >> 5) owns butterflies j = q + 8 i (i < 2) of its column, 16 rows
 // each (rows j + 16 t).  LDS: one [256][32] complex buffer (64 KB), one exchange per direction.
 // ---------------------------------------------------------------------------------------------
-template <bool INV>
-__device__ __forceinline__ void col_stages16(cpx (&v)[2][16], cpx *lds, const cpx *tw256, int col, int q)
+template <bool INV, int NBF>
+__device__ __forceinline__ void col_stages16(cpx (&v)[NBF][16], cpx *lds, const cpx *tw256, int col, int q)
 {
+    constexpr int QS = 16 / NBF;               // butterfly j = q + QS * i
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NBF; ++i) {
         dft16<INV>(v[i]);
-        const int j = q + 8 * i;
+        const int j = q + QS * i;
 #pragma unroll
         for (int k = 0; k < 16; ++k) lds[(16 * j + k) * OLS_CB + col] = v[i][DFT16_AT(k)];
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int j = q + 8 * i;
+    for (int i = 0; i < NBF; ++i) {
+        const int j = q + QS * i;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             cpx x = lds[(j + 16 * t) * OLS_CB + col];
@@ -138,15 +140,20 @@ __device__ __forceinline__ void col_stages16(cpx (&v)[2][16], cpx *lds, const cp
     }
 }
 
-__global__ void __launch_bounds__(256, 2)
+// NBF = butterflies per thread: 2 -> 256 threads (8 waves per CU at 2 workgroups), 1 -> 512 threads
+// (16 waves per CU, half the registers per thread).  PROBE (development, tools/ols_knobs.py):
+// 1 = no FFT (load -> store), 2 = loads only, 3 = stores only.
+template <int NBF, int PROBE>
+__global__ void __launch_bounds__(512 / NBF, 2)
 ols_col_fwd16_kernel(const float *__restrict__ x, cpx *__restrict__ T, const cpx *__restrict__ tw256g,
                      OlsGeom g, int64_t frame0)
 {
+    constexpr int QS = 16 / NBF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cpx *lds = (cpx *)smem;                    // [256][32]
     cpx *tw256 = lds + OLS_N1 * OLS_CB;        // [256]
     const int tid = threadIdx.x, col = tid & 31, q = tid >> 5;
-    tw256[tid] = tw256g[tid];
+    if (tid < 256) tw256[tid] = tw256g[tid];
     const int ncb = g.N2 / OLS_CB;
     const int64_t pair = blockIdx.x / ncb;
     const int cb = blockIdx.x % ncb;
@@ -156,24 +163,29 @@ ols_col_fwd16_kernel(const float *__restrict__ x, cpx *__restrict__ T, const cpx
     const bool has_b = fb < g.nframes;
     const int64_t cb_ = has_b ? fb / g.F : 0, ib0 = has_b ? (fb % g.F) * g.S - g.pad_left : 0;
     const float *xa = x + ca * g.Tn, *xb = x + cb_ * g.Tn;
-    cpx v[2][16];
+    cpx v[NBF][16];
     // interior frames (the common case) need no bounds checks
     const int64_t span = (int64_t)OLS_N1 * g.N2;
     const bool inner = ia0 >= 0 && ia0 + span <= g.Tn && has_b && ib0 >= 0 && ib0 + span <= g.Tn;
-    if (inner) {
+    if (PROBE == 3) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NBF; ++i)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) v[i][t] = make_float2((float)t, (float)col);
+    } else if (inner) {
+#pragma unroll
+        for (int i = 0; i < NBF; ++i)
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const int64_t n = (int64_t)(q + 8 * i + 16 * t) * g.N2 + n2;
+                const int64_t n = (int64_t)(q + QS * i + 16 * t) * g.N2 + n2;
                 v[i][t] = make_float2(xa[ia0 + n], xb[ib0 + n]);
             }
     } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NBF; ++i)
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const int64_t n = (int64_t)(q + 8 * i + 16 * t) * g.N2 + n2;
+                const int64_t n = (int64_t)(q + QS * i + 16 * t) * g.N2 + n2;
                 const int64_t ia = ia0 + n, ib = ib0 + n;
                 const float re = (ia >= 0 && ia < g.Tn) ? xa[ia] : 0.0f;
                 const float im = (has_b && ib >= 0 && ib < g.Tn) ? xb[ib] : 0.0f;
@@ -181,47 +193,74 @@ ols_col_fwd16_kernel(const float *__restrict__ x, cpx *__restrict__ T, const cpx
             }
     }
     __syncthreads();
-    col_stages16<false>(v, lds, tw256, col, q);
+    if (PROBE == 0) col_stages16<false, NBF>(v, lds, tw256, col, q);
     cpx *Tp = T + pair * ((int64_t)OLS_N1 * g.P2);
+    if (PROBE == 2) {
+        float acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NBF; ++i)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc += v[i][k].x + v[i][k].y;
+        if (acc == 1.2345e30f) Tp[n2] = make_float2(acc, acc);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < NBF; ++i)
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-            Tp[(int64_t)(q + 8 * i + 16 * k) * g.P2 + n2] = v[i][DFT16_AT(k)];
+            Tp[(int64_t)(q + QS * i + 16 * k) * g.P2 + n2] = v[i][DFT16_AT(k)];
 }
 
-__global__ void __launch_bounds__(256, 2)
+template <int NBF, int PROBE>
+__global__ void __launch_bounds__(512 / NBF, 2)
 ols_col_inv16_kernel(const cpx *__restrict__ T, float *__restrict__ y, const cpx *__restrict__ tw256g,
                      OlsGeom g, int64_t frame0)
 {
+    constexpr int QS = 16 / NBF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cpx *lds = (cpx *)smem;
     cpx *tw256 = lds + OLS_N1 * OLS_CB;
     const int tid = threadIdx.x, col = tid & 31, q = tid >> 5;
-    tw256[tid] = tw256g[tid];
+    if (tid < 256) tw256[tid] = tw256g[tid];
     const int ncb = g.N2 / OLS_CB;
     const int64_t pair = blockIdx.x / ncb;
     const int cb = blockIdx.x % ncb;
     const int n2 = cb * OLS_CB + col;
     const cpx *Tp = T + pair * ((int64_t)OLS_N1 * g.P2);
-    cpx v[2][16];
+    cpx v[NBF][16];
+    if (PROBE == 3) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NBF; ++i)
 #pragma unroll
-        for (int t = 0; t < 16; ++t) v[i][t] = Tp[(int64_t)(q + 8 * i + 16 * t) * g.P2 + n2];
+            for (int t = 0; t < 16; ++t) v[i][t] = make_float2((float)t, (float)col);
+    } else {
+#pragma unroll
+        for (int i = 0; i < NBF; ++i)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) v[i][t] = Tp[(int64_t)(q + QS * i + 16 * t) * g.P2 + n2];
+    }
     __syncthreads();
-    col_stages16<true>(v, lds, tw256, col, q);
+    if (PROBE == 0) col_stages16<true, NBF>(v, lds, tw256, col, q);
 
     const int64_t fa = frame0 + 2 * pair, fb = fa + 1;
     const int64_t ca = fa / g.F, oa0 = (fa % g.F) * g.S;
     const bool has_b = fb < g.nframes;
     const int64_t cb_ = has_b ? fb / g.F : 0, ob0 = has_b ? (fb % g.F) * g.S : 0;
     float *ya = y + ca * g.Tout, *yb = y + cb_ * g.Tout;
+    if (PROBE == 2) {
+        float acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NBF; ++i)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc += v[i][k].x + v[i][k].y;
+        if (acc == 1.2345e30f) ya[oa0] = acc;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < NBF; ++i)
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const int64_t n = (int64_t)(q + 8 * i + 16 * k) * g.N2 + n2;
+            const int64_t n = (int64_t)(q + QS * i + 16 * k) * g.N2 + n2;
             if (n < g.S) {                                   // valid part of the block
                 const cpx o = v[i][DFT16_AT(k)];
                 const int64_t oa = oa0 + n - g.out_shift, ob = ob0 + n - g.out_shift;
@@ -466,16 +505,22 @@ __device__ __forceinline__ void row_fft4096(cpx (&v)[16], cpx *lds, const cpx *t
     for (int k = 0; k < 16; ++k) v[k] = o[k];
 }
 
-// PF = persistent workgroups with the next row's loads in flight during the current row's FFTs
-// (the plain version leaves the memory system idle while a workgroup is in its six FFT stages)
-__global__ void __launch_bounds__(256, 3)
+// Row -> workgroup mapping (MAP):
+//   0  row = blockIdx (pair-major, as stored)
+//   1  XCD-aware: workgroup b runs on XCD b % 8 (observed dispatch order, MI355X_MICROARCH.md; only speed
+//      depends on it).  Each XCD owns the spectrum rows k1 = xcd (mod 8) and walks them k1-major, so the
+//      `np` frame pairs of the slab that share one spectrum row Hp[k1] are processed back to back by
+//      neighbouring workgroups of ONE XCD: the 32 KB row is fetched from memory once per slab and
+//      hit in that XCD's L2 by the other np - 1 rows (was: re-fetched for about every second pair,
+//      +25 % read traffic of this pass).
+// (Keeping Hp[k1] in registers and looping a workgroup over the pairs needs 168 VGPRs -> spills at 3 waves/SIMD.)
+template <int MAP>
+__global__ void __launch_bounds__(256, 4)
 ols_row4096_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *__restrict__ tw256g,
                    const cpx *__restrict__ t4log, const cpx *__restrict__ t4hig,
                    const cpx *__restrict__ tlo, const cpx *__restrict__ thi, const cpx *__restrict__ tu,
-                   int64_t Nmask, int P2, int64_t nrows)
+                   int64_t Nmask, int P2, int64_t npairs)
 {
-    // one workgroup per row (a persistent variant that prefetched the next row into registers ran at
-    // 2 waves/SIMD and was slower: DESIGN.md 6.1)
     constexpr int N2 = 4096;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cpx *lds = (cpx *)smem;                      // [4096 + 256]
@@ -487,35 +532,44 @@ ols_row4096_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *_
     typedef const float __attribute__((address_space(4))) *cfp;
     const cfp tuc = (cfp)(uintptr_t)tu;          // uniform per row: W_N^(256 k1 t)
     const unsigned umask = (unsigned)(Nmask >> 8);
-    const int64_t row = blockIdx.x;
-    if (row >= nrows) return;
+    int k1;
+    int64_t p;
+    if (MAP == 0) {
+        k1 = (int)(blockIdx.x % OLS_N1);
+        p = blockIdx.x / OLS_N1;
+    } else {
+        const unsigned xcd = blockIdx.x & 7u, m = blockIdx.x >> 3;
+        k1 = (int)((m / (unsigned)npairs) * 8u + xcd);
+        p = m % (unsigned)npairs;
+    }
     __syncthreads();                             // tables visible
-    const int k1 = (int)(row % OLS_N1);
-    cpx *base = T + row * P2;
     const cpx *hrow = Hp + (int64_t)k1 * N2;
     const unsigned ml = (unsigned)(k1 * j);
     const cpx wl = cmul(tlo[ml & 511], thi[ml >> 9]);
-    cpx v[16];
+    {
+        cpx *base = T + (p * OLS_N1 + k1) * P2;
+        cpx v[16];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const unsigned iu = 2u * ((unsigned)(k1 * t) & umask);
-        const cpx ut = make_float2(tuc[iu], tuc[iu + 1]);
-        v[t] = cmul(base[j + 256 * t], cmul(wl, ut));
-    }
-    row_fft4096<false>(v, lds, twB, twA, j);
-    __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < 16; ++t) {
+            const unsigned iu = 2u * ((unsigned)(k1 * t) & umask);
+            const cpx ut = make_float2(tuc[iu], tuc[iu + 1]);
+            v[t] = cmul(base[j + 256 * t], cmul(wl, ut));
+        }
+        row_fft4096<false>(v, lds, twB, twA, j);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) v[t] = cmul(v[t], hrow[j + 256 * t]);
-    __builtin_amdgcn_sched_barrier(0);
-    row_fft4096<true>(v, lds, twB, twA, j);
-    float wlx = wl.x, wly = wl.y;
-    asm volatile("" : "+v"(wlx), "+v"(wly));     // recompute, do not keep 16 twiddles live (see row1024)
-    const cpx wl2 = make_float2(wlx, wly);
+        for (int t = 0; t < 16; ++t) v[t] = cmul(v[t], hrow[j + 256 * t]);
+        __builtin_amdgcn_sched_barrier(0);
+        row_fft4096<true>(v, lds, twB, twA, j);
+        float wlx = wl.x, wly = wl.y;
+        asm volatile("" : "+v"(wlx), "+v"(wly));     // recompute, do not keep 16 twiddles live (see row1024)
+        const cpx wl2 = make_float2(wlx, wly);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const unsigned iu = 2u * ((unsigned)(k1 * t) & umask);
-        const cpx ut = make_float2(tuc[iu], tuc[iu + 1]);
-        base[j + 256 * t] = cmulc(v[t], cmul(wl2, ut));
+        for (int t = 0; t < 16; ++t) {
+            const unsigned iu = 2u * ((unsigned)(k1 * t) & umask);
+            const cpx ut = make_float2(tuc[iu], tuc[iu + 1]);
+            base[j + 256 * t] = cmulc(v[t], cmul(wl2, ut));
+        }
     }
 }
 
@@ -578,6 +632,7 @@ static NativePlan *get_native_plan(const float *kf, int64_t K, int64_t N, int64_
     std::vector<char> key((const char *)kf, (const char *)kf + K * sizeof(float));
     key.insert(key.end(), (const char *)&N, (const char *)&N + sizeof(N));
     key.insert(key.end(), (const char *)&lead, (const char *)&lead + sizeof(lead));
+    key.push_back((char)current_device());
     auto it = g_nplans.find(key);
     if (it != g_nplans.end()) return it->second;
     if (g_nplans.size() > 16) {
@@ -690,31 +745,71 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     g.nframes = C * g.F; g.N2 = plan->N2;
     g.P2 = g.N2 + (int)envi("TFX_OLS_PITCH_PAD", 0);
     const int64_t npairs = ceil_div(g.nframes, 2);
+    // Slab = the frame pairs one A / B / C launch triple covers.  Launches of a few thousand workgroups are
+    // dominated by their ramp and tail (64 MB slabs: 12.2 ms for the three passes of cfg 4 on one stream,
+    // 1 GB slabs: 9.8 ms), so slabs are as large as the workspace budget allows (1 GB per lane), but
+    // there are at least two per internal stream so that the passes of different slabs overlap.
+    constexpr int MAXL = 4;
+    int nlanes = (int)envi("TFX_OLS_STREAMS", 3);
+    if (nlanes < 1) nlanes = 1;
+    if (nlanes > MAXL) nlanes = MAXL;
+    const int64_t pair_bytes = (int64_t)OLS_N1 * g.P2 * (int64_t)sizeof(cpx);
     int64_t slab = envi("TFX_OLS_PAIRS_PER_SLAB", 0);
-    if (slab <= 0) slab = (envi("TFX_OLS_SLAB_MB", 64) << 20) / ((int64_t)OLS_N1 * g.P2 * (int64_t)sizeof(cpx));
-    if (slab < 1) slab = 1;
+    if (slab <= 0) {
+        const int64_t hi = std::max<int64_t>(1, (envi("TFX_OLS_SLAB_MB", 1024) << 20) / pair_bytes);
+        const int64_t lo = std::max<int64_t>(1, (envi("TFX_OLS_SLAB_MIN_MB", 64) << 20) / pair_bytes);
+        slab = ceil_div(npairs, 2 * nlanes);
+        if (slab < lo) slab = lo;
+        if (slab > hi) slab = hi;
+    }
     if (slab > npairs) slab = npairs;
     cpx *T = (cpx *)scratch("olsn_T", (size_t)slab * (size_t)OLS_N1 * (size_t)g.P2 * sizeof(cpx), stream);
     const size_t shm_col = (size_t)(OLS_N1 * OLS_CB + 256) * sizeof(cpx);
     const size_t shm_row = (size_t)(g.N2 * 5) * sizeof(cpx);
-    static bool attr = false;
+    const int probe = (int)envi("TFX_OLS_PROBE", 0);           // development only (tools/ols_knobs.py)
+    const int nbf = envi("TFX_OLS_COL_THREADS", 512) == 512 ? 1 : 2;
+    const int rowmap = (int)envi("TFX_OLS_ROWMAP", 1);
+    typedef void (*colf_t)(const float *, cpx *, const cpx *, OlsGeom, int64_t);
+    typedef void (*coli_t)(const cpx *, float *, const cpx *, OlsGeom, int64_t);
+    typedef void (*row_t)(cpx *, const cpx *, const cpx *, const cpx *, const cpx *, const cpx *, const cpx *, const cpx *,
+                          int64_t, int, int64_t);
+    static const colf_t colf_tab[2][4] = {
+        {ols_col_fwd16_kernel<2, 0>, ols_col_fwd16_kernel<2, 1>, ols_col_fwd16_kernel<2, 2>, ols_col_fwd16_kernel<2, 3>},
+        {ols_col_fwd16_kernel<1, 0>, ols_col_fwd16_kernel<1, 1>, ols_col_fwd16_kernel<1, 2>, ols_col_fwd16_kernel<1, 3>}};
+    static const coli_t coli_tab[2][4] = {
+        {ols_col_inv16_kernel<2, 0>, ols_col_inv16_kernel<2, 1>, ols_col_inv16_kernel<2, 2>, ols_col_inv16_kernel<2, 3>},
+        {ols_col_inv16_kernel<1, 0>, ols_col_inv16_kernel<1, 1>, ols_col_inv16_kernel<1, 2>, ols_col_inv16_kernel<1, 3>}};
+    static const row_t row_tab[2] = {ols_row4096_kernel<0>, ols_row4096_kernel<1>};
+    const colf_t colf = colf_tab[nbf == 1][probe & 3];
+    const coli_t coli = coli_tab[nbf == 1][probe & 3];
+    const row_t rowk = row_tab[rowmap == 0 ? 0 : 1];
+    static bool attr_tab[TFX_MAX_DEVICES] = {};
+    const int dev = current_device();
+    bool &attr = attr_tab[dev];
     if (!attr) {
-        TFX_HIP(hipFuncSetAttribute((const void *)ols_row4096_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
-        TFX_HIP(hipFuncSetAttribute((const void *)ols_col_fwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_col));
-        TFX_HIP(hipFuncSetAttribute((const void *)ols_col_inv16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_col));
+        for (int a = 0; a < 2; ++a)
+            TFX_HIP(hipFuncSetAttribute((const void *)row_tab[a], hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
+        for (int a = 0; a < 2; ++a)
+            for (int b = 0; b < 4; ++b) {
+                TFX_HIP(hipFuncSetAttribute((const void *)colf_tab[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_col));
+                TFX_HIP(hipFuncSetAttribute((const void *)coli_tab[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_col));
+            }
         attr = true;
     }
     const int ncb = g.N2 / OLS_CB;
     // Two internal streams, slabs alternate between them: while one slab drains the tail of a pass
     // (the last, partially filled round of workgroups) the other slab's pass fills the idle CUs.
     // Fork/join with events on the caller's stream; each lane has its own workspace.
-    constexpr int MAXL = 4;
-    int nlanes = (int)envi("TFX_OLS_STREAMS", 2);
-    if (nlanes < 1) nlanes = 1;
-    if (nlanes > MAXL) nlanes = MAXL;
     if (npairs <= slab) nlanes = 1;
-    static hipStream_t lane_stream[MAXL] = {nullptr, nullptr, nullptr, nullptr};
-    static hipEvent_t ev_fork = nullptr, ev_join[MAXL] = {nullptr, nullptr, nullptr, nullptr};
+    struct Lanes {                      // internal streams and fork/join events of one device
+        hipStream_t stream[MAXL] = {nullptr, nullptr, nullptr, nullptr};
+        hipEvent_t fork = nullptr, join[MAXL] = {nullptr, nullptr, nullptr, nullptr};
+    };
+    static Lanes lanes_tab[TFX_MAX_DEVICES];
+    Lanes &ln_ = lanes_tab[dev];
+    hipStream_t *lane_stream = ln_.stream;
+    hipEvent_t &ev_fork = ln_.fork;
+    hipEvent_t *ev_join = ln_.join;
     cpx *Tlane[MAXL] = {T, T, T, T};
     hipStream_t user_stream = stream;
     if (nlanes > 1) {
@@ -739,18 +834,19 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
         cpx *T = Tlane[ln];
         {
             ProfScope ps("ols_col_fwd16_kernel", stream);
-            hipLaunchKernelGGL(ols_col_fwd16_kernel, dim3((unsigned)(np * ncb)), dim3(256), shm_col, stream,
+            hipLaunchKernelGGL(colf, dim3((unsigned)(np * ncb)), dim3(512 / nbf), shm_col, stream,
                                x, T, plan->tw256, g, 2 * p0);
             TFX_HIP(hipGetLastError());
         }
         {
             const int64_t nrows = np * OLS_N1;
             ProfScope ps(g.N2 == 4096 ? "ols_row4096_kernel" : (g.N2 == 1024 && envi("TFX_OLS_ROW_R4", 0) == 0 ? "ols_row1024_kernel" : "ols_row_kernel"), stream);
-            if (g.N2 == 4096)
-                hipLaunchKernelGGL(ols_row4096_kernel, dim3((unsigned)nrows), dim3(256),
-                                   (size_t)(4096 + 256 + 512) * sizeof(cpx), stream,
+            if (g.N2 == 4096 && probe == 0) {
+                hipLaunchKernelGGL(rowk, dim3((unsigned)nrows), dim3(256), (size_t)(4096 + 256 + 512) * sizeof(cpx), stream,
                                    T, plan->Hp, plan->tw256, plan->t4lo, plan->t4hi, plan->tlo, plan->thi, plan->tu,
-                                   N - 1, g.P2, nrows);
+                                   N - 1, g.P2, np);
+            } else if (g.N2 == 4096) {
+            }
             else if (g.N2 == 1024 && envi("TFX_OLS_ROW_R4", 0) == 0)
                 hipLaunchKernelGGL(ols_row1024_kernel, dim3((unsigned)ceil_div(nrows, 4)), dim3(256),
                                    (size_t)(1024 + 4 * (1024 + 64)) * sizeof(cpx), stream,
@@ -765,7 +861,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
         }
         {
             ProfScope ps("ols_col_inv16_kernel", stream);
-            hipLaunchKernelGGL(ols_col_inv16_kernel, dim3((unsigned)(np * ncb)), dim3(256), shm_col, stream,
+            hipLaunchKernelGGL(coli, dim3((unsigned)(np * ncb)), dim3(512 / nbf), shm_col, stream,
                                T, y, plan->tw256, g, 2 * p0);
             TFX_HIP(hipGetLastError());
         }

@@ -643,6 +643,7 @@ static SosPlan *get_plan(const double *sos_host, int64_t K, hipStream_t stream, 
 {
     std::vector<double> key(sos_host, sos_host + NB * K * 6);
     key.push_back((double)NB);             // a bank of NB x K sections is not a cascade of NB*K
+    key.push_back((double)current_device());   // the tables live on one device
     std::lock_guard<std::mutex> lk(g_plan_mu);
     auto it = g_plans.find(key);
     if (it != g_plans.end()) return it->second;
@@ -701,17 +702,16 @@ static int env_int(const char *name, int dflt)
     return (e && *e) ? atoi(e) : dflt;
 }
 
-static int g_cus = 0;
+static int g_cus[TFX_MAX_DEVICES] = {0};
 static int device_cus()
 {
-    if (!g_cus) {
-        int dev = 0;
+    const int dev = current_device();
+    if (!g_cus[dev]) {
         hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess)
-            g_cus = pr.multiProcessorCount;
-        if (g_cus <= 0) g_cus = 256;
+        if (hipGetDeviceProperties(&pr, dev) == hipSuccess) g_cus[dev] = pr.multiProcessorCount;
+        if (g_cus[dev] <= 0) g_cus[dev] = 256;
     }
-    return g_cus;
+    return g_cus[dev];
 }
 
 // Time segmentation.  Streams are persistent (one wavefront walks its whole segment), so the
@@ -755,8 +755,11 @@ static void launch_one(SosParams p, int64_t plan_warm, hipStream_t stream)
     auto kern = sos_stream_kernel<TIn, TOut, TC, LC, VEC, TAPS, PF, MINW, SUMB>;
     if (shmem > 64 * 1024)
         TFX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    static int blocks_per_cu = 0;          // per template instance
-    static size_t blocks_shmem = 0;
+    static int blocks_per_cu_tab[TFX_MAX_DEVICES] = {0};     // per template instance and device
+    static size_t blocks_shmem_tab[TFX_MAX_DEVICES] = {0};
+    const int dev = current_device();
+    int &blocks_per_cu = blocks_per_cu_tab[dev];
+    size_t &blocks_shmem = blocks_shmem_tab[dev];
     if (!blocks_per_cu || blocks_shmem != shmem) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, 256, shmem) != hipSuccess || nb < 1) nb = 1;

@@ -1,74 +1,81 @@
-"""``FusedSOSCascade``: several IIR / Biquad modules as ONE ``sos_forward`` call.
+"""``FusedSOSCascade``: several IIR / Biquad modules behind ONE launch of the HIP cascade kernel.
 
-Reference: ``src/torchfx/filter/fused.py:19-132`` -- concatenate the members' SOS matrices
-into ``[sum K, 6]``, own state, same stateful forward as a single IIR.  On the HIP backend
-this is where chain fusion pays off: the K_total sections run inside one kernel launch that
-reads the signal once and writes it once.
+Public surface of the reference class (``src/torchfx/filter/fused.py:19-132``): constructor from
+filters, ``from_chain``, ``fs``, ``_sos`` (``[sum K, 6]`` float64), ``_state_x`` / ``_state_y``,
+``reset_state``, ``move_coeff``, stateful ``forward``.  Internally it is a thin module around the
+planner's two objects (``filter/_sos.py``): a ``CascadeTable`` gathered from the members and the
+``CascadeStream`` that carries the DF1 state -- the same objects ``Wave.plan()`` builds, so a planned
+pipeline and a hand-made ``FusedSOSCascade`` run the identical code.  On this backend fusion is
+where the chain pays off: all K_total sections run in one kernel that reads the signal once and
+writes it once.
 """
 from __future__ import annotations
 
 import torch
 from torch import Tensor, nn
 
-from torchfx_amd.filter.biquad import Biquad
-from torchfx_amd.filter.iir import IIR, _sos_cascade_forward
+from torchfx_amd.filter._sos import CascadeStream, CascadeTable
 
 
 class FusedSOSCascade(nn.Module):
-    def __init__(self, *filters: IIR | Biquad) -> None:
+    def __init__(self, *filters) -> None:
         super().__init__()
-        if not filters:
-            raise ValueError("FusedSOSCascade requires at least one IIR filter")
-        rows: list[Tensor] = []
-        fs_seen: int | None = None
-        for f in filters:
-            if not hasattr(f, "_sos"):
-                raise TypeError(f"Expected filter with SOS coefficients, got {type(f).__name__}")
-            if f._sos is None:
-                if f.fs is None:
-                    raise ValueError(
-                        f"Filter {type(f).__name__} has no sampling frequency set. Set fs before fusing.")
-                f.compute_coefficients()
-            rows.append(f._sos)
-            if f.fs is not None:
-                if fs_seen is None:
-                    fs_seen = f.fs
-                elif f.fs != fs_seen:
-                    raise ValueError(f"Cannot fuse filters with different sample rates: {fs_seen} vs {f.fs}")
-        self._sos: Tensor = torch.cat(rows, dim=0).to(dtype=torch.float64)
-        self._num_sections: int = self._sos.shape[0]
-        self.fs: int | None = fs_seen
-        self._sos_device_cache: Tensor | None = None
-        self._state_x: Tensor | None = None
-        self._state_y: Tensor | None = None
-        self._stateful: bool = False
+        self._stream = CascadeStream(CascadeTable.gather(filters))
+
+    @classmethod
+    def from_table(cls, table: CascadeTable) -> "FusedSOSCascade":
+        """Planner entry: wrap an already gathered (possibly gain-folded) table."""
+        self = cls.__new__(cls)
+        nn.Module.__init__(self)
+        self._stream = CascadeStream(table)
+        return self
 
     @classmethod
     def from_chain(cls, chain: nn.Module) -> "FusedSOSCascade":
-        """Fuse every IIR / Biquad child of an ``nn.Sequential`` (``fused.py:87-107``)."""
-        if isinstance(chain, nn.Sequential):
-            members = [m for m in chain if isinstance(m, (IIR, Biquad))]
-        elif isinstance(chain, (IIR, Biquad)):
-            members = [chain]
-        else:
+        """Every SOS filter found directly in an ``nn.Sequential`` (or a lone SOS filter)."""
+        from torchfx_amd.filter.biquad import Biquad
+        from torchfx_amd.filter.iir import IIR
+
+        if isinstance(chain, (IIR, Biquad)):
+            return cls(chain)
+        if not isinstance(chain, nn.Sequential):
             raise TypeError(f"Expected nn.Sequential or IIR/Biquad, got {type(chain).__name__}")
-        if not members:
+        picked = tuple(m for m in chain.children() if isinstance(m, (IIR, Biquad)))
+        if not picked:
             raise ValueError("No IIR/Biquad filters found in chain to fuse")
-        return cls(*members)
+        return cls(*picked)
+
+    # ---- the attributes callers and tests of the reference class read -------------------------
+    @property
+    def _sos(self) -> Tensor:
+        return self._stream.table.sos
+
+    @property
+    def fs(self) -> int | None:
+        return self._stream.table.fs
+
+    @property
+    def _state_x(self) -> Tensor | None:
+        return self._stream.sx
+
+    @_state_x.setter
+    def _state_x(self, value: Tensor | None) -> None:
+        self._stream.sx = value
+
+    @property
+    def _state_y(self) -> Tensor | None:
+        return self._stream.sy
+
+    @_state_y.setter
+    def _state_y(self, value: Tensor | None) -> None:
+        self._stream.sy = value
 
     def move_coeff(self, device) -> None:
-        """Kept for API parity (``fused.py:109-111``).  The canonical SOS stays on the host
-        (the HIP op reads it there); only the dtype is normalised."""
-        self._sos = self._sos.to(dtype=torch.float64)
+        """API parity only: the canonical table stays on the host, where the HIP op reads it."""
 
     def reset_state(self) -> None:
-        self._state_x = self._state_y = None
-        self._stateful = False
-        self._sos_device_cache = None
+        self._stream.reset()
 
     @torch.no_grad()
     def forward(self, x: Tensor) -> Tensor:
-        result, self._sos_device_cache, self._state_x, self._state_y = _sos_cascade_forward(
-            x, self._sos.cpu(), self._sos_device_cache, self._state_x, self._state_y)
-        self._stateful = True
-        return result
+        return self._stream(x)

@@ -40,6 +40,9 @@ def upload_interleaved(frames: np.ndarray, device, chunk_frames: int = 1 << 22) 
     staged = [torch.empty((chunk, C), dtype=tdt, device=dev) for _ in range(2)]
     compute = torch.cuda.current_stream(dev)
     copy = torch.cuda.Stream(dev)
+    # `staged` was allocated on the compute stream: the caching allocator may have handed out blocks that
+    # still have work queued there, so the copy stream must not touch them before that work has run
+    copy.wait_stream(compute)
     done_copy = [torch.cuda.Event() for _ in range(2)]
     done_use = [torch.cuda.Event() for _ in range(2)]
     for i, f0 in enumerate(range(0, F, chunk)):

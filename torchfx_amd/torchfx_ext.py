@@ -197,12 +197,28 @@ def delay_line_forward(x: Tensor, delay_samples: int, decay: float, mix: float) 
     return y
 
 
+_TAPS_HOST: dict = {}        # id(tensor) -> (weakref, version, dtype, host array)
+
+
 def _kernel_host(kernel, dtype: torch.dtype) -> np.ndarray:
+    """Flat host copy of the taps in the signal's dtype.  The C ABI takes the taps as a host array
+    (they key its device-side caches), so a filter that was moved to the GPU would otherwise pay a
+    blocking device-to-host copy on every forward: the copy is cached per tensor object and
+    invalidated by its version counter (in-place edits) or its death."""
     npdt = np.float32 if dtype == torch.float32 else np.float64
-    if isinstance(kernel, Tensor):
-        k = kernel.detach().to(device="cpu").reshape(-1).to(dtype).contiguous().numpy()
-    else:
-        k = np.ascontiguousarray(np.asarray(kernel).reshape(-1), dtype=npdt)
+    if not isinstance(kernel, Tensor):
+        return np.ascontiguousarray(np.asarray(kernel).reshape(-1), dtype=npdt)
+    ent = _TAPS_HOST.get(id(kernel))
+    if ent is not None and ent[0]() is kernel and ent[1] == kernel._version and ent[2] == dtype:
+        return ent[3]
+    k = kernel.detach().to(device="cpu").reshape(-1).to(dtype).contiguous().numpy()
+    if kernel.is_cuda:
+        import weakref
+
+        if len(_TAPS_HOST) > 64:
+            for key in [key for key, e in _TAPS_HOST.items() if e[0]() is None] or list(_TAPS_HOST)[:32]:
+                _TAPS_HOST.pop(key, None)
+        _TAPS_HOST[id(kernel)] = (weakref.ref(kernel), kernel._version, dtype, k)
     return k
 
 

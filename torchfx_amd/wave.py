@@ -9,12 +9,13 @@ steps), ``__len__`` / ``channels``.  ``from_file`` / ``save`` (:406-576) keep ``
 (imported lazily, as there) but, for a ROCm target, hand the decoder's interleaved buffer to
 ``torchfx_amd.io`` -- chunked pinned upload + device-side de-interleave.
 
-Beyond the reference, the planner can also merge consecutive ``FIR`` steps into one
-overlap-save pass (``fuse_fir=True`` or env ``TORCHFX_AMD_FUSE_FIR=1``): convolution is
-associative, so ``FIR(b1) | FIR(b2)`` == ``FIR(b1 * b2)``; the merged taps are computed on the
-host in float64.  Off by default so the default results follow the reference's staged
-float32 arithmetic; ``bench.py`` turns it on for the chain workload and checks it against the
-staged oracle.
+Beyond the reference, the planner merges consecutive FFT-mode ``FIR`` steps into one overlap-save
+pass (``fuse_fir``): convolution is associative, so ``FIR(b1) | FIR(b2)`` == ``FIR(b1 * b2)``; the
+merged taps are computed on the host in float64.  With ``fuse_spectral`` a fresh IIR cascade in front
+of such a run is folded in as well (``_spectral_plan``).  Both are on by default
+(``TORCHFX_AMD_FUSION=auto``) -- results stay within the FIR/FFT tolerance of the reference's staged
+output (``tests/golden/chain*.npz``, 1e-5) -- and off with ``TORCHFX_AMD_FUSION=reference``, which
+stages every step exactly as the reference does.
 
 ``fuse_gain=True`` (env ``TORCHFX_AMD_FUSE_GAIN=1``, also opt-in) folds a clamp-free ``Gain`` into
 the coefficients of the filter run it touches -- scaling is linear, so ``iir | gain | iir`` stays one
@@ -33,6 +34,23 @@ from torch import Tensor, nn
 
 from torchfx_amd.effect import FX
 from torchfx_amd.filter._base import AbstractFilter
+
+
+def _fusion_defaults() -> tuple[bool, bool, bool]:
+    """(fuse_fir, fuse_spectral, fuse_gain) of a new ``Wave``.
+
+    ``TORCHFX_AMD_FUSION`` = ``auto`` (default) turns on the two fusions whose result stays within the
+    FIR/FFT tolerance of the staged reference chain (1e-5 relative, checked against the reference's
+    staged output in ``tests/golden/chain*.npz`` and at full size): merging runs of FFT-mode FIRs and
+    folding a fresh IIR cascade into the FIR run that follows it.  ``reference`` stages every step
+    exactly as ``src/torchfx/wave.py:207-239`` does.  The per-feature variables
+    ``TORCHFX_AMD_FUSE_{FIR,SPECTRAL,GAIN}`` (0/1) override either way; gain folding stays opt-in."""
+    auto = os.environ.get("TORCHFX_AMD_FUSION", "auto").lower() != "reference"
+
+    def flag(name: str, dflt: bool) -> bool:
+        v = os.environ.get(name)
+        return dflt if v is None or v == "" else v == "1"
+    return flag("TORCHFX_AMD_FUSE_FIR", auto), flag("TORCHFX_AMD_FUSE_SPECTRAL", auto), flag("TORCHFX_AMD_FUSE_GAIN", False)
 
 
 def _merge_fir_run(run: list) -> nn.Module:
@@ -85,9 +103,7 @@ class Wave:
         self._pipeline: list[nn.Module] = []
         self._ys = ys if isinstance(ys, Tensor) else Tensor(ys)   # Tensor(ys): float32, as wave.py:137
         self.metadata = metadata or {}
-        self.fuse_fir = os.environ.get("TORCHFX_AMD_FUSE_FIR", "0") == "1"
-        self.fuse_spectral = os.environ.get("TORCHFX_AMD_FUSE_SPECTRAL", "0") == "1"
-        self.fuse_gain = os.environ.get("TORCHFX_AMD_FUSE_GAIN", "0") == "1"
+        self.fuse_fir, self.fuse_spectral, self.fuse_gain = _fusion_defaults()
         self.to(device)
 
     # ------------------------------------------------------------------ lazy data
@@ -105,6 +121,7 @@ class Wave:
         """The fused execution plan of the pending pipeline (``wave.py:216-233``)."""
         from torchfx_amd.filter.biquad import Biquad
         from torchfx_amd.filter.fir import FIR
+        from torchfx_amd.filter._sos import CascadeTable
         from torchfx_amd.filter.fused import FusedSOSCascade
         from torchfx_amd.filter.iir import IIR
 
@@ -115,13 +132,6 @@ class Wave:
         lead: list = []           # folded Gains seen while no run is open: they go into the next run
         kind = None
         fold = getattr(self, "fuse_gain", False)
-
-        def scaled_iir(m, g):
-            if g == 1.0:
-                return m
-            sos = m._sos.detach().clone().to(torch.float64)
-            sos[0, :3] *= g       # H(g x) = g H(x): scale the first section's numerator
-            return type("ScaledSOS", (), {"_sos": sos, "fs": m.fs})()
 
         def scaled_fir(m, g):
             if g == 1.0:
@@ -144,11 +154,12 @@ class Wave:
                 scales, nxt = [1.0] * len(filters), 0
                 for m in items:
                     if isinstance(m, Gain):
-                        scales[min(nxt, len(filters) - 1)] *= m.linear_gain() or 1.0
+                        g = m.linear_gain()
+                        scales[min(nxt, len(filters) - 1)] *= 1.0 if g is None else g
                     else:
                         nxt += 1
                 if kind == "iir":
-                    plan.append(FusedSOSCascade(*[scaled_iir(m, g) for m, g in zip(filters, scales)]))
+                    plan.append(FusedSOSCascade.from_table(CascadeTable.gather(filters, scales)))
                 else:
                     mem = [scaled_fir(m, g) for m, g in zip(filters, scales)]
                     plan.append(_merge_fir_run(mem) if len(mem) >= 2 else mem[0])
@@ -180,11 +191,15 @@ class Wave:
 
     @staticmethod
     def _spectral_plan(plan: list[nn.Module]) -> list[nn.Module]:
-        """Opt-in (``fuse_spectral``): an LTI run  IIR-cascade | FIR...  is ONE linear system, so a
-        freshly created (stateless) cascade that is followed by FFT-mode FIRs is folded into them as
-        its truncated impulse response -- the whole run becomes a single overlap-save pass and the
-        recursive kernel is not launched at all.  Arithmetic then is float32 FFT convolution instead
-        of float64 recursion (error ~1e-6 instead of 1 ulp), which is why this is not the default."""
+        """``fuse_spectral``: an LTI run  IIR-cascade | FIR...  is ONE linear system, so a freshly
+        created (stateless) cascade that is followed by an FFT-mode FIR is folded into it as its
+        impulse response, truncated where the cascade has forgotten its past to float64 round-off --
+        the whole run becomes a single overlap-save pass (8 B/sample less HBM traffic, the recursive
+        kernel is not launched).  The IIR part then runs in float32 FFT arithmetic like the FIR it
+        joins (error ~1e-6 of the output scale instead of 1 ulp).  Not applied when the cascade carries
+        state (a lone IIR step, a user-held ``FusedSOSCascade`` that has run), when its memory is
+        longer than the FIR it would join (the block efficiency of the overlap-save pass would
+        suffer) or when the FIR is in direct mode."""
         from torchfx_amd.filter.fir import FIR
         from torchfx_amd.filter.fused import FusedSOSCascade
 
@@ -195,8 +210,7 @@ class Wave:
             nxt = plan[i + 1] if i + 1 < len(plan) else None
             if (isinstance(m, FusedSOSCascade) and m._state_x is None and isinstance(nxt, FIR)
                     and nxt._conv_mode != "direct"):
-                members = [type("S", (), {"_sos": m._sos})()]
-                eq = _iir_as_fir(members)
+                eq = _iir_as_fir([m], max_taps=max(4096, int(nxt.kernel.numel())))
                 if eq is not None:
                     out.append(_merge_fir_run([eq, nxt]))
                     i += 2
@@ -283,9 +297,7 @@ class Wave:
             w = object.__new__(cls)
             w._ys = _io.upload_interleaved(data_np, device)
             w.fs, w._device, w.metadata, w._pipeline = fs, device, metadata, []
-            w.fuse_fir = os.environ.get("TORCHFX_AMD_FUSE_FIR", "0") == "1"
-            w.fuse_spectral = os.environ.get("TORCHFX_AMD_FUSE_SPECTRAL", "0") == "1"
-            w.fuse_gain = os.environ.get("TORCHFX_AMD_FUSE_GAIN", "0") == "1"
+            w.fuse_fir, w.fuse_spectral, w.fuse_gain = _fusion_defaults()
             return w
         return cls(torch.from_numpy(np.ascontiguousarray(data_np.T)), fs, metadata=metadata)
 
