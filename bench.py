@@ -4,22 +4,26 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is one pass of the hot path over one batch of synthetic audio already resident in
-HBM.  Default workload = the configuration BASELINE.json's metric is quoted on: the fused pipe
-chain  4-section SOS cascade | FIR-1024 | 65536-tap reverb IR  over 64 channels x 600 s @ 48 kHz
-float32 PER GPU (configs[4] is 512 channels over 8 GPUs = 64 per GPU).  Other workloads
-(`--workload sos|fir|fftconv` = configs[1..3]) are there for profiling; the parity tests cover
-them.  Channels shard across ranks with no data-path collective (weak scaling); `--gather`
-additionally times the final RCCL gather to rank 0 outside the timed region.
+A "step" is one pass of the hot path over one batch of synthetic audio already resident in HBM.
+Default workload = the configuration BASELINE.json's metric is quoted on: the fused pipe chain
+4-section SOS cascade | FIR-1024 | 65536-tap reverb IR  over 64 channels x 600 s @ 48 kHz float32 PER
+GPU (configs[4] is 512 channels over 8 GPUs = 64 per GPU), executed exactly as the product executes
+it: ``Wave(x) | f1 | f2 | fir | rev`` -> ``Wave.plan()`` (default fusion policy) -> the planned modules.
+At N = 1 the line also carries the driver-timed stage figures of configs[1..3] (``stages``) and two
+untimed variants of the chain (``variants``).  Channels shard across ranks with no data-path
+collective: ``--scaling weak`` (default) keeps 64 channels per GPU, ``--scaling strong
+--total-channels 512`` splits a fixed batch; ``--gather`` adds the final RCCL gather to rank 0 and
+reports ``value_with_gather`` beside ``value``.
 
-Prints ONE JSON line on rank 0.  `roofline` follows SURVEY.md 8(d): algorithmic bytes are
-8 B per sample-channel (4 B read + 4 B written) for every stage and for the fused chain.
-`cpu_baseline` times the oracle (our CPU restatement of the reference path, pinned by golden
-vectors) on a bounded sample of the same workload -- a reported baseline, never a target.
+Prints ONE JSON line on rank 0.  ``roofline`` follows SURVEY.md 8(d): algorithmic bytes are 8 B per
+sample-channel (4 B read + 4 B written) for every stage and for the fused chain.  ``cpu_baseline``
+times the oracle (our CPU restatement of the reference path, pinned by golden vectors) on a bounded
+sample of the same workload -- a reported baseline, never a target.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -34,6 +38,7 @@ sys.path.insert(0, ROOT)
 FS = 48000
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TF = 157.3
+TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
 
 
 def reverb_ir(K: int = 65536) -> np.ndarray:
@@ -55,46 +60,68 @@ def build_filters():
     return f1, f2, fir, rev
 
 
+def plan_chain(x: torch.Tensor, fuse_fir: bool | None = None, fuse_spectral: bool | None = None):
+    """The product's execution plan for  x | f1 | f2 | fir | rev  (None = the Wave's default policy)."""
+    from torchfx_amd import Wave
+
+    f1, f2, fir, rev = build_filters()
+    w = Wave(x, FS, device=x.device)
+    if fuse_fir is not None:
+        w.fuse_fir = fuse_fir
+    if fuse_spectral is not None:
+        w.fuse_spectral = fuse_spectral
+    plan = (w | f1 | f2 | fir | rev).plan()
+    names = []
+    for m in plan:
+        taps = getattr(m, "kernel", None)
+        names.append(f"{type(m).__name__}[{m._sos.shape[0]} sections]" if hasattr(m, "_sos") and taps is None
+                     else f"{type(m).__name__}[{taps.numel()} taps, {m._conv_mode}]")
+    return plan, " | ".join(names)
+
+
+def run_plan(plan, x: torch.Tensor) -> torch.Tensor:
+    y = x
+    for m in plan:
+        if hasattr(m, "reset_state") and hasattr(m, "_stream"):
+            m.reset_state()                     # every step is a fresh wave: no state carried between steps
+        y = m(y)
+    return y
+
+
+def _ols_taps(plan) -> int:
+    return max(int(m.kernel.numel()) for m in plan if hasattr(m, "kernel"))
+
+
 def make_step(workload: str, x: torch.Tensor):
-    """Returns (step_fn, description, n_stages_reference)."""
-    from torchfx_amd import filter as F
+    """Returns (step_fn, description, taps of the overlap-save pass or None)."""
     from torchfx_amd import torchfx_ext as E
-    from torchfx_amd.wave import _merge_fir_run
 
     f1, f2, fir, rev = build_filters()
     sos = torch.cat([f1._sos, f2._sos]).contiguous()
     if workload == "sos":
-        return (lambda: E.sos_forward(x, None, sos, None, None)[0]), "cfg2: fused 4-section SOS cascade", 1
+        return (lambda: E.sos_forward(x, None, sos, None, None)[0]), "cfg2: fused 4-section SOS cascade (LoButterworth-6 | ParametricEQ), float64 recursion", None
     if workload == "fir":
         k = fir.kernel.reshape(-1)
-        return (lambda: E.fir_direct_forward(x, k)), "cfg3: direct FIR, 1024 taps", 1
+        return (lambda: E.fir_direct_forward(x, k)), "cfg3: direct FIR, 1024 taps (exact-f32 MFMA Toeplitz)", None
     if workload == "fftconv":
         k = rev.kernel.reshape(-1)
-        return (lambda: E.fft_conv_forward(x, k, (k.numel() - 1, 0))), "cfg4: overlap-save FFT conv, 65536 taps", 1
+        return (lambda: E.fft_conv_forward(x, k, (k.numel() - 1, 0))), "cfg4: overlap-save FFT conv, 65536 taps", 65536
     if workload == "chain":
-        merged = _merge_fir_run([fir, rev])          # conv associativity: one 66559-tap overlap-save pass
-        k = merged.kernel.reshape(-1).to(torch.float32)
-        pad = (k.numel() - 1, 0)
-
-        def step():
-            y = E.sos_forward(x, None, sos, None, None)[0]
-            return E.fft_conv_forward(y, k, pad)
-        return step, "cfg5/GPU: fused chain 4xbiquad | FIR-1024 | FFT-conv-65536 (FIRs merged)", 3
-    if workload == "chain_spectral":
-        # opt-in planner mode (Wave.fuse_spectral): the stateless IIR cascade is folded into the
-        # FIR pass as its truncated impulse response -> ONE overlap-save pass for the whole chain
-        from torchfx_amd.wave import _iir_as_fir
-        eq = _iir_as_fir([f1, f2])
-        merged = _merge_fir_run([eq, fir, rev])
-        k = merged.kernel.reshape(-1).to(torch.float32)
-        pad = (k.numel() - 1, 0)
-        return (lambda: E.fft_conv_forward(x, k, pad)), f"chain as one spectral pass ({k.numel()} taps)", 3
+        plan, names = plan_chain(x)
+        return (lambda: run_plan(plan, x)), f"cfg5/GPU: 4xbiquad | FIR-1024 | FFT-conv-65536 via Wave.plan() (default fusion) = {names}", _ols_taps(plan)
+    if workload == "chain_iir_kernel":
+        plan, names = plan_chain(x, fuse_fir=True, fuse_spectral=False)
+        return (lambda: run_plan(plan, x)), f"chain with the IIR as its own float64 recursive pass = {names}", _ols_taps(plan)
+    if workload == "chain_reference_staging":
+        plan, names = plan_chain(x, fuse_fir=False, fuse_spectral=False)
+        return (lambda: run_plan(plan, x)), f"chain staged as the reference stages it (TORCHFX_AMD_FUSION=reference) = {names}", _ols_taps(plan)
     raise SystemExit(f"unknown workload {workload}")
 
 
 def cpu_baseline(workload: str, seconds: float, channels: int) -> dict:
-    """Oracle on the host, bounded sample of the same workload: all cores it can use (one per
-    channel, at most 32 -- `cores` is what actually ran) and, on a quarter of the sample, one thread."""
+    """Oracle on the host, bounded sample of the same workload.  The reference's CPU path is parallel over
+    channels only (OpenMP loop, iir_cpu.cpp:106), so the baseline runs one thread per channel -- `cores` is
+    what actually ran -- plus, on a quarter of the sample, one thread."""
     from oracle import oracle as O
 
     f1, f2, fir, rev = build_filters()
@@ -115,7 +142,7 @@ def cpu_baseline(workload: str, seconds: float, channels: int) -> dict:
             "chain": lambda: O.chain_forward(xx, sos, [kf, kr], threads=nthr),
         }[workload]
 
-    want = max(1, min(os.cpu_count() or 1, channels, 32))
+    want = max(1, min(os.cpu_count() or 1, channels))
     # explicit thread pinning: the OpenMP runtime is already up, environment variables are too late
     cores = min(want, O.set_threads(want))
     t0 = time.perf_counter()
@@ -173,16 +200,77 @@ def cpu_baseline(workload: str, seconds: float, channels: int) -> dict:
         return {"value": ref_iir["value"], "unit": "Msamples/s", "cores": cores, "kind": "reference",
                 "single_thread_value": ref_iir.get("single_thread_value"),
                 "port_value": round(channels * T / dt / 1e6, 3), "port_single_thread_value": single,
-                "scipy_value": scipy_val,
+                "scipy_value": scipy_val, "host_cores": os.cpu_count(),
                 "sample": f"{channels} ch x {seconds:g} s @ 48 kHz float32, the reference's own sos_forward_cpu "
                           f"(oracle/_ref/torchfx_ext.so, -O3 -ffast-math -fopenmp as its CMakeLists) incl. its float64 "
                           f"casts, {cores} OpenMP threads (one per channel), {ref_iir['seconds']:.2f} s; port_value = our C "
                           f"oracle, same sample and threads"}
     return {"value": round(channels * T / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "single_thread_value": single, "scipy_value": scipy_val, "reference_iir_stage": ref_iir,
+            "host_cores": os.cpu_count(),
             "sample": f"{channels} ch x {seconds:g} s @ 48 kHz float32, oracle (C float64 DF1 + numpy overlap-save, "
-                      f"reference framing N=int(5K)), {cores} threads (one per channel), {dt:.2f} s; "
-                      f"single_thread_value on {x1.shape[0]} ch, {dt1:.2f} s"}
+                      f"reference framing N=int(5K)), {cores} threads (one per channel: the reference's CPU path is "
+                      f"parallel over channels only), {dt:.2f} s; single_thread_value on {x1.shape[0]} ch, {dt1:.2f} s"}
+
+
+def source_digest() -> str:
+    """Identifies the kernels that were profiled: sha256 over the HIP sources (profiles/*_traffic.json
+    records the digest of the build its PMC numbers were taken from)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "torchfx_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def timed_region(step, steps: int, warmup: int, sync, lib):
+    out = None
+    for _ in range(warmup):
+        out = step()
+    sync()
+    lib.tfx_prof_enable(1)
+    lib.tfx_prof_collect()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = json.loads(lib.tfx_prof_collect().decode())
+    lib.tfx_prof_enable(0)
+    return elapsed, prof, out
+
+
+def batch_timed(step, sync, lib, batches: int, per_batch: int, warmup: int = 2):
+    """Secondary figures (stages, variants): `batches` groups of `per_batch` back-to-back steps, device
+    synchronised around every group; returns (median group time / per_batch in ms, all group values,
+    per-kernel ms per step from the library's HIP events, last output).  The median keeps a one-off
+    allocator stall (a fresh multi-GB hipMalloc inside torch.empty) out of a 5-step figure."""
+    out = None
+    for _ in range(warmup):
+        out = step()
+    sync()
+    lib.tfx_prof_enable(1)
+    lib.tfx_prof_collect()
+    groups = []
+    for _ in range(batches):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(per_batch):
+            out = step()
+        sync()
+        groups.append((time.perf_counter() - t0) / per_batch * 1e3)
+    prof = json.loads(lib.tfx_prof_collect().decode())
+    lib.tfx_prof_enable(0)
+    kern = {k: round(v["total_ms"] / (batches * per_batch), 4) for k, v in prof.items()}
+    return float(np.median(groups)), [round(g, 4) for g in groups], kern, out
+
+
+def kernel_table(prof: dict, steps: int) -> dict:
+    return {name: {"launches_per_step": round(v["calls"] / steps, 2),
+                   "avg_ms_per_launch": round(v["total_ms"] / v["calls"], 4),
+                   "ms_per_step": round(v["total_ms"] / steps, 4)} for name, v in prof.items()}
 
 
 def main() -> None:
@@ -190,13 +278,16 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="chain", choices=["chain", "sos", "fir", "fftconv"])  # chain_spectral: internal
-    ap.add_argument("--channels", type=int, default=64, help="channels PER GPU")
+    ap.add_argument("--workload", default="chain",
+                    choices=["chain", "sos", "fir", "fftconv", "chain_iir_kernel", "chain_reference_staging"])
+    ap.add_argument("--channels", type=int, default=64, help="channels PER GPU (weak scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--total-channels", type=int, default=512, help="fixed batch of --scaling strong (cfg 5)")
     ap.add_argument("--seconds", type=float, default=None, help="signal length (default: 600 chain/fftconv, 60 sos/fir)")
     ap.add_argument("--gather", action="store_true", help="also time the final RCCL gather to rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="only warm-up + timed steps (for rocprofv3 runs: no single-stream / variant passes)")
+                    help="only warm-up + timed steps (for rocprofv3 runs: no stage / variant / single-stream passes)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -223,13 +314,20 @@ def main() -> None:
     from torchfx_amd import _lib
     lib = _lib.load()                      # fails loudly if the HIP extension is missing
 
-    seconds = args.seconds if args.seconds is not None else (600.0 if args.workload in ("chain", "fftconv") else 60.0)
-    C, T = args.channels, int(seconds * FS)
+    chainlike = args.workload.startswith("chain") or args.workload == "fftconv"
+    seconds = args.seconds if args.seconds is not None else (600.0 if chainlike else 60.0)
+    if args.scaling == "strong":
+        if args.total_channels % world:
+            raise SystemExit(f"--total-channels {args.total_channels} does not divide over {world} ranks")
+        C = args.total_channels // world
+    else:
+        C = args.channels
+    T = int(seconds * FS)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.randn(C, T, device=dev, generator=gen, dtype=torch.float32)
     x.mul_(1.0 / float(x.abs().max()))     # max|x| <= 1 (benchmarks/conftest.py:70-82 of the reference)
 
-    step, desc, _ = make_step(args.workload, x)
+    step, desc, ols_taps = make_step(args.workload, x)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -237,65 +335,74 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        out = step()
-    sync()
-    lib.tfx_prof_enable(1)
-    lib.tfx_prof_collect()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    prof = json.loads(lib.tfx_prof_collect().decode())
-    lib.tfx_prof_enable(0)
+    elapsed, prof, out = timed_region(step, args.steps, args.warmup, sync, lib)
     if world > 1:
         t = torch.tensor([elapsed], device="cpu" if share else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-kernel durations without overlap: the overlap-save passes of consecutive slabs run on two
-    # internal streams in the timed region, which inflates each kernel's elapsed time; one extra,
-    # untimed pass on a single stream gives the clean per-kernel numbers
+    extras = rank == 0 and world == 1 and not args.no_extras
+    # per-kernel durations without overlap: the overlap-save passes of consecutive slabs run on internal
+    # streams in the timed region, which inflates each kernel's elapsed time; one extra, untimed pass on a
+    # single stream gives the clean per-kernel numbers
     prof_serial = None
-    if args.workload in ("chain", "fftconv") and not args.no_extras:
+    if extras and chainlike:
         old_env = os.environ.get("TFX_OLS_STREAMS")
         os.environ["TFX_OLS_STREAMS"] = "1"
         try:
-            out = step()
-            sync()
-            lib.tfx_prof_enable(1)
-            lib.tfx_prof_collect()
-            for _ in range(2):
-                out = step()
-            sync()
-            prof_serial = json.loads(lib.tfx_prof_collect().decode())
-            lib.tfx_prof_enable(0)
+            _, prof_serial, _ = timed_region(step, 2, 1, sync, lib)
         finally:
             if old_env is None:
                 os.environ.pop("TFX_OLS_STREAMS", None)
             else:
                 os.environ["TFX_OLS_STREAMS"] = old_env
-    variant = None
-    if args.workload == "chain" and rank == 0 and not args.no_extras:
-        try:                                   # secondary figure, outside the timed region
-            vstep, vdesc, _ = make_step("chain_spectral", x)
-            vout = vstep()
-            torch.cuda.synchronize(dev)
-            v0 = time.perf_counter()
-            for _ in range(3):
-                vout = vstep()
-            torch.cuda.synchronize(dev)
-            vms = (time.perf_counter() - v0) / 3 * 1e3
-            diff = float((vout[:, : 4 * FS] - out[:, : 4 * FS]).abs().max())
-            variant = {"what": vdesc + "; opt-in (Wave.fuse_spectral), float32 FFT arithmetic for the IIR too",
-                       "ms_per_step": round(vms, 4), "Msamples_per_s": round(C * T / vms / 1e3, 1),
-                       "frac_of_8TBps_at_8B_per_sample": round(8.0 * C * T / (vms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                       "max_abs_diff_vs_default_chain_first_4s": diff}
-            del vout
-        except Exception as e:
-            variant = {"error": repr(e)}
+
+    variants = None
+    if extras and args.workload == "chain":
+        # secondary figures, outside the timed region: the same chain with the IIR as its own float64
+        # recursive pass (round-1 default) and staged exactly like the reference
+        variants = {}
+        head = out[:, : 4 * FS].clone()
+        for vname in ("chain_iir_kernel", "chain_reference_staging"):
+            try:
+                vstep, vdesc, _ = make_step(vname, x)
+                vms, vgroups, _, vout = batch_timed(vstep, sync, lib, 3, 3)
+                variants[vname] = {"what": vdesc, "ms_per_step": round(vms, 4), "ms_per_step_groups_of_3": vgroups,
+                                   "Msamples_per_s": round(C * T / vms / 1e3, 1),
+                                   "frac_of_8TBps_at_8B_per_sample": round(8.0 * C * T / (vms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "max_abs_diff_vs_default_chain_first_4s": float((vout[:, : 4 * FS] - head).abs().max())}
+                del vout, vstep
+            except Exception as e:
+                variants[vname] = {"error": repr(e)}
+        del head
+
+    stages = None
+    if extras and args.workload == "chain":
+        # configs[1..3] of BASELINE.json, timed by this same driver-run process (wall clock, see batch_timed),
+        # kernel time from the library's HIP events beside it
+        stages = {}
+        for key, wl, sec, bound in (("cfg2", "sos", 60.0, "hbm"), ("cfg3", "fir", 60.0, "mfma"), ("cfg4", "fftconv", 600.0, "hbm")):
+            try:
+                xs = x if sec == seconds else x[:, : int(sec * FS)].contiguous()
+                sstep, sdesc, _ = make_step(wl, xs)
+                sms, sgroups, skern, sout = batch_timed(sstep, sync, lib, 5, 5)
+                n = xs.numel()
+                ent = {"workload": sdesc, "channels": C, "seconds": sec, "ms_per_step": round(sms, 4),
+                       "timing": "median of 5 groups of 5 back-to-back steps, wall clock, device synchronised around each group",
+                       "ms_per_step_groups": sgroups,
+                       "Msamples_per_s": round(n / sms / 1e3, 1), "bound": bound, "kernel_ms_per_step": skern}
+                if bound == "hbm":
+                    ent["achieved_GBps"] = round(8.0 * n / (sms * 1e-3) / 1e9, 1)
+                    ent["frac"] = round(ent["achieved_GBps"] / HBM_PEAK_GBS, 4)
+                else:
+                    ent["achieved_TFLOPs"] = round(2.0 * 1024 * n / (sms * 1e-3) / 1e12, 2)
+                    ent["frac"] = round(ent["achieved_TFLOPs"] / FP32_PEAK_TF, 4)
+                    ent["frac_of_hbm_roofline"] = round(8.0 * n / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                stages[key] = ent
+                del sout, sstep, xs
+            except Exception as e:
+                stages[key] = {"error": repr(e)}
+
     gather_ms = None
     if args.gather and world > 1:
         bufs = [torch.empty_like(out) for _ in range(world)] if rank == 0 else None
@@ -304,44 +411,41 @@ def main() -> None:
         dist.gather(out, bufs, dst=0)
         sync()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        if world > 1:
+            tg = torch.tensor([gather_ms], device="cpu" if share else dev, dtype=torch.float64)
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            gather_ms = float(tg.item())
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         samples = C * T
         value = world * samples / (elapsed / args.steps) / 1e6            # whole-job Msamples/s
-        kernels = {}
-        for name, v in prof.items():
-            calls_per_step = v["calls"] / args.steps
-            kernels[name] = {"launches_per_step": round(calls_per_step, 2),
-                             "avg_ms_per_launch": round(v["total_ms"] / v["calls"], 4),
-                             "ms_per_step": round(v["total_ms"] / args.steps, 4)}
+        kernels = kernel_table(prof, args.steps)
         # per-kernel HBM model: the bytes each launch group must move by design (not the 8 B/sample
-        # algorithmic figure) -> achieved GB/s of that kernel; PMC-measured traffic agrees within
-        # a few % (profiles/r01_traffic.json)
+        # algorithmic figure) -> achieved GB/s of that kernel; PMC-measured traffic agrees within a few %
+        line_ols = None
         try:
             from torchfx_amd import torchfx_ext as E
             model = {"sos_stream_kernel<f64>": 8.0 * samples, "sos_stream_kernel<f32>": 8.0 * samples}
-            if args.workload in ("chain", "fftconv"):
-                kk = 66559 if args.workload == "chain" else 65536
+            if ols_taps:
+                kk = ols_taps
                 info = E.ols_plan_info(kk, T, (kk - 1, 0))
                 frames = C * info["F"]
                 pairs = (frames + 1) // 2
                 n = info["N"]
-                for sfx in ("", "16"):
-                    model["ols_col_fwd%s_kernel" % sfx] = frames * n * 4.0 + pairs * n * 8.0
-                    model["ols_col_inv%s_kernel" % sfx] = pairs * n * 8.0 + 4.0 * samples
+                model["ols_col_fwd16_kernel"] = frames * n * 4.0 + pairs * n * 8.0
+                model["ols_col_inv16_kernel"] = pairs * n * 8.0 + 4.0 * samples
                 for nm in ("ols_row_kernel", "ols_row1024_kernel", "ols_row4096_kernel"):
                     model[nm] = pairs * n * 16.0
-                line_ols = {"fft_block": n, "hop": info["S"], "blocks_per_row": info["F"], "native_lds_fft": info["native"]}
-            else:
-                line_ols = None
+                line_ols = {"taps": kk, "fft_block": n, "hop": info["S"], "blocks_per_row": info["F"],
+                            "native_lds_fft": info["native"], "model_bytes_per_sample": round((20.0 * n / info["S"]) + 4.0, 2)}
             for name, k in kernels.items():
                 if name in model and k["ms_per_step"] > 0:
                     k["model_GB_per_step"] = round(model[name] / 1e9, 3)
                     k["GBps"] = round(model[name] / 1e9 / (k["ms_per_step"] * 1e-3), 1)
                     k["frac_of_8TBps"] = round(k["GBps"] / HBM_PEAK_GBS, 4)
         except Exception:
-            line_ols = None
+            pass
         kernels_serial = None
         if prof_serial:
             kernels_serial = {}
@@ -377,55 +481,69 @@ def main() -> None:
         roof["frac"] = round(ach / roof["peak"], 4)
         roof["step_achieved"] = round(step_ach, 2)
         roof["step_frac"] = round(step_ach / roof["peak"], 4)
-        # HBM bytes measured with rocprofv3 PMC passes of this same command (profiles/): counters
-        # cannot be read from inside the process, so the last profiled values are reported --
-        # `traffic` per launch of the dominant kernel (like `achieved`), `step_traffic` per step
+        # HBM bytes from rocprofv3 PMC passes of this same command (tools/profile_gpu.sh -> profiles/):
+        # counters cannot be read from inside the process, so the file written by the last profiling
+        # session is reported together with the digest of the HIP sources it was taken from
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if args.workload in tr and C == 64 and seconds == 600.0:
-                ent = tr[args.workload]
+            tr = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
+            ent = tr.get(args.workload)
+            if ent and C == 64 and seconds == ent.get("seconds", 600.0):
                 roof["step_traffic"] = ent["bytes_per_step"]
                 pk = ent.get("per_kernel_GB_per_launch", {}).get(dom)
                 if pk:
-                    roof["traffic"] = round((pk["read"] + pk["write"]) * 1e9)
-                roof["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                    lps = pk.get("launches_per_step")
+                    scale = (lps / kernels[dom]["launches_per_step"]) if lps else 1.0   # same bytes, other slab count
+                    roof["traffic"] = round((pk["read"] + pk["write"]) * 1e9 * scale)
+                roof["traffic_source"] = f"{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this command)"
+                roof["traffic_from_this_build"] = tr.get("source_digest") == source_digest()
         except Exception:
             pass
         roof["dominant_kernel"] = dom
         if dom:
             roof["dominant_kernel_avg_ms"] = kernels[dom]["avg_ms_per_launch"]
             roof["dominant_kernel_ms_per_step"] = kernels[dom]["ms_per_step"]
-        if "sos_stream_kernel<f64>" in kernels or "sos_stream_kernel<f32>" in kernels:
-            kn = "sos_stream_kernel<f64>" if "sos_stream_kernel<f64>" in kernels else "sos_stream_kernel<f32>"
-            a = alg_gb / (kernels[kn]["ms_per_step"] * 1e-3)
-            roof["iir_kernel"] = {"name": kn, "achieved": round(a, 1), "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4)}
+        for kn in ("sos_stream_kernel<f64>", "sos_stream_kernel<f32>"):
+            if kn in kernels:
+                a = alg_gb / (kernels[kn]["ms_per_step"] * 1e-3)
+                roof["iir_kernel"] = {"name": kn, "achieved": round(a, 1), "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4)}
+        dtype = {"chain": "f32 (overlap-save FFT arithmetic for the whole fused chain; f32 I/O)",
+                 "chain_iir_kernel": "f64 (IIR) + f32 (FFT); f32 I/O", "chain_reference_staging": "f64 (IIR) + f32 (FFT); f32 I/O",
+                 "sos": "f64; f32 I/O", "fir": "f32", "fftconv": "f32"}[args.workload]
+        if args.workload == "chain" and "sos_stream_kernel<f64>" in kernels:
+            dtype = "f64 (IIR) + f32 (FFT); f32 I/O"
         line = {
             # BASELINE.json's metric string; `value` is the whole-job aggregate, `per_gpu_value` the per-GPU rate
-            "metric": "Msamples/s/GPU (64-ch fused biquad\u2192FIR\u2192FFT-conv chain); % HBM roofline"
+            "metric": "Msamples/s/GPU (64-ch fused biquad→FIR→FFT-conv chain); % HBM roofline"
                       if args.workload == "chain" else f"Msamples/s ({args.workload})",
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": {"chain": "f64 (IIR) + f32 (FFT); f32 I/O", "sos": "f64; f32 I/O", "fir": "f32", "fftconv": "f32"}[args.workload],
+            "scaling": args.scaling, "vs_baseline": None, "dtype": dtype,
             "data": "synthetic", "per_gpu_value": round(value / world, 1),
-            "config": {"workload": desc, "channels_per_gpu": C, "seconds": seconds, "fs": FS,
+            "config": {"workload": desc, "channels_per_gpu": C, "total_channels": C * world, "seconds": seconds, "fs": FS,
                        "samples_per_gpu": samples, "parallelism": f"channel-shard x{world}, no data-path collective",
-                       "iir_precision": os.environ.get("TORCHFX_AMD_IIR_PRECISION", "f64")},
+                       "fusion_policy": os.environ.get("TORCHFX_AMD_FUSION", "auto"),
+                       "iir_precision": os.environ.get("TORCHFX_AMD_IIR_PRECISION", "f64"),
+                       "source_digest": source_digest()},
             "roofline": roof,
             "kernels": kernels, "gpu_ms_per_step_sum_of_kernels": round(gpu_ms, 4),
-            "kernels_note": "timed region: overlap-save passes of alternate slabs overlap on two internal streams, so "
+            "kernels_note": "timed region: overlap-save passes of different slabs overlap on internal streams, so "
                             "per-kernel times there include contention; kernels_single_stream = same kernels, one stream, untimed pass",
             "kernels_single_stream": kernels_serial,
         }
         if line_ols:
             line["config"]["overlap_save"] = line_ols
-        if variant:
-            line["variants"] = {"spectral_fusion": variant}
+        if stages:
+            line["stages"] = stages
+        if variants:
+            line["variants"] = variants
         if gather_ms is not None:
             line["gather_ms"] = round(gather_ms, 2)
+            line["value_with_gather"] = round(world * samples / (elapsed / args.steps + gather_ms * 1e-3) / 1e6, 1)
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only (contract)
             try:
-                sec, ch = {"chain": (600.0, 32), "sos": (600.0, 32), "fir": (120.0, 16), "fftconv": (600.0, 32)}[args.workload]
-                line["cpu_baseline"] = cpu_baseline(args.workload, sec, ch)     # ~10-20 s of CPU work
+                base_wl = "chain" if args.workload.startswith("chain") else args.workload
+                sec, ch = {"chain": (300.0, 64), "sos": (600.0, 64), "fir": (60.0, 32), "fftconv": (300.0, 64)}[base_wl]
+                line["cpu_baseline"] = cpu_baseline(base_wl, sec, ch)     # ~10-20 s of CPU work
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 line["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)

@@ -340,6 +340,26 @@ def main() -> None:
     check("chain.cfg5small", O.chain_forward(xc.numpy(), d["c_sos"], [d["c_fir"], d["c_ir"]]), yc, 2e-5)
     np.savez(os.path.join(OUT, "chain.npz"), **d)
 
+    # chain whose IIR run has a non-trivial gain (+12 dB shelf, +9 dB high-Q peak, 80 Hz high-pass) in front
+    # of two FFT-mode FIRs: the case the planner's spectral folding (IIR run -> taps of the FIR run) must
+    # reproduce; the reference stages it as cascade -> FIR -> FIR
+    xg = rnd((2, 100000), 31)          # long enough for the LDS-resident overlap-save path (one 65536 block + tail)
+    xg = (0.5 * xg + 0.5 * torch.sin(2 * np.pi * 500.0 / 48000.0 * torch.arange(100000, dtype=torch.float64))[None, :]
+          .to(torch.float32) * torch.tensor([[1.0], [-0.7]])).to(torch.float32)
+    g1 = F.HiShelving(3000, q=0.7, gain=4.0, fs=48000)
+    g2 = F.ParametricEQ(frequency=500, q=4.0, gain=9.0, fs=48000)
+    g3 = F.HiButterworth(80, order=2, fs=48000)
+    gf = F.FIR(firwin(257, 6000, fs=48000))
+    irg = (np.random.default_rng(2).standard_normal(2049) * np.exp(-np.arange(2049) / 300.0))
+    irg = 8.0 * irg / np.abs(irg).sum()
+    gr = F.FIR(irg)
+    yg = (Wave(xg, 48000) | g1 | g2 | g3 | gf | gr).ys.numpy()
+    dg = dict(x=xg.numpy(), y=yg, sos=np.vstack([sos_of(g1), sos_of(g2), sos_of(g3)]),
+              fir=gf.kernel.numpy().reshape(-1), ir=gr.kernel.numpy().reshape(-1))
+    check("chain.gain", O.chain_forward(xg.numpy(), dg["sos"], [dg["fir"], dg["ir"]]), yg, 2e-5)
+    assert float(np.abs(yg).max()) > 1.5, float(np.abs(yg).max())     # the fixture really has gain
+    np.savez(os.path.join(OUT, "chain_gain.npz"), **dg)
+
     # delay line (export kept for API compat)
     xd = rnd((2, 1000), 15)
     yd = _ops.delay_line_forward(xd, 100, 0.5, 0.3).numpy()

@@ -329,15 +329,42 @@ def test_cfg5_small_chain_golden_staged_and_fused(golden):
     irs = np.random.default_rng(1).standard_normal(4097) * np.exp(-np.arange(4097) / 500.0)
     irs = irs / np.abs(irs).sum()
 
-    def pipe(fuse):
+    def pipe(fuse, spectral=False):
         w = Wave(g["xc"], 48000, device=DEV)
-        w.fuse_fir = fuse
+        w.fuse_fir, w.fuse_spectral = fuse, spectral
         return (w | F.LoButterworth(2000, order=6) | F.ParametricEQ(frequency=1000, q=2.0, gain=3.0)
                 | F.FIR(firwin(1024, 5000, fs=48000)) | F.FIR(irs))
-    close(pipe(False).ys, g["yc"], TOL_CONV_F32, "staged chain")
+    ws = pipe(False)
+    assert [type(m).__name__ for m in ws.plan()] == ["FusedSOSCascade", "FIR", "FIR"]   # the reference's staging
+    close(ws.ys, g["yc"], TOL_CONV_F32, "staged chain")
     wf = pipe(True)
     assert len(wf.plan()) == 2          # one SOS cascade + one merged FIR
     close(wf.ys, g["yc"], TOL_CONV_F32, "fused chain (merged FIR)")
+    wd = (Wave(g["xc"], 48000, device=DEV) | F.LoButterworth(2000, order=6) | F.ParametricEQ(frequency=1000, q=2.0, gain=3.0)
+          | F.FIR(firwin(1024, 5000, fs=48000)) | F.FIR(irs))
+    assert (wd.fuse_fir, wd.fuse_spectral) == (True, True)      # default policy: the whole LTI run is one overlap-save pass
+    assert [type(m).__name__ for m in wd.plan()] == ["FIR"]
+    close(wd.ys, g["yc"], TOL_CONV_F32, "default plan (IIR folded into the merged FIR)")
+
+
+@pytest.mark.parametrize("policy", ["auto", "fir_only", "reference"])
+def test_chain_with_iir_gain_golden(golden, policy):
+    """tests/golden/chain_gain.npz (reference staged output; IIR run with +12 dB shelf, +9 dB Q=4 peak, 80 Hz
+    high-pass, then FIR-257 | FIR-2049) under the three plans: default (one overlap-save pass for the whole
+    chain), cascade kernel + merged FIR, and the reference's staging."""
+    from scipy.signal import firwin
+    from torchfx_amd import Wave
+    from torchfx_amd import filter as F
+    g = golden("chain_gain")
+    w = Wave(g["x"], 48000, device=DEV)
+    if policy != "auto":
+        w.fuse_spectral = False
+        w.fuse_fir = policy == "fir_only"
+    irg = np.random.default_rng(2).standard_normal(2049) * np.exp(-np.arange(2049) / 300.0)
+    w = (w | F.HiShelving(3000, q=0.7, gain=4.0) | F.ParametricEQ(frequency=500, q=4.0, gain=9.0)
+         | F.HiButterworth(80, order=2) | F.FIR(firwin(257, 6000, fs=48000)) | F.FIR(8.0 * irg / np.abs(irg).sum()))
+    assert len(w.plan()) == {"auto": 1, "fir_only": 2, "reference": 3}[policy]
+    close(w.ys, g["y"], TOL_CONV_F32, f"chain with IIR gain, plan {policy}")
 
 
 def test_module_shapes_dtype_and_state_rules(golden):

@@ -111,7 +111,9 @@ def test_wave_is_lazy_and_fuses_iir_runs(oracle_backend, golden):
     f1, f2 = F.HiButterworth(100, order=2), F.LoButterworth(8000, order=4)
     f3 = F.ParametricEQ(2000, 1.0, -3.0)
     fir = F.DesignableFIR(cutoff=6000, num_taps=127)
-    w = fx.Wave(g["x"], 48000) | f1 | f2 | fir | f3
+    w = fx.Wave(g["x"], 48000)
+    w.fuse_fir = w.fuse_spectral = False                                   # the reference's staging (wave.py:207-239)
+    w = w | f1 | f2 | fir | f3
     assert f1.fs == 48000 and fir.fs == 48000 and f1._sos is not None      # fs propagated, eager design
     assert oracle_backend.calls == []                                      # nothing computed yet
     plan = w.plan()
@@ -330,6 +332,27 @@ def test_spectral_fusion_matches_staged(oracle_backend, golden):
     integ._set_coefficients(1.0, 0.0, 0.0, -1.0, 0.0)
     w = w | integ | F.Notch(50, 2.0) | F.FIR([0.5, 0.5])
     assert [type(m).__name__ for m in w.plan()] == ["FusedSOSCascade", "FIR"]
+
+
+def _gain_chain(wave):
+    from scipy.signal import firwin
+    irg = np.random.default_rng(2).standard_normal(2049) * np.exp(-np.arange(2049) / 300.0)
+    return (wave | F.HiShelving(3000, q=0.7, gain=4.0) | F.ParametricEQ(frequency=500, q=4.0, gain=9.0)
+            | F.HiButterworth(80, order=2) | F.FIR(firwin(257, 6000, fs=48000)) | F.FIR(8.0 * irg / np.abs(irg).sum()))
+
+
+def test_default_plan_folds_a_cascade_with_gain_into_the_fir_run(oracle_backend, golden):
+    """Reference output of the staged chain (tests/golden/chain_gain.npz) vs the default plan, which is a
+    single FIR: the 3-filter IIR run as taps, convolved with both FIRs."""
+    g = golden("chain_gain")
+    w = _gain_chain(fx.Wave(g["x"], 48000))
+    plan = w.plan()
+    assert [type(m).__name__ for m in plan] == ["FIR"] and plan[0].kernel.numel() > 257 + 2049
+    oracle_backend.calls.clear()
+    close(w.ys, g["y"], 2e-5)
+    assert [c[0] for c in oracle_backend.calls] == ["fft_conv_forward"]
+    assert np.allclose(np.vstack([m._sos.numpy() for m in _gain_chain(fx.Wave(g["x"], 48000))._pipeline[:3]]), g["sos"],
+                       rtol=0, atol=0)          # the designers reproduce the reference's SOS bit for bit
 
 
 def test_pad_to_and_unfold_helpers():

@@ -127,3 +127,10 @@ def test_chain_and_parallel(golden):
 def test_delay(golden):
     g = golden("delay")
     close(O.delay_line(g["x"], 100, 0.5, 0.3), g["y"], 1e-7)
+
+
+def test_chain_with_iir_gain_staged_like_the_reference(golden):
+    """cascade with +12 dB shelf / +9 dB high-Q peak / 80 Hz high-pass -> FIR-257 -> FIR-2049, staged."""
+    g = golden("chain_gain")
+    close(O.chain_forward(g["x"], g["sos"], [g["fir"], g["ir"]]), g["y"], 2e-5)
+    assert float(np.abs(g["y"]).max()) > 1.5          # the fixture really has gain

@@ -186,20 +186,30 @@ class Wave:
         flush()
         plan.extend(lead)
         if getattr(self, "fuse_spectral", False):
-            plan = self._spectral_plan(plan)
+            plan = self._spectral_plan(plan, int(self._ys.shape[-1]) if self._ys.dim() else 0)
         return plan
 
     @staticmethod
-    def _spectral_plan(plan: list[nn.Module]) -> list[nn.Module]:
+    def _ols_bytes_per_sample(taps: int, length: int) -> float:
+        """HBM bytes per output sample of one overlap-save pass with `taps` taps on rows of `length`
+        samples (three passes over a complex workspace of two real frames: 20 N / S + 4; the rocFFT
+        path used for short rows moves ~95)."""
+        from torchfx_amd import torchfx_ext
+
+        info = torchfx_ext.ols_plan_info(taps, length, (taps - 1, 0))
+        return 20.0 * info["N"] / info["S"] + 4.0 if info["native"] else 95.0
+
+    @staticmethod
+    def _spectral_plan(plan: list[nn.Module], length: int = 0) -> list[nn.Module]:
         """``fuse_spectral``: an LTI run  IIR-cascade | FIR...  is ONE linear system, so a freshly
         created (stateless) cascade that is followed by an FFT-mode FIR is folded into it as its
         impulse response, truncated where the cascade has forgotten its past to float64 round-off --
         the whole run becomes a single overlap-save pass (8 B/sample less HBM traffic, the recursive
         kernel is not launched).  The IIR part then runs in float32 FFT arithmetic like the FIR it
         joins (error ~1e-6 of the output scale instead of 1 ulp).  Not applied when the cascade carries
-        state (a lone IIR step, a user-held ``FusedSOSCascade`` that has run), when its memory is
-        longer than the FIR it would join (the block efficiency of the overlap-save pass would
-        suffer) or when the FIR is in direct mode."""
+        state (a lone IIR step, a user-held ``FusedSOSCascade`` that has run), when the FIR is in direct
+        mode, or when the longer taps would cost the overlap-save pass more HBM bytes per sample (block
+        efficiency) than the 8 B/sample the recursive pass takes."""
         from torchfx_amd.filter.fir import FIR
         from torchfx_amd.filter.fused import FusedSOSCascade
 
@@ -210,11 +220,17 @@ class Wave:
             nxt = plan[i + 1] if i + 1 < len(plan) else None
             if (isinstance(m, FusedSOSCascade) and m._state_x is None and isinstance(nxt, FIR)
                     and nxt._conv_mode != "direct"):
-                eq = _iir_as_fir([m], max_taps=max(4096, int(nxt.kernel.numel())))
+                eq = _iir_as_fir([m])
                 if eq is not None:
-                    out.append(_merge_fir_run([eq, nxt]))
-                    i += 2
-                    continue
+                    k0, k1 = int(nxt.kernel.numel()), int(nxt.kernel.numel()) + int(eq.kernel.numel()) - 1
+                    try:
+                        pays = Wave._ols_bytes_per_sample(k1, length) <= Wave._ols_bytes_per_sample(k0, length) + 8.0
+                    except RuntimeError:          # signal shorter than the taps: nothing to gain
+                        pays = False
+                    if pays:
+                        out.append(_merge_fir_run([eq, nxt]))
+                        i += 2
+                        continue
             out.append(m)
             i += 1
         return out
