@@ -35,8 +35,10 @@ def _built_artifacts():
     """The shared libraries are git-ignored build products: build them if this checkout does not
     have them yet (hipcc cross-compiles gfx950 without a GPU; ~2 minutes once)."""
     import subprocess
+    import glob
     lib = os.path.join(ROOT, "torchfx_amd", "libtorchfx_hip.so")
-    if not os.path.exists(lib):
+    ext = glob.glob(os.path.join(ROOT, "torchfx_amd", "native", "torchfx_ext*.so"))
+    if not os.path.exists(lib) or not ext:
         subprocess.check_call(["make", "-s", "-j", "8", "-C", os.path.join(ROOT, "torchfx_amd", "csrc")])
     if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])

@@ -24,8 +24,9 @@ def test_product_never_touches_the_oracle_or_the_reference():
 
 
 def test_no_cpu_fallback_branches():
-    """torchfx_ext must not be able to compute on the host: no SciPy / torch.nn.functional /
-    torch.fft imports, and every op checks the device first."""
+    """torchfx_ext must not be able to compute on the host: no SciPy / torch.nn.functional / torch.fft
+    imports, every tensor op goes to the compiled extension, and every kernel of the extension checks
+    the device before anything else."""
     import ast
     src = open(os.path.join(ROOT, "torchfx_amd", "torchfx_ext.py")).read()
     tree = ast.parse(src)
@@ -36,7 +37,16 @@ def test_no_cpu_fallback_branches():
         elif isinstance(node, ast.ImportFrom):
             mods.add(node.module or "")
     assert not any(m.startswith(("scipy", "torch.nn", "torch.fft", "oracle")) for m in mods), mods
-    ops = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name.endswith("_forward") and n.name != "sum_forward"]
-    assert len(ops) >= 11                # every device op of the boundary; each must check the device first
+    ops = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name.endswith("_forward")]
+    assert len(ops) >= 13                # every device op of the boundary
     for fn in ops:
-        assert "require_device" in ast.unparse(fn), fn.name
+        assert "native.ops()" in ast.unparse(fn), fn.name
+    cpp = open(os.path.join(ROOT, "torchfx_amd", "csrc", "ext", "torchfx_ext.cpp")).read()
+    cuda_block = cpp[cpp.index("TORCH_LIBRARY_IMPL(torchfx_hip, CUDA, m)"):cpp.index("TORCH_LIBRARY_IMPL(torchfx_hip, Meta, m)")]
+    impls = re.findall(r'm\.impl\("(\w+)", (\w+)\)', cuda_block)
+    assert len(impls) >= 14
+    for name, fn in impls:
+        body = cpp[cpp.index(" " + fn + "("):]
+        body = body[:body.index("\n}\n")]
+        assert "need_device(" in body or "_impl(" in body or "deinterleave_into_op(" in body, (name, fn)
+    assert cpp.count("need_device(") >= 12

@@ -1,0 +1,485 @@
+// torchfx_ext -- the compiled boundary module of the HIP backend.
+//
+// The reference binds its native kernels through a pybind11 torch extension named `torchfx_ext`
+// (src/torchfx/_csrc/binding.cpp:83-96, imported as `from torchfx import torchfx_ext`).  This file is
+// that module for MI355X: the same three entry points with the same signatures on at::Tensor
+// (biquad_forward, sos_forward, delay_line_forward), launched on PyTorch's current HIP stream, plus a
+// TORCH_LIBRARY(torchfx_hip) registration of every op of the backend so that Python reaches the kernels
+// through the dispatcher (torch.ops.torchfx_hip.*) -- no ctypes on the tensor path.  It is a thin,
+// host-only translation unit (compiled with g++): tensors are checked, outputs allocated, and the
+// extern "C" ABI of libtorchfx_hip.so (include/torchfx_hip.h) is called -- the C ABI stays the one
+// boundary non-torch hosts and this module share.
+//
+// There is no CPU path: the ops are registered for the CUDA dispatch key only (= ROCm device tensors
+// in a ROCm build of PyTorch) and for Meta (shape inference); a CPU tensor gets an explicit error.
+#include <torch/extension.h>
+#include <torch/library.h>
+
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+
+#include <optional>
+#include <tuple>
+#include <vector>
+
+#include "../../../include/torchfx_hip.h"
+
+namespace {
+
+using at::Tensor;
+using OptTensor = std::optional<Tensor>;
+
+void check_rc(int rc, const char *what)
+{
+    TORCH_CHECK(rc == 0, what, ": ", tfx_last_error());
+}
+
+int dtype_code(const Tensor &t, const char *what)
+{
+    if (t.scalar_type() == at::kFloat) return TFX_F32;
+    if (t.scalar_type() == at::kDouble) return TFX_F64;
+    TORCH_CHECK(false, what, ": expected a float32 or float64 tensor, got ", t.scalar_type());
+}
+
+void need_device(const Tensor &t, const char *what)
+{
+    TORCH_CHECK(t.is_cuda(), "torchfx_amd: ", what, " must live on a ROCm device (got ", t.device(),
+                "); this backend has no CPU path -- move the tensor with .to('cuda').");
+}
+
+tfx_stream_t stream_of(const Tensor &t)
+{
+    return (tfx_stream_t)c10::hip::getCurrentHIPStream(t.get_device()).stream();
+}
+
+// small coefficient tensor -> contiguous host float64 (O(K) bytes; the C ABI takes coefficients on the host)
+Tensor host_f64(const Tensor &t, int64_t last, const char *what)
+{
+    Tensor h = t.detach().to(at::kCPU, at::kDouble).contiguous();
+    TORCH_CHECK(h.dim() >= 1 && h.size(-1) == last, what, ": expected last dimension ", last, ", got shape ", h.sizes());
+    return h;
+}
+
+const double *state_ptr(const OptTensor &s, at::IntArrayRef shape, const Tensor &x, const char *what, Tensor &keep)
+{
+    if (!s.has_value() || !s->defined()) return nullptr;
+    TORCH_CHECK(s->sizes() == shape, what, " must have shape ", shape, ", got ", s->sizes());
+    keep = s->to(x.device(), at::kDouble).contiguous();
+    return keep.data_ptr<double>();
+}
+
+int precision_or_default(int64_t precision)
+{
+    if (precision >= 0) return (int)precision;
+    const char *e = getenv("TORCHFX_AMD_IIR_PRECISION");
+    if (!e || !*e) return TFX_PREC_F64;
+    const std::string s(e);
+    if (s == "f64" || s == "float64") return TFX_PREC_F64;
+    if (s == "f32" || s == "float32") return TFX_PREC_F32;
+    if (s == "auto") return TFX_PREC_AUTO;
+    TORCH_CHECK(false, "TORCHFX_AMD_IIR_PRECISION=", s, ": expected f64, f32 or auto");
+}
+
+at::ScalarType out_type(const Tensor &x, const std::optional<at::ScalarType> &out_dtype)
+{
+    return out_dtype.has_value() ? *out_dtype : x.scalar_type();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SOS cascade (binding.cpp:52-66) and its filter-bank / sum forms
+// ---------------------------------------------------------------------------------------------------
+std::tuple<Tensor, Tensor, Tensor, Tensor> sos_impl(const Tensor &x_in, const Tensor &sos_cpu, const OptTensor &state_x,
+                                                    const OptTensor &state_y, std::optional<at::ScalarType> out_dtype,
+                                                    int64_t precision, bool sections)
+{
+    TORCH_CHECK(x_in.dim() == 2, "sos_forward: x must be [C, T], got ", x_in.sizes());
+    need_device(x_in, "x");
+    const Tensor x = x_in.contiguous();
+    const Tensor sos = host_f64(sos_cpu, 6, "sos_forward");
+    TORCH_CHECK(sos.dim() == 2, "sos_forward: sos must be [K, 6]");
+    const int64_t C = x.size(0), T = x.size(1), K = sos.size(0);
+    Tensor kx, ky;
+    const double *sx = state_ptr(state_x, {K, C, 2}, x, "state_x", kx);
+    const double *sy = state_ptr(state_y, {K, C, 2}, x, "state_y", ky);
+    const auto odt = out_type(x, out_dtype);
+    Tensor y = at::empty({C, T}, x.options().dtype(odt));
+    Tensor nsx = at::empty({K, C, 2}, x.options().dtype(at::kDouble));
+    Tensor nsy = at::empty({K, C, 2}, x.options().dtype(at::kDouble));
+    Tensor sec = sections ? at::empty({K, C, T}, x.options().dtype(odt)) : at::empty({0}, x.options().dtype(odt));
+    c10::hip::HIPGuard guard(x.get_device());
+    check_rc(tfx_sos_forward(x.data_ptr(), dtype_code(x, "sos_forward"), y.data_ptr(), dtype_code(y, "sos_forward"), C, T,
+                             sos.data_ptr<double>(), K, sx, sy, nsx.data_ptr<double>(), nsy.data_ptr<double>(),
+                             sections ? sec.data_ptr() : nullptr, precision_or_default(precision), stream_of(x)),
+             "sos_forward");
+    return {y, nsx, nsy, sec};
+}
+
+std::tuple<Tensor, Tensor, Tensor> sos_op(const Tensor &x, const Tensor &sos_cpu, const OptTensor &sx, const OptTensor &sy,
+                                          std::optional<at::ScalarType> out_dtype, int64_t precision)
+{
+    auto r = sos_impl(x, sos_cpu, sx, sy, out_dtype, precision, false);
+    return {std::get<0>(r), std::get<1>(r), std::get<2>(r)};
+}
+
+std::tuple<Tensor, Tensor, Tensor, Tensor> sos_sections_op(const Tensor &x, const Tensor &sos_cpu, const OptTensor &sx,
+                                                           const OptTensor &sy, std::optional<at::ScalarType> out_dtype,
+                                                           int64_t precision)
+{
+    return sos_impl(x, sos_cpu, sx, sy, out_dtype, precision, true);
+}
+
+std::tuple<Tensor, Tensor, Tensor> bank_impl(const Tensor &x_in, const Tensor &banks_cpu, const OptTensor &state_x,
+                                             const OptTensor &state_y, std::optional<at::ScalarType> out_dtype,
+                                             int64_t precision, bool sum)
+{
+    const char *what = sum ? "sos_bank_sum_forward" : "sos_bank_forward";
+    TORCH_CHECK(x_in.dim() == 2, what, ": x must be [C, T], got ", x_in.sizes());
+    need_device(x_in, "x");
+    const Tensor x = x_in.contiguous();
+    const Tensor banks = host_f64(banks_cpu, 6, what);
+    TORCH_CHECK(banks.dim() == 3, what, ": sos_banks must be [NB, K, 6]");
+    const int64_t C = x.size(0), T = x.size(1), NB = banks.size(0), K = banks.size(1);
+    Tensor kx, ky;
+    const double *sx = state_ptr(state_x, {K, NB * C, 2}, x, "state_x", kx);
+    const double *sy = state_ptr(state_y, {K, NB * C, 2}, x, "state_y", ky);
+    const auto odt = sum ? x.scalar_type() : out_type(x, out_dtype);
+    Tensor y = sum ? at::empty({C, T}, x.options()) : at::empty({NB, C, T}, x.options().dtype(odt));
+    Tensor nsx = at::empty({K, NB * C, 2}, x.options().dtype(at::kDouble));
+    Tensor nsy = at::empty({K, NB * C, 2}, x.options().dtype(at::kDouble));
+    c10::hip::HIPGuard guard(x.get_device());
+    auto fn = sum ? tfx_sos_bank_sum_forward : tfx_sos_bank_forward;
+    check_rc(fn(x.data_ptr(), dtype_code(x, what), y.data_ptr(), dtype_code(y, what), C, T, banks.data_ptr<double>(), NB, K,
+                sx, sy, nsx.data_ptr<double>(), nsy.data_ptr<double>(), precision_or_default(precision), stream_of(x)),
+             what);
+    return {y, nsx, nsy};
+}
+
+std::tuple<Tensor, Tensor, Tensor> bank_op(const Tensor &x, const Tensor &banks, const OptTensor &sx, const OptTensor &sy,
+                                           std::optional<at::ScalarType> out_dtype, int64_t precision)
+{
+    return bank_impl(x, banks, sx, sy, out_dtype, precision, false);
+}
+std::tuple<Tensor, Tensor, Tensor> bank_sum_op(const Tensor &x, const Tensor &banks, const OptTensor &sx, const OptTensor &sy,
+                                               int64_t precision)
+{
+    return bank_impl(x, banks, sx, sy, std::nullopt, precision, true);
+}
+
+// single biquad (binding.cpp:30-50): b [3] tensor, a1 / a2 scalars, states [C, 2]
+std::tuple<Tensor, Tensor, Tensor> biquad_op(const Tensor &x_in, const Tensor &b, double a1, double a2, const OptTensor &state_x,
+                                             const OptTensor &state_y, std::optional<at::ScalarType> out_dtype, int64_t precision)
+{
+    TORCH_CHECK(x_in.dim() == 2, "biquad_forward: x must be [C, T], got ", x_in.sizes());
+    need_device(x_in, "x");
+    const Tensor x = x_in.contiguous();
+    const Tensor bh = host_f64(b.reshape({-1}), 3, "biquad_forward");
+    const int64_t C = x.size(0), T = x.size(1);
+    Tensor kx, ky;
+    const double *sx = state_ptr(state_x, {C, 2}, x, "state_x", kx);
+    const double *sy = state_ptr(state_y, {C, 2}, x, "state_y", ky);
+    Tensor y = at::empty({C, T}, x.options().dtype(out_type(x, out_dtype)));
+    Tensor nsx = at::empty({C, 2}, x.options().dtype(at::kDouble));
+    Tensor nsy = at::empty({C, 2}, x.options().dtype(at::kDouble));
+    c10::hip::HIPGuard guard(x.get_device());
+    check_rc(tfx_biquad_forward(x.data_ptr(), dtype_code(x, "biquad_forward"), y.data_ptr(), dtype_code(y, "biquad_forward"), C, T,
+                                bh.data_ptr<double>(), a1, a2, sx, sy, nsx.data_ptr<double>(), nsy.data_ptr<double>(),
+                                precision_or_default(precision), stream_of(x)),
+             "biquad_forward");
+    return {y, nsx, nsy};
+}
+
+// delay line (binding.cpp:68-81 / delay_cpu.cpp:43-85): the input itself when the signal is not longer than the delay
+Tensor delay_line_op(const Tensor &x, int64_t delay_samples, double decay, double mix)
+{
+    need_device(x, "x");
+    const int64_t T = x.dim() ? x.size(-1) : 1;
+    if (T <= delay_samples) return x;
+    const Tensor xc = x.contiguous();
+    const int64_t rows = xc.numel() / T;
+    Tensor y = at::empty_like(xc);
+    c10::hip::HIPGuard guard(x.get_device());
+    check_rc(tfx_delay_line_forward(xc.data_ptr(), y.data_ptr(), dtype_code(xc, "delay_line_forward"), rows, T, delay_samples,
+                                    decay, mix, stream_of(x)),
+             "delay_line_forward");
+    return y;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// FIR (fir.py:556-568) and overlap-save FFT convolution (_fftconv.py:70-141)
+// ---------------------------------------------------------------------------------------------------
+Tensor taps_host(const Tensor &kernel, const Tensor &x)
+{
+    return kernel.detach().reshape({-1}).to(at::kCPU, x.scalar_type()).contiguous();
+}
+
+Tensor fir_direct_op(const Tensor &x_in, const Tensor &kernel)
+{
+    TORCH_CHECK(x_in.dim() == 2, "fir_direct_forward: x must be [C, T], got ", x_in.sizes());
+    need_device(x_in, "x");
+    const Tensor x = x_in.contiguous();
+    const Tensor k = taps_host(kernel, x);
+    Tensor y = at::empty_like(x);
+    c10::hip::HIPGuard guard(x.get_device());
+    check_rc(tfx_fir_direct_forward(x.data_ptr(), y.data_ptr(), dtype_code(x, "fir_direct_forward"), x.size(0), x.size(1),
+                                    k.data_ptr(), k.numel(), stream_of(x)),
+             "fir_direct_forward");
+    return y;
+}
+
+Tensor fft_conv_op(const Tensor &x_in, const Tensor &kernel, int64_t pad_left, int64_t pad_right)
+{
+    TORCH_CHECK(x_in.dim() == 2, "fft_conv_forward: x must be [C, T], got ", x_in.sizes());
+    need_device(x_in, "x");
+    const Tensor x = x_in.contiguous();
+    const Tensor k = taps_host(kernel, x);
+    const int64_t C = x.size(0), T = x.size(1), K = k.numel();
+    const int64_t tout = T + pad_left + pad_right - K + 1;
+    Tensor y = at::empty({C, tout > 0 ? tout : 0}, x.options());
+    c10::hip::HIPGuard guard(x.get_device());
+    check_rc(tfx_fft_conv_forward(x.data_ptr(), y.data_ptr(), dtype_code(x, "fft_conv_forward"), C, T, k.data_ptr(), K, pad_left,
+                                  pad_right, stream_of(x)),
+             "fft_conv_forward");
+    return y;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// `+` of branch outputs, Gain / Normalize passes, layout kernels
+// ---------------------------------------------------------------------------------------------------
+Tensor sum_op(at::TensorList tensors)
+{
+    TORCH_CHECK(!tensors.empty(), "sum_forward: need at least one tensor");
+    std::vector<Tensor> ts;
+    for (const Tensor &t : tensors) {
+        need_device(t, "branch output");
+        TORCH_CHECK(t.sizes() == tensors[0].sizes() && t.scalar_type() == tensors[0].scalar_type(),
+                    "sum_forward: branch outputs differ in shape or dtype");
+        ts.push_back(t.contiguous());
+    }
+    Tensor out = at::empty_like(ts[0]);
+    c10::hip::HIPGuard guard(out.get_device());
+    for (size_t i = 0; i < ts.size(); i += 15) {            // the kernel takes up to 16 inputs per launch
+        std::vector<const void *> grp;
+        if (i > 0) grp.push_back(out.data_ptr());
+        for (size_t j = i; j < ts.size() && j < i + 15; ++j) grp.push_back(ts[j].data_ptr());
+        check_rc(tfx_sum_forward(grp.data(), (int)grp.size(), out.data_ptr(), dtype_code(out, "sum_forward"), out.numel(),
+                                 stream_of(out)),
+                 "sum_forward");
+    }
+    return out;
+}
+
+Tensor gain_op(const Tensor &x, double gain, bool clamp)
+{
+    need_device(x, "x");
+    const Tensor xc = x.contiguous();
+    Tensor y = at::empty_like(xc);
+    c10::hip::HIPGuard guard(x.get_device());
+    check_rc(tfx_gain_forward(xc.data_ptr(), y.data_ptr(), dtype_code(xc, "gain_forward"), xc.numel(), gain, clamp ? 1 : 0,
+                              stream_of(x)),
+             "gain_forward");
+    return y;
+}
+
+Tensor stat_op(const Tensor &x, int64_t mode, bool per_row)
+{
+    need_device(x, "x");
+    const Tensor xc = x.contiguous();
+    const int64_t T = xc.dim() ? xc.size(-1) : 1, rows = T ? xc.numel() / T : 0;
+    Tensor out = at::empty({per_row ? rows : 1}, x.options().dtype(at::kDouble));
+    c10::hip::HIPGuard guard(x.get_device());
+    check_rc(tfx_stat_forward(xc.data_ptr(), dtype_code(xc, "stat_forward"), rows, T, (int)mode, per_row ? 1 : 0,
+                              out.data_ptr<double>(), stream_of(x)),
+             "stat_forward");
+    return out;
+}
+
+Tensor normalize_op(const Tensor &x, double peak, int64_t mode, bool per_row)
+{
+    need_device(x, "x");
+    const Tensor xc = x.contiguous();
+    const int64_t T = xc.dim() ? xc.size(-1) : 1, rows = T ? xc.numel() / T : 0;
+    Tensor y = at::empty_like(xc);
+    c10::hip::HIPGuard guard(x.get_device());
+    check_rc(tfx_normalize_forward(xc.data_ptr(), y.data_ptr(), dtype_code(xc, "normalize_forward"), rows, T, (int)mode,
+                                   per_row ? 1 : 0, peak, stream_of(x)),
+             "normalize_forward");
+    return y;
+}
+
+void deinterleave_into_op(const Tensor &frames, Tensor out, int64_t frame_base, double scale)
+{
+    need_device(frames, "frames");
+    TORCH_CHECK(frames.dim() == 2 && (frames.scalar_type() == at::kFloat || frames.scalar_type() == at::kShort),
+                "deinterleave_forward: expected [F, C] float32 or int16, got ", frames.sizes(), " ", frames.scalar_type());
+    const Tensor fr = frames.contiguous();
+    const int64_t F = fr.size(0), C = fr.size(1);
+    TORCH_CHECK(out.dim() == 2 && out.size(0) == C && out.scalar_type() == at::kFloat && out.is_contiguous() &&
+                    out.device() == fr.device(),
+                "deinterleave_forward: out must be a contiguous float32 [C, F_total] tensor on the same device");
+    c10::hip::HIPGuard guard(fr.get_device());
+    check_rc(tfx_deinterleave_forward(fr.data_ptr(), fr.scalar_type() == at::kFloat ? 0 : 1, out.data_ptr(), F, C, out.size(1),
+                                      frame_base, scale, stream_of(fr)),
+             "deinterleave_forward");
+}
+
+Tensor deinterleave_op(const Tensor &frames, double scale)
+{
+    TORCH_CHECK(frames.dim() == 2, "deinterleave_forward: expected [F, C], got ", frames.sizes());
+    Tensor out = at::empty({frames.size(1), frames.size(0)}, frames.options().dtype(at::kFloat));
+    deinterleave_into_op(frames, out, 0, scale);
+    return out;
+}
+
+Tensor interleave_op(const Tensor &x, int64_t frame_base, int64_t frames)
+{
+    need_device(x, "x");
+    TORCH_CHECK(x.dim() == 2 && x.scalar_type() == at::kFloat, "interleave_forward: expected float32 [C, F], got ", x.sizes(), " ",
+                x.scalar_type());
+    const Tensor xc = x.contiguous();
+    const int64_t C = xc.size(0), Ft = xc.size(1);
+    const int64_t F = frames < 0 ? Ft - frame_base : frames;
+    Tensor out = at::empty({F > 0 ? F : 0, C}, x.options());
+    c10::hip::HIPGuard guard(x.get_device());
+    check_rc(tfx_interleave_forward(xc.data_ptr(), out.data_ptr(), F, C, Ft, frame_base, stream_of(x)), "interleave_forward");
+    return out;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Meta kernels (shape / dtype inference: torch.compile, fake tensors)
+// ---------------------------------------------------------------------------------------------------
+std::tuple<Tensor, Tensor, Tensor> sos_meta(const Tensor &x, const Tensor &sos_cpu, const OptTensor &, const OptTensor &,
+                                            std::optional<at::ScalarType> out_dtype, int64_t)
+{
+    const int64_t K = sos_cpu.size(0), C = x.size(0);
+    Tensor st = at::empty({K, C, 2}, x.options().dtype(at::kDouble));
+    return {at::empty(x.sizes(), x.options().dtype(out_type(x, out_dtype))), st, at::empty_like(st)};
+}
+std::tuple<Tensor, Tensor, Tensor, Tensor> sos_sections_meta(const Tensor &x, const Tensor &sos_cpu, const OptTensor &a,
+                                                             const OptTensor &b, std::optional<at::ScalarType> out_dtype, int64_t p)
+{
+    auto r = sos_meta(x, sos_cpu, a, b, out_dtype, p);
+    return {std::get<0>(r), std::get<1>(r), std::get<2>(r),
+            at::empty({sos_cpu.size(0), x.size(0), x.size(1)}, x.options().dtype(out_type(x, out_dtype)))};
+}
+std::tuple<Tensor, Tensor, Tensor> bank_meta(const Tensor &x, const Tensor &banks, const OptTensor &, const OptTensor &,
+                                             std::optional<at::ScalarType> out_dtype, int64_t)
+{
+    const int64_t NB = banks.size(0), K = banks.size(1), C = x.size(0);
+    Tensor st = at::empty({K, NB * C, 2}, x.options().dtype(at::kDouble));
+    return {at::empty({NB, C, x.size(1)}, x.options().dtype(out_type(x, out_dtype))), st, at::empty_like(st)};
+}
+std::tuple<Tensor, Tensor, Tensor> bank_sum_meta(const Tensor &x, const Tensor &banks, const OptTensor &, const OptTensor &, int64_t)
+{
+    const int64_t NB = banks.size(0), K = banks.size(1), C = x.size(0);
+    Tensor st = at::empty({K, NB * C, 2}, x.options().dtype(at::kDouble));
+    return {at::empty_like(x), st, at::empty_like(st)};
+}
+std::tuple<Tensor, Tensor, Tensor> biquad_meta(const Tensor &x, const Tensor &, double, double, const OptTensor &, const OptTensor &,
+                                               std::optional<at::ScalarType> out_dtype, int64_t)
+{
+    Tensor st = at::empty({x.size(0), 2}, x.options().dtype(at::kDouble));
+    return {at::empty(x.sizes(), x.options().dtype(out_type(x, out_dtype))), st, at::empty_like(st)};
+}
+Tensor fft_conv_meta(const Tensor &x, const Tensor &kernel, int64_t pad_left, int64_t pad_right)
+{
+    const int64_t tout = x.size(1) + pad_left + pad_right - kernel.numel() + 1;
+    return at::empty({x.size(0), tout > 0 ? tout : 0}, x.options());
+}
+
+// CPU tensors: an explicit error instead of the dispatcher's "no kernel for backend CPU"
+template <typename R, typename... A> R no_cpu(A...)
+{
+    TORCH_CHECK(false, "torchfx_amd: tensors must live on a ROCm device; this backend has no CPU path -- move them with .to('cuda').");
+}
+
+}  // namespace
+
+TORCH_LIBRARY(torchfx_hip, m)
+{
+    m.def("sos_forward(Tensor x, Tensor sos_cpu, Tensor? state_x=None, Tensor? state_y=None, *, ScalarType? out_dtype=None, "
+          "int precision=-1) -> (Tensor, Tensor, Tensor)");
+    m.def("sos_forward_sections(Tensor x, Tensor sos_cpu, Tensor? state_x=None, Tensor? state_y=None, *, ScalarType? out_dtype=None, "
+          "int precision=-1) -> (Tensor, Tensor, Tensor, Tensor)");
+    m.def("sos_bank_forward(Tensor x, Tensor sos_banks_cpu, Tensor? state_x=None, Tensor? state_y=None, *, ScalarType? out_dtype=None, "
+          "int precision=-1) -> (Tensor, Tensor, Tensor)");
+    m.def("sos_bank_sum_forward(Tensor x, Tensor sos_banks_cpu, Tensor? state_x=None, Tensor? state_y=None, *, int precision=-1) "
+          "-> (Tensor, Tensor, Tensor)");
+    m.def("biquad_forward(Tensor x, Tensor b, float a1, float a2, Tensor? state_x=None, Tensor? state_y=None, *, "
+          "ScalarType? out_dtype=None, int precision=-1) -> (Tensor, Tensor, Tensor)");
+    m.def("delay_line_forward(Tensor(a) x, int delay_samples, float decay, float mix) -> Tensor(a)");
+    m.def("fir_direct_forward(Tensor x, Tensor kernel) -> Tensor");
+    m.def("fft_conv_forward(Tensor x, Tensor kernel, int pad_left, int pad_right) -> Tensor");
+    m.def("sum_forward(Tensor[] tensors) -> Tensor");
+    m.def("gain_forward(Tensor x, float gain, bool clamp) -> Tensor");
+    m.def("stat_forward(Tensor x, int mode, bool per_row) -> Tensor");
+    m.def("normalize_forward(Tensor x, float peak, int mode, bool per_row) -> Tensor");
+    m.def("deinterleave_forward(Tensor frames, float scale=3.0517578125e-05) -> Tensor");
+    m.def("deinterleave_into(Tensor frames, Tensor(a!) out, int frame_base=0, float scale=3.0517578125e-05) -> ()");
+    m.def("interleave_forward(Tensor x, int frame_base=0, int frames=-1) -> Tensor");
+}
+
+TORCH_LIBRARY_IMPL(torchfx_hip, CUDA, m)          // "CUDA" is the dispatch key of ROCm device tensors
+{
+    m.impl("sos_forward", sos_op);
+    m.impl("sos_forward_sections", sos_sections_op);
+    m.impl("sos_bank_forward", bank_op);
+    m.impl("sos_bank_sum_forward", bank_sum_op);
+    m.impl("biquad_forward", biquad_op);
+    m.impl("delay_line_forward", delay_line_op);
+    m.impl("fir_direct_forward", fir_direct_op);
+    m.impl("fft_conv_forward", fft_conv_op);
+    m.impl("sum_forward", sum_op);
+    m.impl("gain_forward", gain_op);
+    m.impl("stat_forward", stat_op);
+    m.impl("normalize_forward", normalize_op);
+    m.impl("deinterleave_forward", deinterleave_op);
+    m.impl("deinterleave_into", deinterleave_into_op);
+    m.impl("interleave_forward", interleave_op);
+}
+
+TORCH_LIBRARY_IMPL(torchfx_hip, Meta, m)
+{
+    m.impl("sos_forward", sos_meta);
+    m.impl("sos_forward_sections", sos_sections_meta);
+    m.impl("sos_bank_forward", bank_meta);
+    m.impl("sos_bank_sum_forward", bank_sum_meta);
+    m.impl("biquad_forward", biquad_meta);
+    m.impl("fir_direct_forward", [](const Tensor &x, const Tensor &) { return at::empty_like(x); });
+    m.impl("fft_conv_forward", fft_conv_meta);
+    m.impl("gain_forward", [](const Tensor &x, double, bool) { return at::empty_like(x); });
+    m.impl("normalize_forward", [](const Tensor &x, double, int64_t, bool) { return at::empty_like(x); });
+}
+
+TORCH_LIBRARY_IMPL(torchfx_hip, CPU, m)
+{
+    m.impl("sos_forward", no_cpu<std::tuple<Tensor, Tensor, Tensor>, const Tensor &, const Tensor &, const OptTensor &, const OptTensor &,
+                                 std::optional<at::ScalarType>, int64_t>);
+    m.impl("biquad_forward", no_cpu<std::tuple<Tensor, Tensor, Tensor>, const Tensor &, const Tensor &, double, double, const OptTensor &,
+                                    const OptTensor &, std::optional<at::ScalarType>, int64_t>);
+    m.impl("delay_line_forward", no_cpu<Tensor, const Tensor &, int64_t, double, double>);
+    m.impl("fir_direct_forward", no_cpu<Tensor, const Tensor &, const Tensor &>);
+    m.impl("fft_conv_forward", no_cpu<Tensor, const Tensor &, const Tensor &, int64_t, int64_t>);
+    m.impl("gain_forward", no_cpu<Tensor, const Tensor &, double, bool>);
+    m.impl("normalize_forward", no_cpu<Tensor, const Tensor &, double, int64_t, bool>);
+}
+
+// The reference's module surface (binding.cpp:83-96): exactly these three names and argument lists.
+PYBIND11_MODULE(torchfx_ext, m)
+{
+    m.doc() = "torchfx native extension for MI355X (HIP kernels behind the reference's torchfx_ext interface)";
+    m.def("biquad_forward",
+          [](const Tensor &x, const Tensor &b, double a1, double a2, const OptTensor &state_x, const OptTensor &state_y) {
+              return biquad_op(x, b, a1, a2, state_x, state_y, std::nullopt, -1);
+          },
+          "Biquad forward pass (x, b, a1, a2, state_x, state_y) -> (y, new_state_x, new_state_y)", py::arg("x"), py::arg("b"),
+          py::arg("a1"), py::arg("a2"), py::arg("state_x"), py::arg("state_y"));
+    m.def("sos_forward",
+          [](const Tensor &x, const OptTensor &sos, const Tensor &sos_cpu, const OptTensor &state_x, const OptTensor &state_y) {
+              (void)sos;      // device copy of the coefficients: the reference's sync-avoidance argument, unused here
+              return sos_op(x, sos_cpu, state_x, state_y, std::nullopt, -1);
+          },
+          "SOS cascade forward pass (x, sos, sos_cpu, state_x, state_y) -> (y, new_state_x, new_state_y)", py::arg("x"),
+          py::arg("sos"), py::arg("sos_cpu"), py::arg("state_x"), py::arg("state_y"));
+    m.def("delay_line_forward", &delay_line_op, "Delay line forward pass (x, delay_samples, decay, mix) -> y", py::arg("x"),
+          py::arg("delay_samples"), py::arg("decay"), py::arg("mix"));
+}
