@@ -405,12 +405,15 @@ def main() -> None:
 
     gather_ms = None
     if args.gather and world > 1:
-        bufs = [torch.empty_like(out) for _ in range(world)] if rank == 0 else None
+        from torchfx_amd.distributed import gather_rows
         sync()
         g0 = time.perf_counter()
-        dist.gather(out, bufs, dst=0)
+        gathered = gather_rows(out, C * world, dst=0)          # one RCCL gather: each peer -> root over its own xGMI link
         sync()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        if rank == 0:
+            assert gathered.shape == (C * world, out.shape[1])
+        del gathered
         if world > 1:
             tg = torch.tensor([gather_ms], device="cpu" if share else dev, dtype=torch.float64)
             dist.all_reduce(tg, op=dist.ReduceOp.MAX)

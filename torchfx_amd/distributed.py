@@ -34,12 +34,14 @@ def shard_rows(x: Tensor, group=None) -> Tensor:
 
 
 def run_sharded(pipeline: nn.Module | list, x_local: Tensor, fs: int | None = None,
-                fuse_fir: bool = False) -> Tensor:
-    """Run a filter pipeline on this rank's rows.  No communication."""
+                fuse_fir: bool | None = None) -> Tensor:
+    """Run a filter pipeline on this rank's rows (``fuse_fir=None``: the planner's default policy).
+    No communication."""
     from torchfx_amd.wave import Wave
 
     w = Wave(x_local, fs if fs is not None else 0, device=x_local.device)
-    w.fuse_fir = fuse_fir
+    if fuse_fir is not None:
+        w.fuse_fir = fuse_fir
     steps = pipeline if isinstance(pipeline, (list, tuple)) else [pipeline]
     for s in steps:
         w = w | s
@@ -58,15 +60,20 @@ def gather_rows(y_local: Tensor, n_rows: int, dst: int = 0, group=None) -> Tenso
         send = torch.zeros((big, T), dtype=y_local.dtype, device=y_local.device)
         send[: y_local.shape[0]] = y_local
     send = send.contiguous()
-    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-    dist.gather(send, bufs, dst=dst, group=group)
+    # "nccl" (= RCCL) moves device buffers peer to root directly; a gloo group (CPU collectives: the
+    # development set-up where several ranks share one GPU) stages device rows through host memory
+    staged = send.is_cuda and dist.get_backend(group) == "gloo"
+    wire = send.cpu() if staged else send
+    bufs = [torch.empty_like(wire) for _ in range(world)] if rank == dst else None
+    dist.gather(wire, bufs, dst=dst, group=group)
     if rank != dst:
         return None
-    return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
+    out = torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
+    return out.to(y_local.device) if staged else out
 
 
 def filter_sharded(pipeline, x: Tensor, fs: int, gather: bool = True, dst: int = 0, group=None,
-                   fuse_fir: bool = False) -> Tensor | None:
+                   fuse_fir: bool | None = None) -> Tensor | None:
     """shard -> run -> (optionally) gather.  ``x`` is the full ``[C, T]`` signal (each rank only
     touches its own rows)."""
     y = run_sharded(pipeline, shard_rows(x, group), fs, fuse_fir)
