@@ -1024,7 +1024,10 @@ def test_two_ranks_share_one_device_hip_kernels_sharded_and_gathered(tmp_path):
     one = (Wave(x, 48000, device=DEV) | F.LoButterworth(2000, order=6) | F.ParametricEQ(1000, 2.0, 3.0)
            | F.FIR(np.hanning(301) / np.hanning(301).sum())).ys
     y = torch.load(tmp_path / "gathered.pt")
-    assert torch.equal(y, one.cpu())                  # rows are independent: bit-identical to one process
+    # the overlap-save pass packs two real frames (of neighbouring rows) into one complex transform, so a
+    # row's float32 rounding noise depends on which row it is paired with: equal to one process within
+    # the FFT tolerance, not bit for bit (the recursive kernel below is row-independent: bit-identical)
+    close(y, one.cpu().numpy(), 2e-6, "sharded chain vs one process")
     loc = torch.cat([torch.load(tmp_path / f"local{r}.pt") for r in range(world)])
     assert torch.equal(loc, F.HiButterworth(300, order=4, fs=48000)(x).cpu())
 
