@@ -21,11 +21,16 @@ def test_cpu_baseline_fields_and_workload_filters():
 def test_traffic_file_is_consistent():
     import os
     from tests.conftest import ROOT
-    tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-    c = tr["chain"]
-    per = c["per_kernel_GB_per_launch"]
-    total = 0.0
-    for name, v in per.items():
-        total += (v["read"] + v["write"]) * v.get("launches_per_step", 1)
-    assert abs(total * 1e9 - c["bytes_per_step"]) / c["bytes_per_step"] < 0.03
-    assert c["bytes_per_step"] > c["algorithmic_bytes_per_step"]
+    import bench
+    tr = json.load(open(os.path.join(ROOT, bench.TRAFFIC_FILE)))
+    assert len(tr["source_digest"]) == 16
+    for wl in ("chain", "sos", "fir", "fftconv"):
+        c = tr[wl]
+        per = c["per_kernel_GB_per_launch"]
+        total = sum((v["read"] + v["write"]) * v.get("launches_per_step", 1) for v in per.values())
+        assert abs(total * 1e9 - c["bytes_per_step"]) / c["bytes_per_step"] < 0.03
+        assert c["bytes_per_step"] > c["algorithmic_bytes_per_step"]
+    # the row pass reads and writes its workspace slab exactly once: the counter corrections reproduce known bytes
+    mc = tr["chain"]["model_check"]
+    assert abs(mc["measured_write"] / mc["row_pass_slab_GB_per_launch"] - 1) < 0.02
+    assert 1.0 <= mc["measured_read"] / mc["row_pass_slab_GB_per_launch"] < 1.05

@@ -70,6 +70,14 @@ class FusedSOSCascade(nn.Module):
     def _state_y(self, value: Tensor | None) -> None:
         self._stream.sy = value
 
+    @property
+    def _num_sections(self) -> int:                # read by the reference's tests (tests/test_fused.py:60-102)
+        return self._stream.table.sections
+
+    @property
+    def _stateful(self) -> bool:                   # "has run since the last reset" (tests/test_fused.py:176-184)
+        return not self._stream.fresh
+
     def move_coeff(self, device) -> None:
         """API parity only: the canonical table stays on the host, where the HIP op reads it."""
 
