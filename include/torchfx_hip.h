@@ -167,6 +167,21 @@ int tfx_fft_conv_forward(const void *x, void *y, int dtype,
                          int64_t pad_left, int64_t pad_right,
                          tfx_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * tfx_fir_stream_forward -- one chunk of a stateful FIR (streaming).
+ * The reference's FIR is stateless (src/torchfx/filter/fir.py:526-579: every call left-pads with K-1
+ * zeros), so StreamProcessor (src/torchfx/realtime/stream.py:164-347) is only seamless for FIR stages
+ * with overlap >= K-1.  Here the chunk is filtered as the continuation of what came before:
+ *   y[c,n] = sum_{j<K} kernel[j] * xv[c, n+j],   xv = [hist_in[c, 0..K-2] | x[c, 0..T-1]],
+ * the kernels read the K-1 history samples and the chunk from their two buffers (no concatenated copy),
+ * and hist_out receives the last K-1 samples of xv for the next call.
+ *   hist_in  DEVICE [C, K-1] of `dtype` or NULL (= zeros: first chunk);  hist_out DEVICE [C, K-1] or NULL,
+ *   a different buffer than hist_in;  direct != 0: time-domain kernels, else overlap-save.
+ * ------------------------------------------------------------------------- */
+int tfx_fir_stream_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
+                           const void *kernel_host, int64_t K, int direct,
+                           const void *hist_in, void *hist_out, tfx_stream_t stream);
+
 /* Block geometry the overlap-save op would use for a [*, T] signal and a K-tap kernel with
  * padding (l, r): *N = FFT block length, *S = hop (valid outputs per block), *F = blocks per row,
  * *native = 1 when the hand-written LDS-FFT path runs (0 = rocFFT path).  For bench/DESIGN

@@ -71,6 +71,16 @@ def fft_conv_forward(x, kernel, padding=(0, 0)):
     return torch.from_numpy(np.ascontiguousarray(O.fft_conv1d(_np(x), k, padding)))
 
 
+def fir_stream_forward(x, kernel, hist, direct=False):
+    calls.append(("fir_stream_forward", tuple(x.shape), int(kernel.numel()), bool(direct)))
+    xn = _np(x)
+    k = _np(kernel).reshape(-1).astype(xn.dtype)
+    h = np.zeros((xn.shape[0], k.size - 1), xn.dtype) if hist is None else _np(hist).astype(xn.dtype)
+    xv = np.concatenate([h, xn], axis=1)                       # the oracle has no two-pointer form: concatenate here
+    y = O.fir_direct(xv, k)[:, k.size - 1:] if direct else O.fft_conv1d(xv, k, (0, 0))
+    return torch.from_numpy(np.ascontiguousarray(y)), torch.from_numpy(np.ascontiguousarray(xv[:, xv.shape[1] - (k.size - 1):]))
+
+
 def sum_forward(tensors):
     calls.append(("sum_forward", len(tensors)))
     out = torch.zeros_like(tensors[0])

@@ -37,3 +37,26 @@ def read(path, start=0, stop=None, dtype="float64", always_2d=False):
 def write(path, data, samplerate, format=None, subtype=None):  # noqa: A002
     written.append(dict(path=str(path), shape=tuple(data.shape), fs=samplerate, format=format, subtype=subtype,
                         data=np.array(data, copy=True)))
+
+
+class SoundFile:
+    """Write-mode context manager: collects the blocks written to it (``StreamProcessor.process_file``)."""
+
+    def __init__(self, path, mode="w", samplerate=None, channels=None, format=None, subtype=None):  # noqa: A002
+        assert mode == "w"
+        self.rec = dict(path=str(path), fs=samplerate, channels=channels, format=format, subtype=subtype, blocks=[])
+
+    def __enter__(self):
+        return self
+
+    def write(self, data):
+        data = np.asarray(data)
+        assert data.ndim == 2 and data.shape[1] == self.rec["channels"], data.shape
+        self.rec["blocks"].append(np.array(data, copy=True))
+
+    def __exit__(self, *exc):
+        blocks = self.rec.pop("blocks")
+        self.rec["data"] = np.concatenate(blocks, axis=0) if blocks else np.zeros((0, self.rec["channels"]), np.float32)
+        self.rec["shape"] = self.rec["data"].shape
+        written.append(self.rec)
+        return False

@@ -1051,3 +1051,66 @@ def test_bench_two_ranks_on_one_device(tmp_path):
         assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["config"]["channels_per_gpu"] == chans
         assert line["value"] > 0 and 0 < line["value_with_gather"] < line["value"] and line["gather_ms"] > 0
         assert "cpu_baseline" not in line and "stages" not in line          # rank 0 at N = 1 only
+
+
+# ------------------------------------------------------------------ streaming FIR: history + chunk from two buffers
+@pytest.mark.parametrize("direct", [True, False])
+@pytest.mark.parametrize("K,chunks", [
+    (33, [100, 7, 1500, 3393]),                    # short rows: LDS-tiled kernel / rocFFT path; a chunk shorter than K-1
+    (700, [300, 5000, 200, 9000]),                 # history longer than a chunk (old history shifts through)
+    (129, [20_000, 4_096, 30_000]),                # MFMA Toeplitz kernel (rows >= 4096) / rocFFT path
+    (200, [70_000, 66_000, 131_072]),              # LDS-resident overlap-save path, one and two blocks
+    (5000, [140_000, 70_001]),                     # long taps through the native path with history
+])
+def test_fir_stream_forward_chunks_equal_one_shot(K, chunks, direct):
+    """tfx_fir_stream_forward: every chunk continues the previous one through a [C, K-1] history buffer the
+    kernels read beside the chunk; concatenated outputs == one-shot float64 lfilter of the whole signal."""
+    rng = np.random.default_rng(K)
+    C, T = 3, sum(chunks)
+    x = rng.standard_normal((C, T)).astype(np.float32)
+    taps = (rng.standard_normal(K) / np.sqrt(K)).astype(np.float32)
+    import scipy.signal as sg
+    ref = sg.lfilter(taps.astype(np.float64), [1.0], x.astype(np.float64), axis=-1)
+    kernel = torch.from_numpy(taps[::-1].copy())
+    hist, outs, off = None, [], 0
+    for n in chunks:
+        y, hist = ext().fir_stream_forward(dev(x[:, off:off + n]), kernel, hist, direct)
+        assert y.shape == (C, n) and hist.shape == (C, K - 1)
+        lo = max(0, off + n - (K - 1))
+        assert np.array_equal(hist.cpu().numpy()[:, (K - 1) - (off + n - lo):], x[:, lo:off + n])   # the new history
+        outs.append(y)
+        off += n
+    close(torch.cat(outs, dim=1), ref.astype(np.float32), TOL_CONV_F32, f"streamed FIR K={K} direct={direct}")
+
+
+def test_stream_processor_process_file(tmp_path, monkeypatch):
+    """StreamProcessor.process_file / process_file_chunks (src/torchfx/realtime/stream.py:164-347) over the
+    stand-in codec: chunked IIR + stateful FIR over a file == the same effects on the whole signal."""
+    import sys
+
+    from tests import _fake_soundfile as sf
+    from torchfx_amd import filter as F
+    from torchfx_amd.realtime import StatefulFIR, StreamProcessor
+    monkeypatch.setitem(sys.modules, "soundfile", sf)
+    rng = np.random.default_rng(11)
+    frames = (rng.standard_normal((50_000, 2)) * 0.3).astype(np.float32)
+    src = tmp_path / "in.wav"
+    sf.make(src, frames, 44100, subtype="FLOAT")
+    taps = np.hanning(257) / np.hanning(257).sum()
+
+    def effects():
+        return [F.LoButterworth(3000, order=4), StatefulFIR(taps)]
+    whole = dev(torch.from_numpy(frames.T.copy()))
+    fx = effects()
+    fx[0].fs = 44100
+    ref = fx[1](fx[0](whole)).cpu().numpy()
+    for use_graph in (False, True):
+        proc = StreamProcessor(effects(), chunk_size=8192, overlap=0, device=DEV, use_graph=use_graph)
+        proc.process_file(src, tmp_path / "o" / "out.wav")
+        rec = sf.written[-1]
+        assert rec["format"] == "WAV" and rec["subtype"] == "FLOAT" and rec["fs"] == 44100 and rec["channels"] == 2
+        assert rec["data"].shape == frames.shape
+        assert np.abs(rec["data"].T - ref).max() <= 2e-6, use_graph
+    chunks = list(StreamProcessor(effects(), chunk_size=8192, device=DEV).process_file_chunks(src))
+    assert [c.shape[1] for c in chunks] == [8192] * 6 + [50_000 - 6 * 8192] and not chunks[0].is_cuda
+    assert np.abs(torch.cat(chunks, dim=1).numpy() - ref).max() <= 2e-6

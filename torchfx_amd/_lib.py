@@ -39,6 +39,7 @@ SIGNATURES = {
     "tfx_biquad_forward": (_int, [_vp, _int, _vp, _int, _i64, _i64, _vp, _dbl, _dbl, _vp, _vp, _vp, _vp, _int, _vp]),
     "tfx_fir_direct_forward": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _i64, _vp]),
     "tfx_fft_conv_forward": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _i64, _i64, _i64, _vp]),
+    "tfx_fir_stream_forward": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _i64, _int, _vp, _vp, _vp]),
     "tfx_ols_plan_info": (_int, [_i64, _i64, _i64, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64),
                                  ctypes.POINTER(_i64), ctypes.POINTER(_int)]),
     "tfx_delay_line_forward": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _dbl, _dbl, _vp]),

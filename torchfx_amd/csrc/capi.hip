@@ -19,10 +19,13 @@ void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C, in
 void sos_plan_info(const double *sos_host, int64_t K, int *precision, int64_t *warmup, double *err_bound);
 void sos_clear_plans();
 void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
-                        const void *kernel_host, int64_t K, hipStream_t stream);
+                        const void *kernel_host, int64_t K, hipStream_t stream, const void *hist = nullptr, int64_t H = 0);
+void fir_hist_update(const void *x, const void *hist_in, void *hist_out, int dtype, int64_t C, int64_t T, int64_t H,
+                     hipStream_t stream);
 void fir_clear();
 void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, const void *kernel_host,
-                      int64_t K, int64_t pad_left, int64_t pad_right, hipStream_t stream);
+                      int64_t K, int64_t pad_left, int64_t pad_right, hipStream_t stream, const void *hist = nullptr,
+                      int64_t H = 0);
 void fftconv_clear();
 void olsnative_clear();
 bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out);
@@ -231,6 +234,23 @@ int tfx_fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T
 {
     TFX_API_BEGIN
     fft_conv_forward(x, y, dtype, C, T, kernel_host, K, pad_left, pad_right, (hipStream_t)stream);
+    TFX_API_END
+}
+
+int tfx_fir_stream_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, const void *kernel_host, int64_t K,
+                           int direct, const void *hist_in, void *hist_out, tfx_stream_t stream)
+{
+    TFX_API_BEGIN
+    TFX_CHECK(K >= 1, "fir_stream_forward: empty kernel");
+    const int64_t H = K - 1;
+    if (C > 0 && T > 0) {
+        if (direct) fir_direct_forward(x, y, dtype, C, T, kernel_host, K, (hipStream_t)stream, H ? hist_in : nullptr, hist_in ? H : 0);
+        else fft_conv_forward(x, y, dtype, C, T, kernel_host, K, H, 0, (hipStream_t)stream, H ? hist_in : nullptr, hist_in ? H : 0);
+    }
+    if (hist_out && C > 0) {
+        TFX_CHECK(T == 0 || x, "fir_stream_forward: null signal");
+        fir_hist_update(x, hist_in, hist_out, dtype, C, T, H, (hipStream_t)stream);
+    }
     TFX_API_END
 }
 

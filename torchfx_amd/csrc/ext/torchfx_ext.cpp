@@ -242,6 +242,32 @@ Tensor fft_conv_op(const Tensor &x_in, const Tensor &kernel, int64_t pad_left, i
     return y;
 }
 
+// one chunk of a stateful FIR: history and chunk are read from their two buffers, the new history is returned
+std::tuple<Tensor, Tensor> fir_stream_op(const Tensor &x_in, const Tensor &kernel, const OptTensor &hist, bool direct)
+{
+    TORCH_CHECK(x_in.dim() == 2, "fir_stream_forward: x must be [C, T], got ", x_in.sizes());
+    need_device(x_in, "x");
+    const Tensor x = x_in.contiguous();
+    const Tensor k = taps_host(kernel, x);
+    const int64_t C = x.size(0), T = x.size(1), K = k.numel();
+    TORCH_CHECK(K >= 1, "fir_stream_forward: empty kernel");
+    Tensor hin;
+    const void *hp = nullptr;
+    if (hist.has_value() && hist->defined() && K > 1) {
+        TORCH_CHECK(hist->dim() == 2 && hist->size(0) == C && hist->size(1) == K - 1, "fir_stream_forward: history must be [C, K-1] = [",
+                    C, ", ", K - 1, "], got ", hist->sizes());
+        hin = hist->to(x.device(), x.scalar_type()).contiguous();
+        hp = hin.data_ptr();
+    }
+    Tensor y = at::empty_like(x);
+    Tensor hout = at::empty({C, K - 1}, x.options());
+    c10::hip::HIPGuard guard(x.get_device());
+    check_rc(tfx_fir_stream_forward(x.data_ptr(), y.data_ptr(), dtype_code(x, "fir_stream_forward"), C, T, k.data_ptr(), K,
+                                    direct ? 1 : 0, hp, K > 1 ? hout.data_ptr() : nullptr, stream_of(x)),
+             "fir_stream_forward");
+    return {y, hout};
+}
+
 // ---------------------------------------------------------------------------------------------------
 // `+` of branch outputs, Gain / Normalize passes, layout kernels
 // ---------------------------------------------------------------------------------------------------
@@ -409,6 +435,7 @@ TORCH_LIBRARY(torchfx_hip, m)
     m.def("delay_line_forward(Tensor(a) x, int delay_samples, float decay, float mix) -> Tensor(a)");
     m.def("fir_direct_forward(Tensor x, Tensor kernel) -> Tensor");
     m.def("fft_conv_forward(Tensor x, Tensor kernel, int pad_left, int pad_right) -> Tensor");
+    m.def("fir_stream_forward(Tensor x, Tensor kernel, Tensor? hist, bool direct) -> (Tensor, Tensor)");
     m.def("sum_forward(Tensor[] tensors) -> Tensor");
     m.def("gain_forward(Tensor x, float gain, bool clamp) -> Tensor");
     m.def("stat_forward(Tensor x, int mode, bool per_row) -> Tensor");
@@ -428,6 +455,7 @@ TORCH_LIBRARY_IMPL(torchfx_hip, CUDA, m)          // "CUDA" is the dispatch key 
     m.impl("delay_line_forward", delay_line_op);
     m.impl("fir_direct_forward", fir_direct_op);
     m.impl("fft_conv_forward", fft_conv_op);
+    m.impl("fir_stream_forward", fir_stream_op);
     m.impl("sum_forward", sum_op);
     m.impl("gain_forward", gain_op);
     m.impl("stat_forward", stat_op);
@@ -446,6 +474,9 @@ TORCH_LIBRARY_IMPL(torchfx_hip, Meta, m)
     m.impl("biquad_forward", biquad_meta);
     m.impl("fir_direct_forward", [](const Tensor &x, const Tensor &) { return at::empty_like(x); });
     m.impl("fft_conv_forward", fft_conv_meta);
+    m.impl("fir_stream_forward", [](const Tensor &x, const Tensor &kernel, const OptTensor &, bool) {
+        return std::make_tuple(at::empty_like(x), at::empty({x.size(0), kernel.numel() - 1}, x.options()));
+    });
     m.impl("gain_forward", [](const Tensor &x, double, bool) { return at::empty_like(x); });
     m.impl("normalize_forward", [](const Tensor &x, double, int64_t, bool) { return at::empty_like(x); });
 }

@@ -27,7 +27,7 @@ namespace tfx {
 // olsnative.hip: hand-written LDS FFT passes for the long-kernel float32 case
 bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out);
 void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const float *kf_host, int64_t K,
-                       int64_t pl, int64_t pr, int64_t N, hipStream_t stream);
+                       int64_t pl, int64_t pr, int64_t N, hipStream_t stream, const float *hist, int64_t H);
 
 #define TFX_ROCFFT(expr)                                                                     \
     do {                                                                                     \
@@ -41,7 +41,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
 template <typename T>
 __global__ void __launch_bounds__(256)
 ols_frame_kernel(const T *__restrict__ x, T *__restrict__ fr, int64_t Tn, int64_t c0, int64_t F,
-                 int64_t N, int64_t S, int64_t pad_left, int64_t total4)
+                 int64_t N, int64_t S, int64_t pad_left, int64_t total4, const T *__restrict__ hist, int64_t H)
 {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= total4) return;
@@ -55,7 +55,7 @@ ols_frame_kernel(const T *__restrict__ x, T *__restrict__ fr, int64_t Tn, int64_
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int64_t mm = m + e;
-        v[e] = (mm >= 0 && mm < Tn) ? xr[mm] : (T)0;
+        v[e] = (mm >= 0 && mm < Tn) ? xr[mm] : ((hist && mm < 0 && mm >= -H) ? hist[c * H + H + mm] : (T)0);
     }
     T *dst = fr + b * N + i;
 #pragma unroll
@@ -230,7 +230,7 @@ int64_t fftconv_block_size(int64_t K, int64_t L)
 
 template <typename T, typename T2>
 static void fft_conv_typed(const T *x, T *y, int dtype, int64_t C, int64_t Tn, const void *kernel_host,
-                           int64_t K, int64_t pl, int64_t pr, hipStream_t stream)
+                           int64_t K, int64_t pl, int64_t pr, hipStream_t stream, const T *hist, int64_t Hlen)
 {
     const int64_t L = Tn + pl + pr;
     const int64_t Tout = L - K + 1;
@@ -261,7 +261,7 @@ static void fft_conv_typed(const T *x, T *y, int dtype, int64_t C, int64_t Tn, c
             const int64_t total4 = nb * (N / 4);
             ProfScope ps("ols_frame_kernel", stream);
             hipLaunchKernelGGL(ols_frame_kernel<T>, dim3((unsigned)ceil_div(total4, 256)), dim3(256), 0, stream,
-                               x, fr, Tn, c0, F, N, S, pl, total4);
+                               x, fr, Tn, c0, F, N, S, pl, total4, hist, Hlen);
             TFX_HIP(hipGetLastError());
         }
         {
@@ -289,9 +289,12 @@ static void fft_conv_typed(const T *x, T *y, int dtype, int64_t C, int64_t Tn, c
     }
 }
 
+// hist (streaming): [C, H] samples that precede each row, x[-H .. -1], H <= pad_left: they replace the zeros of
+// the left padding
 void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, const void *kernel_host,
-                      int64_t K, int64_t pad_left, int64_t pad_right, hipStream_t stream)
+                      int64_t K, int64_t pad_left, int64_t pad_right, hipStream_t stream, const void *hist, int64_t H)
 {
+    TFX_CHECK(H >= 0 && H <= pad_left && (H == 0 || hist), "fft_conv_forward: bad history");
     TFX_CHECK(dtype == TFX_F32 || dtype == TFX_F64, "fft_conv_forward: bad dtype %d", dtype);
     TFX_CHECK(K >= 1 && pad_left >= 0 && pad_right >= 0, "fft_conv_forward: bad sizes");
     const int64_t L = T + pad_left + pad_right;
@@ -303,13 +306,16 @@ void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, c
     TFX_CHECK(y && kernel_host && (x || T == 0), "fft_conv_forward: null pointer");
     int64_t Nn = 0;
     if (dtype == TFX_F32 && olsnative_supported(K, L, &Nn)) {
-        olsnative_forward((const float *)x, (float *)y, C, T, (const float *)kernel_host, K, pad_left, pad_right, Nn, stream);
+        olsnative_forward((const float *)x, (float *)y, C, T, (const float *)kernel_host, K, pad_left, pad_right, Nn, stream,
+                          (const float *)hist, H);
         return;
     }
     if (dtype == TFX_F32)
-        fft_conv_typed<float, float2>((const float *)x, (float *)y, dtype, C, T, kernel_host, K, pad_left, pad_right, stream);
+        fft_conv_typed<float, float2>((const float *)x, (float *)y, dtype, C, T, kernel_host, K, pad_left, pad_right, stream,
+                                      (const float *)hist, H);
     else
-        fft_conv_typed<double, double2>((const double *)x, (double *)y, dtype, C, T, kernel_host, K, pad_left, pad_right, stream);
+        fft_conv_typed<double, double2>((const double *)x, (double *)y, dtype, C, T, kernel_host, K, pad_left, pad_right, stream,
+                                        (const double *)hist, H);
 }
 
 }  // namespace tfx

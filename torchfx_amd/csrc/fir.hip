@@ -78,8 +78,9 @@ template <int FIR_KC, int DBG = 0>
 __global__ void __launch_bounds__(256, 2)
 fir_direct_mfma_kernel(const float *__restrict__ x, float *__restrict__ y,
                        const float *__restrict__ kf_dev, int64_t C, int64_t T, int K, int nchunks,
-                       int64_t tiles_per_row)
+                       int64_t tiles_per_row, const float *__restrict__ hist, int H)
 {
+    // hist (streaming, StatefulFIR): [C, H] samples that precede the row, x[-H .. -1]; null = zeros
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int XW = FIR_NOUT + FIR_KC + 32;              // window length (floats)
     constexpr int XW_PAD = XW + (XW >> 5) + 1;
@@ -147,7 +148,14 @@ fir_direct_mfma_kernel(const float *__restrict__ x, float *__restrict__ y,
 #pragma unroll
         for (int r = 0; r < XV; ++r) {
             const int m = tid + 256 * r;
-            if (m < XW) xw[xpad33(m)] = (shift + m >= 0) ? xv[r] : 0.0f;
+            if (m < XW) {
+                float v = xv[r];
+                if (shift + m < 0) {                         // before the row start (first tiles only)
+                    const int64_t g = base + m;              // < 0
+                    v = (hist && g >= -(int64_t)H) ? hist[c * H + H + g] : 0.0f;
+                }
+                xw[xpad33(m)] = v;
+            }
         }
 #pragma unroll
         for (int r = 0; r < KV; ++r) {
@@ -189,7 +197,7 @@ fir_direct_mfma_kernel(const float *__restrict__ x, float *__restrict__ y,
 template <typename T>
 __global__ void __launch_bounds__(256)
 fir_direct_simple_kernel(const T *__restrict__ x, T *__restrict__ y, const T *__restrict__ kf_dev,
-                         int64_t C, int64_t Tn, int K, int64_t tiles_per_row)
+                         int64_t C, int64_t Tn, int K, int64_t tiles_per_row, const T *__restrict__ hist, int H)
 {
     constexpr int NO = 1024, KC = 512;
     __shared__ T xw[NO + KC];
@@ -204,7 +212,7 @@ fir_direct_simple_kernel(const T *__restrict__ x, T *__restrict__ y, const T *__
         const int64_t base = n0 + t0 - (int64_t)(K - 1);
         for (int m = tid; m < NO + KC; m += 256) {
             const int64_t g = base + m;
-            xw[m] = (g >= 0 && g < Tn) ? xrow[g] : (T)0;
+            xw[m] = (g >= 0 && g < Tn) ? xrow[g] : ((hist && g < 0 && g >= -(int64_t)H) ? hist[c * H + H + g] : (T)0);
         }
         for (int u = tid; u < KC; u += 256) kp[u] = (t0 + u < K) ? kf_dev[t0 + u] : (T)0;
         __syncthreads();
@@ -228,12 +236,41 @@ static int64_t envi_fir(const char *name, int64_t dflt)
     return e ? atoll(e) : dflt;
 }
 
+// The last H samples of the logical signal [hist | x] (what the next chunk needs as its history).
+template <typename T>
+__global__ void __launch_bounds__(256)
+fir_hist_update_kernel(const T *__restrict__ x, const T *__restrict__ hist_in, T *__restrict__ hist_out,
+                       int64_t C, int64_t Tn, int64_t H)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= C * H) return;
+    const int64_t c = g / H, i = g - c * H;
+    const int64_t j = Tn - H + i;                 // index into x; negative -> older history
+    hist_out[g] = j >= 0 ? x[c * Tn + j] : (hist_in ? hist_in[c * H + H + j] : (T)0);
+}
+
+void fir_hist_update(const void *x, const void *hist_in, void *hist_out, int dtype, int64_t C, int64_t T, int64_t H,
+                     hipStream_t stream)
+{
+    if (C * H == 0) return;
+    TFX_CHECK(hist_out && hist_out != hist_in, "fir_stream_forward: the new history needs its own buffer");
+    const unsigned grid = (unsigned)ceil_div(C * H, 256);
+    if (dtype == TFX_F32)
+        hipLaunchKernelGGL(fir_hist_update_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float *)x,
+                           (const float *)hist_in, (float *)hist_out, C, T, H);
+    else
+        hipLaunchKernelGGL(fir_hist_update_kernel<double>, dim3(grid), dim3(256), 0, stream, (const double *)x,
+                           (const double *)hist_in, (double *)hist_out, C, T, H);
+    TFX_HIP(hipGetLastError());
+}
+
 void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
-                        const void *kernel_host, int64_t K, hipStream_t stream)
+                        const void *kernel_host, int64_t K, hipStream_t stream, const void *hist, int64_t H)
 {
     TFX_CHECK(dtype == TFX_F32 || dtype == TFX_F64, "fir_direct_forward: bad dtype %d", dtype);
     TFX_CHECK(K >= 1, "fir_direct_forward: empty kernel");
     TFX_CHECK(K < (1 << 30), "fir_direct_forward: kernel too long");
+    TFX_CHECK(H >= 0 && H < (1 << 30) && (H == 0 || hist), "fir_direct_forward: bad history");
     if (C == 0 || T == 0) return;
     TFX_CHECK(x && y && kernel_host, "fir_direct_forward: null pointer");
     TFX_CHECK(C > 0 && T > 0, "fir_direct_forward: negative size");
@@ -270,7 +307,7 @@ void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
             }
             ProfScope ps("fir_direct_mfma_kernel", stream);
             hipLaunchKernelGGL(kern, dim3((unsigned)(C * tiles)), dim3(256), shmem, stream, (const float *)x,
-                               (float *)y, (const float *)kdev, C, T, (int)K, nchunks, tiles);
+                               (float *)y, (const float *)kdev, C, T, (int)K, nchunks, tiles, (const float *)hist, (int)H);
             TFX_HIP(hipGetLastError());
         };
         if (kc == 128) launch(fir_direct_mfma_kernel<128, 0>, 128);
@@ -282,11 +319,11 @@ void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
         if (dtype == TFX_F32) {
             ProfScope ps("fir_direct_simple_kernel<f32>", stream);
             hipLaunchKernelGGL(fir_direct_simple_kernel<float>, dim3((unsigned)(C * tiles)), dim3(256), 0, stream,
-                               (const float *)x, (float *)y, (const float *)kdev, C, T, (int)K, tiles);
+                               (const float *)x, (float *)y, (const float *)kdev, C, T, (int)K, tiles, (const float *)hist, (int)H);
         } else {
             ProfScope ps("fir_direct_simple_kernel<f64>", stream);
             hipLaunchKernelGGL(fir_direct_simple_kernel<double>, dim3((unsigned)(C * tiles)), dim3(256), 0, stream,
-                               (const double *)x, (double *)y, (const double *)kdev, C, T, (int)K, tiles);
+                               (const double *)x, (double *)y, (const double *)kdev, C, T, (int)K, tiles, (const double *)hist, (int)H);
         }
         TFX_HIP(hipGetLastError());
     }

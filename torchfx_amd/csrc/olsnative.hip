@@ -72,6 +72,8 @@ struct OlsGeom {
     int64_t pad_left;  // left zero padding of the framed signal (>= the caller's; rounded up for alignment)
     int64_t out_shift; // = pad_left - caller's pad_left: block output i is y[i - out_shift]
     int64_t nframes;   // C * F
+    const float *hist; // streaming: [C, H] samples preceding each row (x[-H .. -1]) instead of zero padding, or null
+    int64_t H;
     int N2;            // row length (N = 256 * N2)
     int P2;            // row pitch of the workspace T in elements (N2 + pad: breaks the power-of-two stride)
 };
@@ -187,8 +189,12 @@ ols_col_fwd16_kernel(const float *__restrict__ x, cpx *__restrict__ T, const cpx
             for (int t = 0; t < 16; ++t) {
                 const int64_t n = (int64_t)(q + QS * i + 16 * t) * g.N2 + n2;
                 const int64_t ia = ia0 + n, ib = ib0 + n;
-                const float re = (ia >= 0 && ia < g.Tn) ? xa[ia] : 0.0f;
-                const float im = (has_b && ib >= 0 && ib < g.Tn) ? xb[ib] : 0.0f;
+                float re = (ia >= 0 && ia < g.Tn) ? xa[ia] : 0.0f;
+                float im = (has_b && ib >= 0 && ib < g.Tn) ? xb[ib] : 0.0f;
+                if (g.hist) {
+                    if (ia < 0 && ia >= -g.H) re = g.hist[ca * g.H + g.H + ia];
+                    if (has_b && ib < 0 && ib >= -g.H) im = g.hist[cb_ * g.H + g.H + ib];
+                }
                 v[i][t] = make_float2(re, im);
             }
     }
@@ -723,12 +729,13 @@ bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out)
 }
 
 void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const float *kf_host, int64_t K,
-                       int64_t pl, int64_t pr, int64_t N, hipStream_t stream)
+                       int64_t pl, int64_t pr, int64_t N, hipStream_t stream, const float *hist, int64_t H)
 {
     std::lock_guard<std::mutex> lk(g_np_mu);
     OlsGeom g;
     const int64_t L = Tn + pl + pr;
     g.Tn = Tn; g.Tout = L - K + 1; g.pad_left = pl; g.out_shift = 0;
+    g.hist = hist; g.H = hist ? H : 0;
     // 128-byte aligned frames (rows themselves aligned): prepend `lead` zeros to the flipped taps so
     // that the left padding becomes a multiple of 32 samples, and round the hop down to a multiple
     // of 32: every 32-column segment the column passes read or write is then exactly one cache

@@ -3,10 +3,14 @@
 Reference: ``StreamProcessor`` (``src/torchfx/realtime/stream.py:164-347``) reads a file in
 chunks of ``chunk_size`` frames with ``overlap``, runs every effect's ``forward`` per chunk and
 relies on the IIR modules' carried DF1 state for continuity; FIR modules are stateless there, so
-seams are only right with ``overlap >= K-1``.  File I/O is out of scope here (host-side
-``soundfile``), so this mirror works on tensors already on the device, with the same chunk /
-overlap arithmetic, plus what the reference lacks: :class:`StatefulFIR`, an FIR that carries its
-last K-1 input samples so that ``overlap = 0`` streaming is exact for FIR stages too.
+seams are only right with ``overlap >= K-1``.  This mirror keeps the same chunk / overlap arithmetic
+on tensors (``process_chunks`` / ``process_tensor``) and on files (``process_file`` /
+``process_file_chunks``: ``soundfile`` stays the codec, as in the reference, but each decoded chunk
+goes to the device interleaved -- pinned staging, de-interleave kernel, ``torchfx_amd.io`` -- and comes
+back interleaved, so the host never transposes), plus what the reference lacks: :class:`StatefulFIR`,
+an FIR that carries its last K-1 input samples so that ``overlap = 0`` streaming is exact for FIR
+stages too; its kernels read the history and the chunk from two buffers (``tfx_fir_stream_forward``),
+there is no concatenated copy of the chunk.
 
 Small chunks are launch-bound (a 2 x 4096 step is ~60 us of host + launch overhead for a few us of
 GPU work), so ``StreamProcessor(..., use_graph=True)`` captures one full-size chunk step -- every
@@ -49,14 +53,10 @@ class StatefulFIR(FIR):
         if k == 1:
             return super().forward(x)
         h = self._hist
-        if h is None or h.shape[0] != rows.shape[0] or h.dtype != rows.dtype or h.device != rows.device:
-            h = rows.new_zeros((rows.shape[0], k - 1))
-        cat = torch.cat([h, rows], dim=1)                  # [rows, K-1+T]: history replaces the zero pad
-        self._hist = cat[:, -(k - 1):].clone()
-        if self._conv_mode == "direct":
-            y = torchfx_ext.fir_direct_forward(cat, taps)[:, k - 1:]
-        else:
-            y = torchfx_ext.fft_conv_forward(cat, taps, (0, 0))
+        if h is not None and (h.shape[0] != rows.shape[0] or h.dtype != rows.dtype or h.device != rows.device):
+            h = None                                          # row count / dtype / device changed: start from silence
+        # history and chunk stay in their own buffers (tfx_fir_stream_forward reads both); no torch.cat
+        y, self._hist = torchfx_ext.fir_stream_forward(rows, taps, h, self._conv_mode == "direct")
         return y.reshape(shape)
 
 
@@ -196,3 +196,64 @@ class StreamProcessor:
     @torch.no_grad()
     def process_tensor(self, x: Tensor, fs: int) -> Tensor:
         return torch.cat(list(self.process_chunks(x, fs)), dim=-1)
+
+    # ---- files (``stream.py:164-347``) -------------------------------------------------------------
+    def _file_steps(self, input_path) -> Generator[tuple[Tensor, bool], None, None]:
+        """Decode ``chunk_size`` frames at a time, run the effects on the device, yield the planar
+        ``[C, n]`` result (device tensor) with the overlap already dropped."""
+        import soundfile as sf
+
+        from torchfx_amd import io as _io
+
+        info = sf.info(str(input_path))
+        fs, num_frames = info.samplerate, info.frames
+        self._configure_effects(fs)
+        hop = self._chunk_size - self._overlap
+        on_gpu = torch.device(self._device).type == "cuda"
+        offset, primed = 0, False
+        while offset < num_frames:
+            n = min(self._chunk_size, num_frames - offset)
+            frames, _ = sf.read(str(input_path), start=offset, stop=offset + n, dtype="float32", always_2d=True)
+            # interleaved [n, C] -> planar [C, n] on the device (reference: data_np.T.copy() on the host)
+            w = _io.upload_interleaved(frames, self._device) if on_gpu else torch.from_numpy(frames.T.copy())
+            if self._use_graph and on_gpu and primed and w.shape[-1] == self._chunk_size:
+                w = self._graph_step(w)
+            else:
+                w = self._run(w)
+                primed = True
+            yield (w[..., self._overlap:] if (self._overlap > 0 and offset > 0) else w), fs
+            offset += hop
+
+    @torch.no_grad()
+    def process_file_chunks(self, input_path) -> Generator[Tensor, None, None]:
+        """Generator over processed chunks of a file, as host tensors ``[channels, frames]`` like the
+        reference's ``process_chunks(path)`` (``stream.py:278-347``)."""
+        for w, _ in self._file_steps(input_path):
+            yield w.cpu()
+
+    @torch.no_grad()
+    def process_file(self, input_path, output_path, format: str | None = None,  # noqa: A002
+                     subtype: str | None = None) -> None:
+        """Process an audio file chunk by chunk into ``output_path`` (``stream.py:164-276``): output format
+        from the extension (WAV when unknown), subtype FLOAT for WAV unless given, parent directories
+        created.  Chunks travel interleaved in both directions; the transposes run on the GPU."""
+        import pathlib
+
+        import soundfile as sf
+
+        from torchfx_amd import io as _io
+
+        out = pathlib.Path(output_path)
+        out.parent.mkdir(parents=True, exist_ok=True)
+        info = sf.info(str(input_path))
+        if format is None:
+            format = {".wav": "WAV", ".flac": "FLAC", ".ogg": "OGG"}.get(out.suffix.lower(), "WAV")  # noqa: A001
+        if subtype is None:
+            subtype = "FLOAT" if format == "WAV" else None
+        with sf.SoundFile(str(out), mode="w", samplerate=info.samplerate, channels=info.channels, format=format,
+                          subtype=subtype) as sink:
+            for w, _ in self._file_steps(input_path):
+                if w.is_cuda and w.dim() == 2 and w.dtype == torch.float32:
+                    sink.write(_io.download_interleaved(w))           # [n, C], interleaved on the device
+                else:
+                    sink.write(w.cpu().numpy().T)

@@ -33,7 +33,7 @@ from torchfx_amd import native
 
 __all__ = [
     "biquad_forward", "sos_forward", "sos_bank_forward", "sos_bank_sum_forward", "delay_line_forward",
-    "fir_direct_forward", "fft_conv_forward", "sum_forward", "gain_forward", "stat_forward", "normalize_forward",
+    "fir_direct_forward", "fft_conv_forward", "fir_stream_forward", "sum_forward", "gain_forward", "stat_forward", "normalize_forward",
     "deinterleave_forward", "interleave_forward", "sos_plan_info", "ols_plan_info",
 ]
 
@@ -127,6 +127,13 @@ def fft_conv_forward(x: Tensor, kernel, padding: tuple[int, int] = (0, 0)) -> Te
     """Overlap-save FFT convolution with ``fft_conv1d`` semantics (``_fftconv.py:70-141``) on ``x [C,T]``:
     returns ``[C, T + l + r - K + 1]``."""
     return native.ops().fft_conv_forward(x, _kernel_host(kernel, x.dtype), int(padding[0]), int(padding[1]))
+
+
+def fir_stream_forward(x: Tensor, kernel, hist: Tensor | None, direct: bool = False) -> tuple[Tensor, Tensor]:
+    """One chunk of a stateful FIR: ``x [C,T]`` continues the signal whose last ``K-1`` samples are ``hist
+    [C,K-1]`` (``None`` = silence).  Returns ``(y [C,T], new_hist [C,K-1])``.  The kernels read history and
+    chunk from their two buffers -- no concatenated copy of the chunk."""
+    return native.ops().fir_stream_forward(x, _kernel_host(kernel, x.dtype), hist, bool(direct))
 
 
 def sum_forward(tensors: list[Tensor]) -> Tensor:
