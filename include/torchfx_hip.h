@@ -168,6 +168,43 @@ int tfx_fft_conv_forward(const void *x, void *y, int dtype,
                          tfx_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Epilogues: `filter | Gain | Normalize` without a streaming pass per effect.
+ * Replaces, when it follows a filter in a pipeline,
+ *   Gain.forward                      src/torchfx/effect.py:361-383   y = x * gain, optional clip to [-1, 1]
+ *   the reduction half of Normalize   src/torchfx/effect.py:696-698 (peak), 719-721 (RMS), 775-786 (per channel)
+ * The producing kernel (the SOS cascade; the last pass of the overlap-save convolution) multiplies and
+ * clips every sample it stores -- in the output dtype, on the rounded value a standalone Gain pass would
+ * have read: bit-identical -- and gathers max|y| or sum y^2 on the fly; `stat_out` receives that raw
+ * statistic (float64, DEVICE, [C] when stat_per_row else [1]) and tfx_normalize_apply turns it into
+ *   y = s > 0 ? x / s * peak : x,   s = max|x|  (mode 0)  or  sqrt(sum x^2 / n)  (mode 1)
+ * in one pass.  Producers without a fused epilogue (direct FIR, the rocFFT path) run the same arithmetic
+ * as separate passes inside the call.
+ * ------------------------------------------------------------------------- */
+typedef struct tfx_epilogue {
+    double gain;          /* linear factor; 1.0 = none */
+    int clamp;            /* != 0: clip to [-1, 1] after the gain */
+    int stat_mode;        /* -1 none, 0 max|y|, 1 sum of y^2 */
+    int stat_per_row;     /* != 0: one statistic per output row, else one for the whole tensor */
+    double *stat_out;     /* DEVICE float64 [C] or [1]; required when stat_mode >= 0 */
+} tfx_epilogue;
+
+/* tfx_sos_forward (no section taps) + epilogue */
+int tfx_sos_forward_ep(const void *x, int x_dtype, void *y, int y_dtype, int64_t C, int64_t T,
+                       const double *sos_host, int64_t K,
+                       const double *state_x_in, const double *state_y_in,
+                       double *state_x_out, double *state_y_out,
+                       int precision, const tfx_epilogue *epilogue, tfx_stream_t stream);
+
+/* tfx_fft_conv_forward + epilogue */
+int tfx_fft_conv_forward_ep(const void *x, void *y, int dtype, int64_t C, int64_t T,
+                            const void *kernel_host, int64_t K, int64_t pad_left, int64_t pad_right,
+                            const tfx_epilogue *epilogue, tfx_stream_t stream);
+
+/* the apply half of Normalize on a statistic left by an epilogue (or by tfx_stat_forward's raw form) */
+int tfx_normalize_apply(const void *x, void *y, int dtype, int64_t C, int64_t T, int mode, int per_row,
+                        double peak, const double *stat_dev, tfx_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * tfx_fir_stream_forward -- one chunk of a stateful FIR (streaming).
  * The reference's FIR is stateless (src/torchfx/filter/fir.py:526-579: every call left-pads with K-1
  * zeros), so StreamProcessor (src/torchfx/realtime/stream.py:164-347) is only seamless for FIR stages

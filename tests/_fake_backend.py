@@ -12,12 +12,25 @@ def _np(t):
     return None if t is None else t.detach().cpu().numpy()
 
 
-def sos_forward(x, sos, sos_cpu, state_x, state_y, *, out_dtype=None, precision=None, return_sections=False):
-    calls.append(("sos_forward", tuple(x.shape), int((sos_cpu if sos_cpu is not None else sos).shape[0])))
+def _epilogue(y, ep):
+    """Gain / clamp / raw statistic of an Epilogue on the oracle's output (the test-side twin of epilogue.h)."""
+    if ep is None:
+        return y
+    if ep.gain != 1.0 or ep.clamp:
+        y = torch.from_numpy(np.ascontiguousarray(O.gain(y.numpy(), ep.gain, "amplitude", ep.clamp)))
+    if ep.stat is not None:
+        a = y.numpy().astype(np.float64)
+        a = a.reshape(-1, a.shape[-1]) if ep.per_row else a.reshape(1, -1)
+        ep.stat_value = torch.from_numpy(np.abs(a).max(axis=1) if ep.stat == "absmax" else (a * a).sum(axis=1))
+    return y
+
+
+def sos_forward(x, sos, sos_cpu, state_x, state_y, *, out_dtype=None, precision=None, return_sections=False, epilogue=None):
+    calls.append(("sos_forward", tuple(x.shape), int((sos_cpu if sos_cpu is not None else sos).shape[0])) + (("ep",) if epilogue else ()))
     s = _np(sos_cpu if sos_cpu is not None else sos)
     y, sx, sy, sec = O.sos_forward(_np(x), s, _np(state_x), _np(state_y), sections=True)
     odt = x.dtype if out_dtype is None else out_dtype
-    out = (torch.from_numpy(y).to(odt), torch.from_numpy(sx), torch.from_numpy(sy))
+    out = (_epilogue(torch.from_numpy(y).to(odt), epilogue), torch.from_numpy(sx), torch.from_numpy(sy))
     return out + (torch.from_numpy(sec).to(odt),) if return_sections else out
 
 
@@ -65,10 +78,26 @@ def fir_direct_forward(x, kernel):
     return torch.from_numpy(O.fir_direct(_np(x), k))
 
 
-def fft_conv_forward(x, kernel, padding=(0, 0)):
-    calls.append(("fft_conv_forward", tuple(x.shape), int(kernel.numel())))
+def fft_conv_forward(x, kernel, padding=(0, 0), epilogue=None):
+    calls.append(("fft_conv_forward", tuple(x.shape), int(kernel.numel())) + (("ep",) if epilogue else ()))
     k = _np(kernel).reshape(-1).astype(_np(x).dtype)
-    return torch.from_numpy(np.ascontiguousarray(O.fft_conv1d(_np(x), k, padding)))
+    return _epilogue(torch.from_numpy(np.ascontiguousarray(O.fft_conv1d(_np(x), k, padding))), epilogue)
+
+
+def normalize_apply(x, stat, peak, mode=0, per_row=False):
+    calls.append(("normalize_apply", tuple(x.shape), int(mode), bool(per_row)))
+    a = _np(x)
+    rows = a.reshape(-1, a.shape[-1]) if per_row else a.reshape(1, -1)
+    st = _np(stat).astype(np.float64)
+    s = (st if mode == 0 else np.sqrt(st / rows.shape[1])).astype(a.dtype)
+    out = rows.copy()
+    for r in range(rows.shape[0]):
+        if s[r] > 0:
+            out[r] = (rows[r] / s[r]) * a.dtype.type(peak)
+    return torch.from_numpy(out.reshape(a.shape))
+
+
+from torchfx_amd.torchfx_ext import Epilogue  # noqa: E402,F401  (plain Python class, no device code)
 
 
 def fir_stream_forward(x, kernel, hist, direct=False):

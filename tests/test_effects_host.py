@@ -87,30 +87,75 @@ def _mixed(fuse):
     return g, fuse
 
 
-@pytest.mark.parametrize("fuse", [False, True])
+@pytest.mark.parametrize("fuse", ["reference", "epilogue", "coefficients"])
 def test_mixed_pipeline_golden_and_plan(golden, oracle_backend, fuse):
-    """wave | iir | iir | Gain | iir | iir (tests/test_chain_fusion.py:102-121 of the reference):
-    staged by default -- two cascades around a gain pass -- one cascade with fuse_gain."""
+    """wave | iir | iir | Gain | iir | iir (tests/test_chain_fusion.py:102-121 of the reference) against the
+    reference's output: staged like the reference (two cascades around a gain pass), default (the gain rides on
+    the first cascade's kernel as an epilogue: two launches), and with fuse_gain (folded into the coefficients:
+    one cascade of four sections)."""
     g = golden("effects")
     mods, _ = _mixed(fuse)
     w = fx.Wave(torch.from_numpy(g["mix_x"]), 48000)
-    w.fuse_gain = fuse
+    assert w.fuse_epilogue is True and w.fuse_gain is False            # default policy
+    w.fuse_gain, w.fuse_epilogue = fuse == "coefficients", fuse == "epilogue"
     for m in mods:
         w = w | m
     names = [type(m).__name__ for m in w.plan()]
-    assert names == (["FusedSOSCascade"] if fuse else ["FusedSOSCascade", "Gain", "FusedSOSCascade"])
+    assert names == {"coefficients": ["FusedSOSCascade"], "reference": ["FusedSOSCascade", "Gain", "FusedSOSCascade"],
+                     "epilogue": ["Epilogued", "FusedSOSCascade"]}[fuse]
     oracle_backend.calls.clear()
     y = w.ys.numpy()
     assert np.abs(y - g["mix_y"]).max() <= 1e-6
     launches = [c[0] for c in oracle_backend.calls]
-    assert launches == (["sos_forward"] if fuse else ["sos_forward", "gain_forward", "sos_forward"])
-    if fuse:
+    assert launches == {"coefficients": ["sos_forward"], "reference": ["sos_forward", "gain_forward", "sos_forward"],
+                        "epilogue": ["sos_forward", "sos_forward"]}[fuse]
+    if fuse == "coefficients":
         assert oracle_backend.calls[0][2] == 4                       # all four sections in one launch
+    if fuse == "epilogue":
+        assert oracle_backend.calls[0][-1] == "ep" and oracle_backend.calls[1][-1] != "ep"
+
+
+def test_epilogue_plan_rules(oracle_backend):
+    """Which `filter | Gain | Normalize` runs become one kernel with an epilogue (effect.Epilogued)."""
+    w = fx.Wave(torch.zeros(2, 64), 48000)
+    w.fuse_fir = w.fuse_spectral = False
+
+    def names(wave):
+        return [type(m).__name__ for m in wave.plan()]
+    lo, hi = F.LoButterworth(4000, order=2), F.HiButterworth(100, order=2)
+    assert names(w | lo | E.Gain(2.0, clamp=True)) == ["Epilogued"]                                   # lone stateful IIR + clamping gain
+    assert names(w | lo | hi | E.Gain(0.5) | E.Normalize(0.9)) == ["Epilogued"]                       # cascade + gain + peak normalise
+    assert names(w | lo | E.Normalize(0.9, E.RMSNormalizationStrategy())) == ["Epilogued"]
+    assert names(w | lo | E.Normalize(0.9, E.PerChannelNormalizationStrategy())) == ["Epilogued"]
+    assert names(w | lo | E.Normalize(0.9, E.PercentileNormalizationStrategy(99.0))) == ["LoButterworth", "Normalize"]   # selection, not a stream
+    assert names(w | lo | E.Normalize(0.9, lambda x, p: x)) == ["LoButterworth", "Normalize"]
+    assert names(w | F.FIR([0.5, 0.5]) | E.Gain(0.5)) == ["Epilogued"]                                # FFT-mode FIR
+    assert names(w | F.FIR([0.5, 0.5], conv_mode="direct") | E.Gain(0.5)) == ["FIR", "Gain"]          # direct mode: no epilogue
+    assert names(w | E.Gain(0.5) | lo) == ["Gain", "LoButterworth"]                                   # a gain BEFORE the filter is not an epilogue
+    assert names(w | lo | E.Gain(0.5) | E.Gain(0.5)) == ["Epilogued", "Gain"]                         # one gain per epilogue (rounding order)
+    w.fuse_epilogue = False
+    assert names(w | lo | E.Gain(0.5)) == ["LoButterworth", "Gain"]
+    # results: identical to the staged pipeline (bit for bit for gain + clamp)
+    x = torch.randn(3, 4000, generator=torch.Generator().manual_seed(3))
+    for tail in ([E.Gain(1.7, clamp=True)], [E.Gain(0.3), E.Normalize(0.8)], [E.Normalize(0.5, E.RMSNormalizationStrategy())],
+                 [E.Gain(2.0, "db", clamp=True), E.Normalize(0.7, E.PerChannelNormalizationStrategy())]):
+        outs = []
+        for ep in (False, True):
+            wave = fx.Wave(x, 48000)
+            wave.fuse_epilogue, wave.fuse_fir, wave.fuse_spectral = ep, False, False
+            wave = wave | F.LoButterworth(3000, order=4) | F.HiShelving(2000, q=0.7, gain=2.0)
+            for t in tail:
+                wave = wave | t
+            outs.append(wave.ys)
+        if not any(isinstance(t, E.Normalize) for t in tail):
+            assert torch.equal(outs[0], outs[1])
+        else:
+            assert float((outs[0] - outs[1]).abs().max()) <= 1e-6 * max(1.0, float(outs[0].abs().max()))
 
 
 def test_gain_folding_rules(oracle_backend):
     w = fx.Wave(torch.zeros(2, 64), 48000)
-    w.fuse_gain, w.fuse_fir, w.fuse_spectral = True, False, False
+    w.fuse_gain, w.fuse_fir, w.fuse_spectral, w.fuse_epilogue = True, False, False, False
     lone = w | E.Gain(0.5) | F.LoButterworth(4000, order=2) | E.Gain(0.1)
     assert [type(m).__name__ for m in lone.plan()] == ["Gain", "LoButterworth", "Gain"]   # stateful lone IIR: staged
     clamp = w | F.LoButterworth(4000, order=2) | F.HiButterworth(100, order=2) | E.Gain(2.0, clamp=True)

@@ -667,7 +667,7 @@ def test_wave_pipeline_with_gain_on_device(golden, fuse):
     from torchfx_amd import filter as F
     g = golden("effects")
     w = fx.Wave(dev(g["mix_x"]), 48000, device=DEV)
-    w.fuse_gain = fuse
+    w.fuse_gain, w.fuse_epilogue = fuse, False
     for m in (F.LoButterworth(4000, order=2), F.HiButterworth(200, order=2), E.Gain(0.5),
               F.LoButterworth(6000, order=2), F.HiButterworth(100, order=2)):
         w = w | m
@@ -1114,3 +1114,87 @@ def test_stream_processor_process_file(tmp_path, monkeypatch):
     chunks = list(StreamProcessor(effects(), chunk_size=8192, device=DEV).process_file_chunks(src))
     assert [c.shape[1] for c in chunks] == [8192] * 6 + [50_000 - 6 * 8192] and not chunks[0].is_cuda
     assert np.abs(torch.cat(chunks, dim=1).numpy() - ref).max() <= 2e-6
+
+
+# ------------------------------------------------------------------ epilogues: Gain / Normalize on the producer's kernel
+def _tails():
+    import torchfx_amd as fx
+    E = fx.effect
+    return {
+        "gain+clamp": lambda: [fx.Gain(1.7, clamp=True)],
+        "gain db": lambda: [fx.Gain(-3.0, "db")],
+        "peak": lambda: [fx.Normalize(0.8)],
+        "gain+peak": lambda: [fx.Gain(0.3), fx.Normalize(0.8)],
+        "rms": lambda: [fx.Normalize(0.5, E.RMSNormalizationStrategy())],
+        "clamp+per_channel": lambda: [fx.Gain(2.0, clamp=True), fx.Normalize(0.7, E.PerChannelNormalizationStrategy())],
+    }
+
+
+@pytest.mark.parametrize("producer", ["cascade f32", "cascade f64 io", "lone iir", "fir fft short rows", "fir fft long rows", "cascade unaligned"])
+@pytest.mark.parametrize("tail", ["gain+clamp", "gain db", "peak", "gain+peak", "rms", "clamp+per_channel"])
+def test_epilogue_equals_staged_passes(producer, tail):
+    """filter | Gain | Normalize as ONE kernel with an epilogue (+ one apply pass for Normalize) against the same
+    modules staged as separate HIP passes: bit-identical for gain / clamp, 1e-6 for the normalisations (the
+    statistic is reduced in another order).  Covers the fused epilogues (float32 cascade kernel, last pass of the
+    LDS-resident overlap-save) and the producers that run the epilogue as passes inside the call (float64 I/O,
+    unaligned rows, rocFFT path)."""
+    import torchfx_amd as fx
+    from torchfx_amd import filter as F
+    T = {"fir fft long rows": 200_000, "cascade unaligned": 30_001}.get(producer, 30_000)
+    dt = np.float64 if producer == "cascade f64 io" else np.float32
+    x = dev(rnd((3, T), 21, dt) * 0.9)
+
+    def filt():
+        if producer.startswith("cascade"):
+            return [F.LoButterworth(3000, order=4), F.HiShelving(2000, q=0.7, gain=2.0)]
+        if producer == "lone iir":
+            return [F.ParametricEQ(frequency=800, q=3.0, gain=6.0)]
+        return [F.FIR(np.hanning(129) / np.hanning(129).sum() * 1.5)]
+    outs = []
+    for ep in (False, True):
+        w = fx.Wave(x, 48000, device=DEV)
+        w.fuse_epilogue, w.fuse_fir, w.fuse_spectral = ep, False, False
+        for m in filt() + _tails()[tail]():
+            w = w | m
+        if ep:
+            assert [type(m).__name__ for m in w.plan()] == ["Epilogued"]
+        outs.append(w.ys)
+    staged, fused = outs
+    assert fused.dtype == staged.dtype and fused.shape == staged.shape
+    if "peak" in tail or "rms" in tail or "per_channel" in tail:
+        close(fused, staged.cpu().numpy(), 1e-6 if dt == np.float32 else 1e-13, f"{producer} | {tail}")
+    else:
+        assert torch.equal(fused, staged), f"{producer} | {tail}"
+
+
+def test_epilogue_statistics_and_golden_mix(golden):
+    """The raw statistic an epilogue leaves on the device == the statistic of the stored output; and the reference's
+    mixed pipeline (tests/golden/effects.npz, iir | iir | Gain | iir | iir) under the default plan."""
+    import torchfx_amd as fx
+    from torchfx_amd import filter as F
+    e = ext()
+    x = dev(rnd((4, 150_000), 22) * 0.9)
+    from scipy.signal import butter
+    sos = torch.from_numpy(butter(4, 3000 / 24000, output="sos"))
+    for stat, per_row in (("absmax", False), ("absmax", True), ("sumsq", False), ("sumsq", True)):
+        ep = e.Epilogue(gain=1.3, clamp=True, stat=stat, per_row=per_row)
+        y, _, _ = e.sos_forward(x, None, sos, None, None, epilogue=ep)
+        yd = y.double()
+        rows = yd if per_row else yd.reshape(1, -1)
+        ref = rows.abs().max(dim=1).values if stat == "absmax" else (rows * rows).sum(dim=1)
+        assert torch.allclose(ep.stat_value, ref, rtol=1e-12, atol=0), (stat, per_row)
+        assert float(y.abs().max()) <= 1.0
+        k = torch.from_numpy((np.hanning(301) / np.hanning(301).sum()).astype(np.float32))
+        ep2 = e.Epilogue(gain=0.5, stat=stat, per_row=per_row)
+        y2 = e.fft_conv_forward(x, k, (300, 0), epilogue=ep2)                  # LDS-resident path: fused into the last pass
+        assert torch.equal(y2, e.gain_forward(e.fft_conv_forward(x, k, (300, 0)), 0.5))
+        rows = y2.double() if per_row else y2.double().reshape(1, -1)
+        ref = rows.abs().max(dim=1).values if stat == "absmax" else (rows * rows).sum(dim=1)
+        assert torch.allclose(ep2.stat_value, ref, rtol=1e-12, atol=0), ("fft", stat, per_row)
+    g = golden("effects")
+    w = fx.Wave(g["mix_x"], 48000, device=DEV)
+    for m in (F.LoButterworth(4000, order=2), F.HiButterworth(200, order=2), fx.Gain(0.5), F.LoButterworth(6000, order=2),
+              F.HiButterworth(100, order=2)):
+        w = w | m
+    assert [type(m).__name__ for m in w.plan()] == ["Epilogued", "FusedSOSCascade"]
+    close(w.ys, g["mix_y"], TOL_IIR_F32OUT * 2, "reference mixed pipeline, gain as an epilogue")

@@ -70,11 +70,14 @@ def parallel_iir_forward(
     sos_cpu: Tensor | None = None,
     out_dtype: torch.dtype | None = torch.float64,
     precision=None,
+    epilogue=None,
 ) -> tuple[Tensor, Tensor, Tensor]:
     """K-section SOS cascade (reference: ``_ops.py:119-176``).  ``None`` states mean zeros
     (``:144-147``).  Returns ``(y, new_state_x [K,C,2], new_state_y [K,C,2])``."""
     if sos_cpu is None:
         sos_cpu = sos.detach().to(dtype=torch.float64, device="cpu") if sos.is_cuda else sos
+    if epilogue is not None:
+        return _ext.sos_forward(x, sos, sos_cpu, state_x, state_y, out_dtype=out_dtype, precision=precision, epilogue=epilogue)
     return _ext.sos_forward(x, sos, sos_cpu, state_x, state_y, out_dtype=out_dtype, precision=precision)
 
 

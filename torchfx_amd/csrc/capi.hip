@@ -2,6 +2,7 @@
 // small shared services: thread-local error text, per-kernel HIP-event timing, device scratch,
 // (the elementwise kernels live in effects.hip).
 #include "common.h"
+#include "epilogue.h"
 #include "../../include/torchfx_hip.h"
 
 #include <map>
@@ -15,7 +16,7 @@ namespace tfx {
 void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C, int64_t T,
                  const double *sos_host, int64_t K, const double *sx_in, const double *sy_in,
                  double *sx_out, double *sy_out, void *y_sections, int precision, hipStream_t stream, int64_t NB = 1,
-                 bool sum_bands = false);
+                 bool sum_bands = false, const Epilogue *ep = nullptr);
 void sos_plan_info(const double *sos_host, int64_t K, int *precision, int64_t *warmup, double *err_bound);
 void sos_clear_plans();
 void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
@@ -25,7 +26,9 @@ void fir_hist_update(const void *x, const void *hist_in, void *hist_out, int dty
 void fir_clear();
 void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, const void *kernel_host,
                       int64_t K, int64_t pad_left, int64_t pad_right, hipStream_t stream, const void *hist = nullptr,
-                      int64_t H = 0);
+                      int64_t H = 0, const Epilogue *ep = nullptr);
+void normalize_apply_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, int mode, int per_row, double peak,
+                             const double *stat, hipStream_t stream);
 void fftconv_clear();
 void olsnative_clear();
 bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out);
@@ -174,6 +177,47 @@ int tfx_sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C,
     TFX_API_BEGIN
     sos_forward(x, x_dtype, y, y_dtype, C, T, sos_host, K, state_x_in, state_y_in, state_x_out, state_y_out,
                 y_sections, precision, (hipStream_t)stream);
+    TFX_API_END
+}
+
+static Epilogue to_epilogue(const tfx_epilogue *e)
+{
+    Epilogue ep;
+    if (!e) return ep;
+    TFX_CHECK(e->stat_mode >= -1 && e->stat_mode <= 1, "epilogue: bad statistic mode %d", e->stat_mode);
+    TFX_CHECK(e->gain == e->gain, "epilogue: NaN gain");
+    ep.gain = e->gain; ep.scale = e->gain != 1.0; ep.clamp = e->clamp != 0;
+    ep.stat_mode = e->stat_mode; ep.per_row = e->stat_per_row != 0; ep.stat_out = e->stat_out;
+    return ep;
+}
+
+int tfx_sos_forward_ep(const void *x, int x_dtype, void *y, int y_dtype, int64_t C, int64_t T,
+                       const double *sos_host, int64_t K, const double *state_x_in, const double *state_y_in,
+                       double *state_x_out, double *state_y_out, int precision, const tfx_epilogue *epilogue,
+                       tfx_stream_t stream)
+{
+    TFX_API_BEGIN
+    const Epilogue ep = to_epilogue(epilogue);
+    sos_forward(x, x_dtype, y, y_dtype, C, T, sos_host, K, state_x_in, state_y_in, state_x_out, state_y_out,
+                nullptr, precision, (hipStream_t)stream, 1, false, &ep);
+    TFX_API_END
+}
+
+int tfx_fft_conv_forward_ep(const void *x, void *y, int dtype, int64_t C, int64_t T, const void *kernel_host,
+                            int64_t K, int64_t pad_left, int64_t pad_right, const tfx_epilogue *epilogue,
+                            tfx_stream_t stream)
+{
+    TFX_API_BEGIN
+    const Epilogue ep = to_epilogue(epilogue);
+    fft_conv_forward(x, y, dtype, C, T, kernel_host, K, pad_left, pad_right, (hipStream_t)stream, nullptr, 0, &ep);
+    TFX_API_END
+}
+
+int tfx_normalize_apply(const void *x, void *y, int dtype, int64_t C, int64_t T, int mode, int per_row, double peak,
+                        const double *stat_dev, tfx_stream_t stream)
+{
+    TFX_API_BEGIN
+    normalize_apply_forward(x, y, dtype, C, T, mode, per_row, peak, stat_dev, (hipStream_t)stream);
     TFX_API_END
 }
 

@@ -10,6 +10,7 @@
 // The statistics stay on the device (no host sync: the reference's `if max_val > 0` is a blocking
 // .item()); the apply kernel reads them and handles the all-zero case itself.
 #include "common.h"
+#include "epilogue.h"
 #include "../../include/torchfx_hip.h"
 
 namespace tfx {
@@ -20,11 +21,6 @@ constexpr int EFX_U = 4;                                   // 16-byte vectors pe
 template <typename T> struct Vec16;
 template <> struct Vec16<float> { typedef float4 type; static constexpr int N = 4; };
 template <> struct Vec16<double> { typedef double2 type; static constexpr int N = 2; };
-
-template <typename T> __device__ __forceinline__ T clamp_unit(T v)
-{
-    return v < (T)-1 ? (T)-1 : (v > (T)1 ? (T)1 : v);      // NaN stays NaN, like torch.clamp
-}
 
 // ---- Gain -------------------------------------------------------------------------------------
 template <typename T, bool CLAMP>
@@ -70,21 +66,6 @@ gain_kernel(const T *__restrict__ x, T *__restrict__ y, int64_t n, T g)
 //                          like torch.max
 //   MODE 1  sum x^2     -- float64 accumulation
 constexpr int EFX_RT = 8;
-
-template <int MODE> __device__ __forceinline__ double red_init() { return 0.0; }
-template <int MODE> __device__ __forceinline__ double red_elem(double v)
-{
-    if (MODE == 0) return __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, v) & 0x7fffffffffffffffull);
-    return v * v;
-}
-template <int MODE> __device__ __forceinline__ double red_comb(double a, double b)
-{
-    if (MODE == 0) {
-        const unsigned long long x = __builtin_bit_cast(unsigned long long, a), y = __builtin_bit_cast(unsigned long long, b);
-        return __builtin_bit_cast(double, x > y ? x : y);
-    }
-    return a + b;
-}
 
 template <typename T, int MODE>
 __global__ void __launch_bounds__(EFX_THREADS)
@@ -386,6 +367,32 @@ void stat_forward(const void *x, int dtype, int64_t C, int64_t T, int mode, int 
     TFX_HIP(hipGetLastError());
 }
 
+void stat_finish(const double *partial, int64_t rows, int64_t groups, int mode, double *stat_dev, hipStream_t stream)
+{
+    ProfScope ps("reduce_finish_kernel", stream);
+    if (mode == 0) hipLaunchKernelGGL(reduce_finish_kernel<0>, dim3((unsigned)rows), dim3(1024), 0, stream, partial, groups, stat_dev);
+    else hipLaunchKernelGGL(reduce_finish_kernel<1>, dim3((unsigned)rows), dim3(1024), 0, stream, partial, groups, stat_dev);
+    TFX_HIP(hipGetLastError());
+}
+
+// a producer without a fused epilogue (direct FIR, the rocFFT path, float64 corner cases): the same
+// arithmetic as separate streaming passes over its output
+void epilogue_as_passes(void *y, int dtype, int64_t C, int64_t T, const Epilogue &ep, hipStream_t stream)
+{
+    if (C * T == 0) {
+        if (ep.stat_mode >= 0 && ep.stat_out) TFX_HIP(hipMemsetAsync(ep.stat_out, 0, (size_t)(ep.per_row ? C : 1) * 8, stream));
+        return;
+    }
+    if (ep.scale || ep.clamp) gain_forward(y, y, dtype, C * T, ep.scale ? ep.gain : 1.0, ep.clamp, stream);
+    if (ep.stat_mode >= 0) {
+        TFX_CHECK(ep.stat_out, "epilogue: statistic requested without an output buffer");
+        stat_launch(y, dtype, ep.per_row ? C : 1, ep.per_row ? T : C * T, ep.stat_mode, ep.stat_out, stream);
+    }
+}
+
+void normalize_apply_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, int mode, int per_row, double peak,
+                             const double *stat, hipStream_t stream);
+
 void normalize_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, int mode, int per_row, double peak,
                        hipStream_t stream)
 {
@@ -396,6 +403,19 @@ void normalize_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, 
     const int64_t rows = per_row ? C : 1, len = per_row ? T : C * T;
     double *stat = (double *)scratch("efx_stat", (size_t)rows * 8, stream);
     stat_launch(x, dtype, rows, len, mode, stat, stream);
+    normalize_apply_forward(x, y, dtype, C, T, mode, per_row, peak, stat, stream);
+}
+
+// the apply pass alone: `stat` = the raw statistic (max|x| or sum x^2, float64, [rows or 1]) a producing
+// kernel's epilogue left on the device
+void normalize_apply_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, int mode, int per_row, double peak,
+                             const double *stat, hipStream_t stream)
+{
+    TFX_CHECK(dtype == TFX_F32 || dtype == TFX_F64, "normalize_apply: bad dtype %d", dtype);
+    TFX_CHECK(mode == 0 || mode == 1, "normalize_apply: bad mode %d", mode);
+    if (C == 0 || T == 0) return;
+    TFX_CHECK(C > 0 && T > 0 && x && y && stat && peak == peak, "normalize_apply: null pointer, negative size or NaN peak");
+    const int64_t rows = per_row ? C : 1, len = per_row ? T : C * T;
     const int esz = dtype == TFX_F32 ? 4 : 8;
     // the apply pass walks the same (rows, len) view, so per-row statistics line up with blockIdx
     const int64_t tiles = efx_tiles(len, esz);

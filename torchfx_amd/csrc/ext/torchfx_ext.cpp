@@ -165,6 +165,42 @@ std::tuple<Tensor, Tensor, Tensor> bank_sum_op(const Tensor &x, const Tensor &ba
     return bank_impl(x, banks, sx, sy, std::nullopt, precision, true);
 }
 
+// cascade + epilogue (Gain / clamp / statistic for Normalize applied by the producing kernel, include/torchfx_hip.h)
+tfx_epilogue make_epilogue(double gain, bool clamp, int64_t stat_mode, bool per_row, Tensor &stat, const Tensor &like, int64_t rows)
+{
+    TORCH_CHECK(stat_mode >= -1 && stat_mode <= 1, "epilogue: stat_mode must be -1 (none), 0 (max|y|) or 1 (sum y^2)");
+    stat = at::empty({stat_mode >= 0 ? (per_row ? rows : 1) : 0}, like.options().dtype(at::kDouble));
+    tfx_epilogue ep;
+    ep.gain = gain; ep.clamp = clamp ? 1 : 0; ep.stat_mode = (int)stat_mode; ep.stat_per_row = per_row ? 1 : 0;
+    ep.stat_out = stat_mode >= 0 ? stat.data_ptr<double>() : nullptr;
+    return ep;
+}
+
+std::tuple<Tensor, Tensor, Tensor, Tensor> sos_ep_op(const Tensor &x_in, const Tensor &sos_cpu, const OptTensor &state_x,
+                                                     const OptTensor &state_y, double gain, bool clamp, int64_t stat_mode,
+                                                     bool per_row, std::optional<at::ScalarType> out_dtype, int64_t precision)
+{
+    TORCH_CHECK(x_in.dim() == 2, "sos_forward_ep: x must be [C, T], got ", x_in.sizes());
+    need_device(x_in, "x");
+    const Tensor x = x_in.contiguous();
+    const Tensor sos = host_f64(sos_cpu, 6, "sos_forward_ep");
+    TORCH_CHECK(sos.dim() == 2, "sos_forward_ep: sos must be [K, 6]");
+    const int64_t C = x.size(0), T = x.size(1), K = sos.size(0);
+    Tensor kx, ky, stat;
+    const double *sx = state_ptr(state_x, {K, C, 2}, x, "state_x", kx);
+    const double *sy = state_ptr(state_y, {K, C, 2}, x, "state_y", ky);
+    Tensor y = at::empty({C, T}, x.options().dtype(out_type(x, out_dtype)));
+    Tensor nsx = at::empty({K, C, 2}, x.options().dtype(at::kDouble));
+    Tensor nsy = at::empty({K, C, 2}, x.options().dtype(at::kDouble));
+    const tfx_epilogue ep = make_epilogue(gain, clamp, stat_mode, per_row, stat, x, C);
+    c10::hip::HIPGuard guard(x.get_device());
+    check_rc(tfx_sos_forward_ep(x.data_ptr(), dtype_code(x, "sos_forward_ep"), y.data_ptr(), dtype_code(y, "sos_forward_ep"), C, T,
+                                sos.data_ptr<double>(), K, sx, sy, nsx.data_ptr<double>(), nsy.data_ptr<double>(),
+                                precision_or_default(precision), &ep, stream_of(x)),
+             "sos_forward_ep");
+    return {y, nsx, nsy, stat};
+}
+
 // single biquad (binding.cpp:30-50): b [3] tensor, a1 / a2 scalars, states [C, 2]
 std::tuple<Tensor, Tensor, Tensor> biquad_op(const Tensor &x_in, const Tensor &b, double a1, double a2, const OptTensor &state_x,
                                              const OptTensor &state_y, std::optional<at::ScalarType> out_dtype, int64_t precision)
@@ -239,6 +275,42 @@ Tensor fft_conv_op(const Tensor &x_in, const Tensor &kernel, int64_t pad_left, i
     check_rc(tfx_fft_conv_forward(x.data_ptr(), y.data_ptr(), dtype_code(x, "fft_conv_forward"), C, T, k.data_ptr(), K, pad_left,
                                   pad_right, stream_of(x)),
              "fft_conv_forward");
+    return y;
+}
+
+std::tuple<Tensor, Tensor> fft_conv_ep_op(const Tensor &x_in, const Tensor &kernel, int64_t pad_left, int64_t pad_right, double gain,
+                                          bool clamp, int64_t stat_mode, bool per_row)
+{
+    TORCH_CHECK(x_in.dim() == 2, "fft_conv_forward_ep: x must be [C, T], got ", x_in.sizes());
+    need_device(x_in, "x");
+    const Tensor x = x_in.contiguous();
+    const Tensor k = taps_host(kernel, x);
+    const int64_t C = x.size(0), T = x.size(1), K = k.numel();
+    const int64_t tout = T + pad_left + pad_right - K + 1;
+    Tensor y = at::empty({C, tout > 0 ? tout : 0}, x.options()), stat;
+    const tfx_epilogue ep = make_epilogue(gain, clamp, stat_mode, per_row, stat, x, C);
+    c10::hip::HIPGuard guard(x.get_device());
+    check_rc(tfx_fft_conv_forward_ep(x.data_ptr(), y.data_ptr(), dtype_code(x, "fft_conv_forward_ep"), C, T, k.data_ptr(), K, pad_left,
+                                     pad_right, &ep, stream_of(x)),
+             "fft_conv_forward_ep");
+    return {y, stat};
+}
+
+// the apply half of Normalize on a statistic an epilogue left on the device
+Tensor normalize_apply_op(const Tensor &x, const Tensor &stat, double peak, int64_t mode, bool per_row)
+{
+    need_device(x, "x");
+    need_device(stat, "stat");
+    const Tensor xc = x.contiguous();
+    const int64_t T = xc.dim() ? xc.size(-1) : 1, rows = T ? xc.numel() / T : 0;
+    TORCH_CHECK(stat.scalar_type() == at::kDouble && stat.numel() == (per_row ? rows : 1), "normalize_apply: stat must be float64 [",
+                per_row ? rows : 1, "], got ", stat.sizes(), " ", stat.scalar_type());
+    const Tensor st = stat.contiguous();
+    Tensor y = at::empty_like(xc);
+    c10::hip::HIPGuard guard(x.get_device());
+    check_rc(tfx_normalize_apply(xc.data_ptr(), y.data_ptr(), dtype_code(xc, "normalize_apply"), rows, T, (int)mode, per_row ? 1 : 0,
+                                 peak, st.data_ptr<double>(), stream_of(x)),
+             "normalize_apply");
     return y;
 }
 
@@ -436,6 +508,11 @@ TORCH_LIBRARY(torchfx_hip, m)
     m.def("fir_direct_forward(Tensor x, Tensor kernel) -> Tensor");
     m.def("fft_conv_forward(Tensor x, Tensor kernel, int pad_left, int pad_right) -> Tensor");
     m.def("fir_stream_forward(Tensor x, Tensor kernel, Tensor? hist, bool direct) -> (Tensor, Tensor)");
+    m.def("sos_forward_ep(Tensor x, Tensor sos_cpu, Tensor? state_x, Tensor? state_y, float gain, bool clamp, int stat_mode, "
+          "bool per_row, *, ScalarType? out_dtype=None, int precision=-1) -> (Tensor, Tensor, Tensor, Tensor)");
+    m.def("fft_conv_forward_ep(Tensor x, Tensor kernel, int pad_left, int pad_right, float gain, bool clamp, int stat_mode, "
+          "bool per_row) -> (Tensor, Tensor)");
+    m.def("normalize_apply(Tensor x, Tensor stat, float peak, int mode, bool per_row) -> Tensor");
     m.def("sum_forward(Tensor[] tensors) -> Tensor");
     m.def("gain_forward(Tensor x, float gain, bool clamp) -> Tensor");
     m.def("stat_forward(Tensor x, int mode, bool per_row) -> Tensor");
@@ -456,6 +533,9 @@ TORCH_LIBRARY_IMPL(torchfx_hip, CUDA, m)          // "CUDA" is the dispatch key 
     m.impl("fir_direct_forward", fir_direct_op);
     m.impl("fft_conv_forward", fft_conv_op);
     m.impl("fir_stream_forward", fir_stream_op);
+    m.impl("sos_forward_ep", sos_ep_op);
+    m.impl("fft_conv_forward_ep", fft_conv_ep_op);
+    m.impl("normalize_apply", normalize_apply_op);
     m.impl("sum_forward", sum_op);
     m.impl("gain_forward", gain_op);
     m.impl("stat_forward", stat_op);

@@ -12,6 +12,7 @@
 //   frame f of row c :  fr[i] = xp[c, f*S + i],  xp = x padded (l, r),   i < N,  S = N-K+1
 //   Z = rfft(fr) ;  Z *= conj(rfft(kf_pad)) / N ;  o = irfft(Z) ;  y[c, f*S + i] = o[i], i < S
 #include "common.h"
+#include "epilogue.h"
 #include "../../include/torchfx_hip.h"
 
 #include <rocfft/rocfft.h>
@@ -27,7 +28,7 @@ namespace tfx {
 // olsnative.hip: hand-written LDS FFT passes for the long-kernel float32 case
 bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out);
 void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const float *kf_host, int64_t K,
-                       int64_t pl, int64_t pr, int64_t N, hipStream_t stream, const float *hist, int64_t H);
+                       int64_t pl, int64_t pr, int64_t N, hipStream_t stream, const float *hist, int64_t H, const Epilogue *ep);
 
 #define TFX_ROCFFT(expr)                                                                     \
     do {                                                                                     \
@@ -292,8 +293,10 @@ static void fft_conv_typed(const T *x, T *y, int dtype, int64_t C, int64_t Tn, c
 // hist (streaming): [C, H] samples that precede each row, x[-H .. -1], H <= pad_left: they replace the zeros of
 // the left padding
 void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, const void *kernel_host,
-                      int64_t K, int64_t pad_left, int64_t pad_right, hipStream_t stream, const void *hist, int64_t H)
+                      int64_t K, int64_t pad_left, int64_t pad_right, hipStream_t stream, const void *hist, int64_t H,
+                      const Epilogue *ep)
 {
+    TFX_CHECK(!ep || ep->stat_mode < 0 || ep->stat_out, "fft_conv_forward: statistic requested without an output buffer");
     TFX_CHECK(H >= 0 && H <= pad_left && (H == 0 || hist), "fft_conv_forward: bad history");
     TFX_CHECK(dtype == TFX_F32 || dtype == TFX_F64, "fft_conv_forward: bad dtype %d", dtype);
     TFX_CHECK(K >= 1 && pad_left >= 0 && pad_right >= 0, "fft_conv_forward: bad sizes");
@@ -306,8 +309,9 @@ void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, c
     TFX_CHECK(y && kernel_host && (x || T == 0), "fft_conv_forward: null pointer");
     int64_t Nn = 0;
     if (dtype == TFX_F32 && olsnative_supported(K, L, &Nn)) {
+        // the LDS-resident path applies the epilogue in its last pass (the store of the inverse column FFT)
         olsnative_forward((const float *)x, (float *)y, C, T, (const float *)kernel_host, K, pad_left, pad_right, Nn, stream,
-                          (const float *)hist, H);
+                          (const float *)hist, H, (ep && ep->any()) ? ep : nullptr);
         return;
     }
     if (dtype == TFX_F32)
@@ -316,6 +320,7 @@ void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, c
     else
         fft_conv_typed<double, double2>((const double *)x, (double *)y, dtype, C, T, kernel_host, K, pad_left, pad_right, stream,
                                         (const double *)hist, H);
+    if (ep && ep->any()) epilogue_as_passes(y, dtype, C, L - K + 1, *ep, stream);     // rocFFT path: separate passes
 }
 
 }  // namespace tfx

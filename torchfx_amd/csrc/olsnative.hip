@@ -28,6 +28,7 @@
 // Semantics = fft_conv1d (src/torchfx/filter/_fftconv.py:70-141): causal correlation with the
 // stored flipped kernel, output length T + l + r - K + 1.
 #include "common.h"
+#include "epilogue.h"
 #include "../../include/torchfx_hip.h"
 
 #include <algorithm>
@@ -74,6 +75,10 @@ struct OlsGeom {
     int64_t nframes;   // C * F
     const float *hist; // streaming: [C, H] samples preceding each row (x[-H .. -1]) instead of zero padding, or null
     int64_t H;
+    // epilogue of the inverse column pass on the stored samples (epilogue.h)
+    float ep_gain;
+    int ep_scale, ep_clamp, ep_stat;
+    double *ep_partial;   // [nframes][N2 / 32]: one partial per (frame, column block); row c owns F * N2/32 consecutive ones
     int N2;            // row length (N = 256 * N2)
     int P2;            // row pitch of the workspace T in elements (N2 + pad: breaks the power-of-two stride)
 };
@@ -262,18 +267,47 @@ ols_col_inv16_kernel(const cpx *__restrict__ T, float *__restrict__ y, const cpx
         if (acc == 1.2345e30f) ya[oa0] = acc;
         return;
     }
+    const bool epi = g.ep_scale | g.ep_clamp | (g.ep_stat >= 0);
+    double acc_a = 0.0, acc_b = 0.0;
 #pragma unroll
     for (int i = 0; i < NBF; ++i)
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int64_t n = (int64_t)(q + QS * i + 16 * k) * g.N2 + n2;
             if (n < g.S) {                                   // valid part of the block
-                const cpx o = v[i][DFT16_AT(k)];
+                cpx o = v[i][DFT16_AT(k)];
                 const int64_t oa = oa0 + n - g.out_shift, ob = ob0 + n - g.out_shift;
-                if (oa >= 0 && oa < g.Tout) ya[oa] = o.x;
-                if (has_b && ob >= 0 && ob < g.Tout) yb[ob] = o.y;
+                const bool wa = oa >= 0 && oa < g.Tout, wb = has_b && ob >= 0 && ob < g.Tout;
+                if (epi) {                                   // Gain / clamp / statistic on the stored values
+                    if (g.ep_scale) { o.x *= g.ep_gain; o.y *= g.ep_gain; }
+                    if (g.ep_clamp) { o.x = clamp_unit(o.x); o.y = clamp_unit(o.y); }
+                    if (g.ep_stat >= 0) {
+                        if (wa) acc_a = red_comb_rt(g.ep_stat, acc_a, red_elem_rt(g.ep_stat, (double)o.x));
+                        if (wb) acc_b = red_comb_rt(g.ep_stat, acc_b, red_elem_rt(g.ep_stat, (double)o.y));
+                    }
+                }
+                if (wa) ya[oa] = o.x;
+                if (wb) yb[ob] = o.y;
             }
         }
+    if (g.ep_stat >= 0) {                  // one partial per (frame, column block), threads combined in a fixed order
+        double *red = (double *)smem;                        // the FFT buffer is free again
+        __syncthreads();
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            acc_a = red_comb_rt(g.ep_stat, acc_a, __shfl_xor(acc_a, off));
+            acc_b = red_comb_rt(g.ep_stat, acc_b, __shfl_xor(acc_b, off));
+        }
+        const int nw = (int)(blockDim.x >> 6), w = tid >> 6;
+        if ((tid & 63) == 0) { red[w] = acc_a; red[nw + w] = acc_b; }
+        __syncthreads();
+        if (tid == 0) {
+            double ra = red[0], rb = red[nw];
+            for (int u = 1; u < nw; ++u) { ra = red_comb_rt(g.ep_stat, ra, red[u]); rb = red_comb_rt(g.ep_stat, rb, red[nw + u]); }
+            g.ep_partial[fa * ncb + cb] = ra;
+            if (has_b) g.ep_partial[fb * ncb + cb] = rb;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -729,13 +763,15 @@ bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out)
 }
 
 void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const float *kf_host, int64_t K,
-                       int64_t pl, int64_t pr, int64_t N, hipStream_t stream, const float *hist, int64_t H)
+                       int64_t pl, int64_t pr, int64_t N, hipStream_t stream, const float *hist, int64_t H, const Epilogue *ep)
 {
     std::lock_guard<std::mutex> lk(g_np_mu);
     OlsGeom g;
     const int64_t L = Tn + pl + pr;
     g.Tn = Tn; g.Tout = L - K + 1; g.pad_left = pl; g.out_shift = 0;
     g.hist = hist; g.H = hist ? H : 0;
+    g.ep_gain = ep ? (float)ep->gain : 1.0f; g.ep_scale = ep ? ep->scale : 0; g.ep_clamp = ep ? ep->clamp : 0;
+    g.ep_stat = ep ? ep->stat_mode : -1; g.ep_partial = nullptr;
     // 128-byte aligned frames (rows themselves aligned): prepend `lead` zeros to the flipped taps so
     // that the left padding becomes a multiple of 32 samples, and round the hop down to a multiple
     // of 32: every 32-column segment the column passes read or write is then exactly one cache
@@ -752,6 +788,8 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     g.nframes = C * g.F; g.N2 = plan->N2;
     g.P2 = g.N2 + (int)envi("TFX_OLS_PITCH_PAD", 0);
     const int64_t npairs = ceil_div(g.nframes, 2);
+    if (g.ep_stat >= 0)                   // every (frame, column block) slot is written by exactly one workgroup
+        g.ep_partial = (double *)scratch("olsn_ep_partial", (size_t)(g.nframes * (g.N2 / OLS_CB)) * sizeof(double), stream);
     // Slab = the frame pairs one A / B / C launch triple covers.  Launches of a few thousand workgroups are
     // dominated by their ramp and tail (64 MB slabs: 12.2 ms for the three passes of cfg 4 on one stream,
     // 1 GB slabs: 9.8 ms), so slabs are as large as the workspace budget allows (1 GB per lane), but
@@ -879,6 +917,9 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
             TFX_HIP(hipStreamWaitEvent(user_stream, ev_join[i], 0));
         }
     }
+    if (g.ep_stat >= 0)                   // after the join: all partials are in
+        stat_finish(g.ep_partial, ep->per_row ? C : 1, (ep->per_row ? g.F : g.nframes) * (g.N2 / OLS_CB), g.ep_stat,
+                    ep->stat_out, user_stream);
 }
 
 }  // namespace tfx

@@ -26,6 +26,7 @@
 //   * arithmetic type TC is float64 by default -- the reference computes in float64
 //     (_ops.py:149) -- or float32 (TFX_PREC_F32).
 #include "common.h"
+#include "epilogue.h"
 #include "../../include/torchfx_hip.h"
 
 #include <cmath>
@@ -58,6 +59,12 @@ struct SosParams {
     int64_t warm;        // multiple of 4
     int K, nseg, nsteps;
     int nsum;            // > 0: sum mode -- every stream runs `nsum` bands over its input row and accumulates them
+    // epilogue on the stored samples (epilogue.h): y *= gain, clip, partial of max|y| / sum y^2 per stream
+    double ep_gain;
+    int ep_scale, ep_clamp, ep_stat;
+    double *ep_partial;  // [C * nseg], one per stream (row-major over (row, segment)), pre-zeroed
+    const void *ep_host; // host side only: the Epilogue this launch serves
+    int ep_fused;        // host side only: the kernel applies it (else separate passes follow the launch)
 };
 
 __device__ __forceinline__ void wave_sync()
@@ -102,7 +109,9 @@ template <typename T> struct U16 {               // 16 bytes of T
 //      cascades ("bands") to its input tile, which stays in the LDS stage, and accumulates their
 //      outputs -- rounded to TOut per band and added in branch order, exactly like the reference's
 //      zeros_like + in-place adds -- so N branches cost 8 B/sample instead of N x 8 + (N + 1) x 4
-template <typename TIn, typename TOut, typename TC, int LC, bool VEC, bool TAPS, bool PF, int MINW, bool SUMB = false>
+// EPI  epilogue on the stored samples (epilogue.h); a separate instantiation so that the plain kernel keeps
+//      its register budget (the statistic accumulator and the extra selects cost ~30 VGPRs = one wave per SIMD)
+template <typename TIn, typename TOut, typename TC, int LC, bool VEC, bool TAPS, bool PF, int MINW, bool SUMB = false, bool EPI = false>
 __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p)
 {
     static_assert(!(TAPS && SUMB), "section taps are not available in sum mode");
@@ -201,6 +210,7 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
     char *const st_own = stage + lane * CHUNK_B;
 
     if constexpr (PF) load_tile(start);
+    double ep_acc = 0.0;                   // this lane's share of the stream's statistic (0 is neutral for both modes)
 
     for (int64_t ts = start; ts < out_end; ts += TILE) {
         TC d[LC];
@@ -381,16 +391,40 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
 
         // ---- store (skipped entirely while still inside the warm-up halo)
         if (ts + TILE > out_begin) {
-#pragma unroll
-            for (int i = 0; i < NUO; ++i) {
-                U16<TOut> v;
-#pragma unroll
-                for (int e = 0; e < EO; ++e) v.e[e] = (TOut)d[i * EO + e];
-                *(uint4 *)(st_own + i * 16) = v.u;
-            }
-            wave_sync();
             const int64_t lo64 = out_begin - ts, hi64 = out_end - ts;
             const bool full = (lo64 <= 0) && (hi64 >= TILE);
+            if constexpr (!EPI) {
+#pragma unroll
+                for (int i = 0; i < NUO; ++i) {
+                    U16<TOut> v;
+#pragma unroll
+                    for (int e = 0; e < EO; ++e) v.e[e] = (TOut)d[i * EO + e];
+                    *(uint4 *)(st_own + i * 16) = v.u;
+                }
+            } else {
+                // Gain / clamp on the rounded output value, in the output dtype (what a standalone Gain pass
+                // would compute from the stored sample), and this lane's share of the statistic over the
+                // samples that are really stored
+                const TOut g_ = (TOut)p.ep_gain;
+                const int lo_s = lo64 > 0 ? (int)lo64 : 0, hi_s = hi64 < TILE ? (int)hi64 : TILE;
+#pragma unroll
+                for (int i = 0; i < NUO; ++i) {
+                    U16<TOut> v;
+#pragma unroll
+                    for (int e = 0; e < EO; ++e) {
+                        TOut o = (TOut)d[i * EO + e];
+                        if (p.ep_scale) o = o * g_;
+                        if (p.ep_clamp) o = clamp_unit(o);
+                        v.e[e] = o;
+                        if (p.ep_stat >= 0) {
+                            const int rel = lane * LC + i * EO + e;
+                            if (full || (rel >= lo_s && rel < hi_s)) ep_acc = red_comb_rt(p.ep_stat, ep_acc, red_elem_rt(p.ep_stat, (double)o));
+                        }
+                    }
+                    *(uint4 *)(st_own + i * 16) = v.u;
+                }
+            }
+            wave_sync();
             if constexpr (VEC) {
                 uint4 *__restrict__ yl = (uint4 *)(yrow + ts) + lane;
                 if (full) {
@@ -420,6 +454,11 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
             }
             wave_sync();
         }
+    }
+    if (EPI && p.ep_stat >= 0) {           // one partial per stream, lanes combined in a fixed order
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ep_acc = red_comb_rt(p.ep_stat, ep_acc, __shfl_xor(ep_acc, off));
+        if (lane == 0) p.ep_partial[sid] = ep_acc;
     }
 }
 
@@ -743,7 +782,7 @@ static void plan_segments(SosParams &p, int64_t plan_warm, int TILE, int residen
     p.nseg = (int)nseg; p.seg_len = seg_len; p.warm = warm;
 }
 
-template <typename TIn, typename TOut, typename TC, int LC, bool VEC, bool TAPS, bool PF, int MINW, bool SUMB = false>
+template <typename TIn, typename TOut, typename TC, int LC, bool VEC, bool TAPS, bool PF, int MINW, bool SUMB = false, bool EPI = false>
 static void launch_one(SosParams p, int64_t plan_warm, hipStream_t stream)
 {
     constexpr int IOB = sizeof(TIn) > sizeof(TOut) ? sizeof(TIn) : sizeof(TOut);
@@ -752,7 +791,8 @@ static void launch_one(SosParams p, int64_t plan_warm, hipStream_t stream)
     const int carry_b = (((nbl * p.K * 4 + 2 * LC) * (int)sizeof(TC)) + 15) & ~15;
     const size_t shmem = 4 * (size_t)(STAGE_B + carry_b);
     TFX_CHECK(shmem <= 160 * 1024, "sos_forward: %d band(s) x K=%d need %zu B of LDS (max 163840)", nbl, p.K, shmem);
-    auto kern = sos_stream_kernel<TIn, TOut, TC, LC, VEC, TAPS, PF, MINW, SUMB>;
+    auto kern = sos_stream_kernel<TIn, TOut, TC, LC, VEC, TAPS, PF, MINW, SUMB, EPI>;
+    if (!EPI) p.ep_stat = -1;                      // the plain instantiation has no epilogue code
     if (shmem > 64 * 1024)
         TFX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     static int blocks_per_cu_tab[TFX_MAX_DEVICES] = {0};     // per template instance and device
@@ -769,9 +809,19 @@ static void launch_one(SosParams p, int64_t plan_warm, hipStream_t stream)
     plan_segments(p, plan_warm, 64 * LC, blocks_per_cu * 4);
     const int64_t nstreams = p.C * p.nseg;
     const unsigned grid = (unsigned)ceil_div(nstreams, 4);
-    ProfScope ps(sizeof(TC) == 8 ? "sos_stream_kernel<f64>" : "sos_stream_kernel<f32>", stream);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, stream, p);
-    TFX_HIP(hipGetLastError());
+    if (p.ep_stat >= 0) {                  // streams that have nothing to store leave their (zeroed) slot alone
+        p.ep_partial = (double *)scratch("sos_ep_partial", (size_t)nstreams * sizeof(double), stream);
+        TFX_HIP(hipMemsetAsync(p.ep_partial, 0, (size_t)nstreams * sizeof(double), stream));
+    }
+    {
+        ProfScope ps(sizeof(TC) == 8 ? "sos_stream_kernel<f64>" : "sos_stream_kernel<f32>", stream);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, stream, p);
+        TFX_HIP(hipGetLastError());
+    }
+    if (p.ep_stat >= 0) {
+        const Epilogue *ep = (const Epilogue *)p.ep_host;
+        stat_finish(p.ep_partial, ep->per_row ? p.C : 1, ep->per_row ? p.nseg : nstreams, p.ep_stat, ep->stat_out, stream);
+    }
 }
 
 // Variants (TFX_SOS_VARIANT): 0 = LC32, 1 = LC16, 2 = LC32 + register prefetch, 3 = LC16 + prefetch.
@@ -788,6 +838,10 @@ static void launch_main(const SosParams &p, bool vec, int variant, int64_t nstre
             if (p.taps) launch_one<TIn, TOut, TC, 32, false, true, false, F32 ? 3 : 2>(p, nstreams, stream);
             else launch_one<TIn, TOut, TC, 32, false, false, false, F32 ? 3 : 2>(p, nstreams, stream);
         }
+        return;
+    }
+    if (p.ep_fused) {          // epilogue instantiation: one register-budget step below the plain kernel
+        launch_one<TIn, TOut, TC, 32, true, false, true, 2, false, true>(p, nstreams, stream);
         return;
     }
     switch (variant) {
@@ -821,8 +875,12 @@ static void launch_sum(const SosParams &p, bool vec, int64_t plan_warm, hipStrea
 void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C_in, int64_t T,
                  const double *sos_host, int64_t K,
                  const double *sx_in, const double *sy_in, double *sx_out, double *sy_out,
-                 void *y_sections, int precision, hipStream_t stream, int64_t NB, bool sum_bands)
+                 void *y_sections, int precision, hipStream_t stream, int64_t NB, bool sum_bands, const Epilogue *ep)
 {
+    Epilogue none;
+    if (!ep) ep = &none;
+    TFX_CHECK(!(ep->any() && y_sections), "sos_forward: no epilogue together with section taps");
+    TFX_CHECK(ep->stat_mode < 0 || ep->stat_out, "sos_forward: statistic requested without an output buffer");
     TFX_CHECK(NB >= 1, "sos_forward: need at least one band");
     TFX_CHECK(!(sum_bands && y_sections), "sos_forward: no section taps in sum mode");
     const int64_t C = sum_bands ? C_in : C_in * NB;
@@ -846,6 +904,7 @@ void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C_in,
             TFX_CHECK(x_dtype == y_dtype && NB == 1, "sos_forward: K=0 needs equal dtypes and a single band");
             TFX_HIP(hipMemcpyAsync(y, x, (size_t)C * T * (x_dtype == TFX_F32 ? 4 : 8), hipMemcpyDeviceToDevice, stream));
         }
+        if (ep->any()) epilogue_as_passes(y, y_dtype, C, K == 0 ? T : 0, *ep, stream);
         return;
     }
     for (int64_t i = 0; i < NB * K * 6; ++i)
@@ -864,6 +923,14 @@ void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C_in,
     p.sx_in = sx_in; p.sy_in = sy_in; p.sx_out = sx_out; p.sy_out = sy_out;
     p.C = C; p.C_in = C_in; p.T = T; p.K = (int)K;
     p.nsum = sum_bands ? (int)NB : 0;
+    p.ep_gain = ep->gain; p.ep_scale = ep->scale; p.ep_clamp = ep->clamp; p.ep_stat = ep->stat_mode;
+    p.ep_partial = nullptr; p.ep_host = ep;
+    // fused into the kernel on the main path (float32 I/O, aligned rows, no taps, single cascade); everything
+    // else runs the plain kernel and the same arithmetic as separate passes over y
+    const bool ep_fused = ep->any() && x_dtype == TFX_F32 && y_dtype == TFX_F32 && !sum_bands && !y_sections &&
+                          (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0) && ((T * 4) % 16 == 0);
+    p.ep_fused = ep_fused ? 1 : 0;
+    if (!ep_fused) { p.ep_scale = p.ep_clamp = 0; p.ep_stat = -1; }
 
     const int64_t nstreams = pl->warm;     // segmentation is decided per kernel instance (launch_one)
 
@@ -890,6 +957,7 @@ void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C_in,
         else if (y_dtype == TFX_F32) launch_rare<double, float, double>(p, vec, nstreams, stream);
         else launch_rare<double, double, double>(p, vec, nstreams, stream);
     }
+    if (ep->any() && !ep_fused) epilogue_as_passes(y, y_dtype, C, T, *ep, stream);
 }
 
 void sos_plan_info(const double *sos_host, int64_t K, int *precision, int64_t *warmup, double *err_bound)

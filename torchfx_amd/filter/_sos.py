@@ -75,8 +75,8 @@ class CascadeStream:
     def reset(self) -> None:
         self.sx = self.sy = None
 
-    def __call__(self, x: Tensor) -> Tensor:
+    def __call__(self, x: Tensor, epilogue=None) -> Tensor:
         from torchfx_amd.filter.iir import _sos_cascade_forward
 
-        y, _, self.sx, self.sy = _sos_cascade_forward(x, self.table.sos, None, self.sx, self.sy)
+        y, _, self.sx, self.sy = _sos_cascade_forward(x, self.table.sos, None, self.sx, self.sy, epilogue)
         return y

@@ -51,7 +51,7 @@ class Biquad(AbstractFilter):
         self._sos_device_cache = None
 
     @torch.no_grad()
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, epilogue=None) -> Tensor:
         if self.fs is None:
             raise ValueError("Sample rate (fs) must be set before filtering.")
         if self._sos is None:
@@ -60,7 +60,7 @@ class Biquad(AbstractFilter):
         from torchfx_amd.filter.iir import _sos_cascade_forward
 
         result, self._sos_device_cache, self._state_x, self._state_y = _sos_cascade_forward(
-            x, self._sos, self._sos_device_cache, self._state_x, self._state_y)
+            x, self._sos, self._sos_device_cache, self._state_x, self._state_y, epilogue)
         return result
 
     def reset_state(self) -> None:

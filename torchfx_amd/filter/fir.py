@@ -36,7 +36,9 @@ class FIR(AbstractFilter):
         """Nothing to design for explicit taps (kept for interface parity, ``fir.py:520-524``)."""
 
     @torch.no_grad()
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, epilogue=None) -> Tensor:
+        """``epilogue`` (``torchfx_ext.Epilogue``, planner-attached, FFT mode only): a following Gain / the
+        reduction half of a following Normalize, applied where the overlap-save pass stores its output."""
         from torchfx_amd import torchfx_ext
 
         if x.ndim not in (1, 2, 3):
@@ -45,7 +47,11 @@ class FIR(AbstractFilter):
         rows = x.reshape(-1, shape[-1])                 # [T] -> [1,T]; [B,C,T] -> [B*C,T]
         taps = self.kernel.reshape(-1)
         if self._conv_mode == "direct":
+            if epilogue is not None:
+                raise RuntimeError("FIR: epilogues are attached to FFT-mode filters only")
             y = torchfx_ext.fir_direct_forward(rows, taps)
+        elif epilogue is not None:
+            y = torchfx_ext.fft_conv_forward(rows, taps, (taps.numel() - 1, 0), epilogue=epilogue)
         else:                                           # "fft" and its alias "auto" (fir.py:552)
             y = torchfx_ext.fft_conv_forward(rows, taps, (taps.numel() - 1, 0))
         return y.reshape(shape)
@@ -93,9 +99,9 @@ class DesignableFIR(FIR):
         self._init_taps(taps, self._pending_conv_mode)
 
     @torch.no_grad()
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, epilogue=None) -> Tensor:
         if self.b is None:
             if self.fs is None:
                 raise ValueError("Sample rate (fs) must be set before filtering.")
             self.compute_coefficients()
-        return super().forward(x)
+        return super().forward(x, epilogue)

@@ -85,5 +85,5 @@ class FusedSOSCascade(nn.Module):
         self._stream.reset()
 
     @torch.no_grad()
-    def forward(self, x: Tensor) -> Tensor:
-        return self._stream(x)
+    def forward(self, x: Tensor, epilogue=None) -> Tensor:
+        return self._stream(x, epilogue)

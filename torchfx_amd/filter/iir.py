@@ -29,6 +29,7 @@ def _sos_cascade_forward(
     sos_device_cache: Tensor | None,
     state_x: Tensor | None,
     state_y: Tensor | None,
+    epilogue=None,
 ) -> tuple[Tensor, Tensor | None, Tensor | None, Tensor | None]:
     """Shared stateful SOS forward: shape, state and dtype rules of ``iir.py:84-184``.
 
@@ -41,6 +42,8 @@ def _sos_cascade_forward(
     path (:149-172): the HIP cascade kernel handles K = 1 and writes the input dtype itself.
     ``sos_device_cache`` is passed through untouched (the coefficients travel as kernel
     tables built from the canonical host copy, so there is nothing to cache on the device).
+    ``epilogue`` (``torchfx_ext.Epilogue``): a following Gain / the reduction half of a following
+    Normalize, applied by the cascade kernel to the samples it stores (planner-attached).
     """
     from torchfx_amd._ops import parallel_iir_forward
 
@@ -60,7 +63,7 @@ def _sos_cascade_forward(
         state_x, state_y = state_x.to(rows.device), state_y.to(rows.device)
 
     out, state_x, state_y = parallel_iir_forward(
-        rows, sos_canonical, state_x, state_y, sos_cpu=sos_canonical, out_dtype=x.dtype)
+        rows, sos_canonical, state_x, state_y, sos_cpu=sos_canonical, out_dtype=x.dtype, epilogue=epilogue)
     assert state_x.shape == (n_sec, n_rows, 2)
     return out.reshape(shape), sos_device_cache, state_x, state_y
 
@@ -85,14 +88,14 @@ class IIR(AbstractFilter):
         self._sos = torch.from_numpy(np.ascontiguousarray(sos, dtype=np.float64))
 
     @torch.no_grad()
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, epilogue=None) -> Tensor:
         if self.fs is None:
             raise ValueError(NONE_FS_ERR)
         if self._sos is None:
             self.compute_coefficients()
             self._sos_device_cache = None
         result, self._sos_device_cache, self._state_x, self._state_y = _sos_cascade_forward(
-            x, self._sos, self._sos_device_cache, self._state_x, self._state_y)
+            x, self._sos, self._sos_device_cache, self._state_x, self._state_y, epilogue)
         return result
 
     def reset_state(self) -> None:

@@ -33,9 +33,28 @@ from torchfx_amd import native
 
 __all__ = [
     "biquad_forward", "sos_forward", "sos_bank_forward", "sos_bank_sum_forward", "delay_line_forward",
-    "fir_direct_forward", "fft_conv_forward", "fir_stream_forward", "sum_forward", "gain_forward", "stat_forward", "normalize_forward",
+    "fir_direct_forward", "fft_conv_forward", "fir_stream_forward", "normalize_apply", "Epilogue", "sum_forward", "gain_forward", "stat_forward", "normalize_forward",
     "deinterleave_forward", "interleave_forward", "sos_plan_info", "ols_plan_info",
 ]
+
+
+class Epilogue:
+    """What the producing kernel does to the samples it stores (``include/torchfx_hip.h``, ``tfx_epilogue``):
+    ``gain`` (linear factor) and ``clamp`` = a following ``Gain``; ``stat`` ("absmax" | "sumsq" | None, optionally
+    ``per_row``) = the reduction half of a following ``Normalize``.  After the call ``stat_value`` holds the raw
+    statistic on the device (float64 ``[rows]`` or ``[1]``) for :func:`normalize_apply`."""
+
+    __slots__ = ("gain", "clamp", "stat", "per_row", "stat_value")
+
+    def __init__(self, gain: float = 1.0, clamp: bool = False, stat: str | None = None, per_row: bool = False) -> None:
+        if stat not in (None, "absmax", "sumsq"):
+            raise ValueError(f"stat must be None, 'absmax' or 'sumsq', got {stat!r}")
+        self.gain, self.clamp, self.stat, self.per_row = float(gain), bool(clamp), stat, bool(per_row)
+        self.stat_value: Tensor | None = None
+
+    @property
+    def stat_mode(self) -> int:
+        return {None: -1, "absmax": 0, "sumsq": 1}[self.stat]
 
 
 def _prec(precision) -> int:
@@ -51,7 +70,7 @@ def _coeff(t) -> Tensor:
 
 def sos_forward(x: Tensor, sos: Tensor | None, sos_cpu: Tensor | None, state_x: Tensor | None,
                 state_y: Tensor | None, *, out_dtype: torch.dtype | None = None,
-                precision=None, return_sections: bool = False):
+                precision=None, return_sections: bool = False, epilogue: Epilogue | None = None):
     """SOS cascade forward -- ``binding.cpp:52-66``.
 
     ``x [C,T]``, ``sos [K,6]`` (device copy, unused here), ``sos_cpu [K,6]`` host float64 (the reference's
@@ -60,6 +79,13 @@ def sos_forward(x: Tensor, sos: Tensor | None, sos_cpu: Tensor | None, state_x: 
     ``return_sections``); inputs are never modified."""
     ops = native.ops()
     coeff = _coeff(sos_cpu if sos_cpu is not None else sos)
+    if epilogue is not None:
+        if return_sections:
+            raise RuntimeError("sos_forward: no epilogue together with section taps")
+        y, nsx, nsy, epilogue.stat_value = ops.sos_forward_ep(
+            x, coeff, state_x, state_y, epilogue.gain, epilogue.clamp, epilogue.stat_mode, epilogue.per_row,
+            out_dtype=out_dtype, precision=_prec(precision))
+        return y, nsx, nsy
     if return_sections:
         return ops.sos_forward_sections(x, coeff, state_x, state_y, out_dtype=out_dtype, precision=_prec(precision))
     return ops.sos_forward(x, coeff, state_x, state_y, out_dtype=out_dtype, precision=_prec(precision))
@@ -123,10 +149,21 @@ def fir_direct_forward(x: Tensor, kernel) -> Tensor:
     return native.ops().fir_direct_forward(x, _kernel_host(kernel, x.dtype))
 
 
-def fft_conv_forward(x: Tensor, kernel, padding: tuple[int, int] = (0, 0)) -> Tensor:
+def fft_conv_forward(x: Tensor, kernel, padding: tuple[int, int] = (0, 0), epilogue: Epilogue | None = None) -> Tensor:
     """Overlap-save FFT convolution with ``fft_conv1d`` semantics (``_fftconv.py:70-141``) on ``x [C,T]``:
     returns ``[C, T + l + r - K + 1]``."""
+    if epilogue is not None:
+        y, epilogue.stat_value = native.ops().fft_conv_forward_ep(
+            x, _kernel_host(kernel, x.dtype), int(padding[0]), int(padding[1]), epilogue.gain, epilogue.clamp,
+            epilogue.stat_mode, epilogue.per_row)
+        return y
     return native.ops().fft_conv_forward(x, _kernel_host(kernel, x.dtype), int(padding[0]), int(padding[1]))
+
+
+def normalize_apply(x: Tensor, stat: Tensor, peak: float, mode: int = 0, per_row: bool = False) -> Tensor:
+    """The apply half of ``Normalize`` on a raw statistic an epilogue left on the device (``stat``: float64
+    ``[rows]`` or ``[1]``, max|x| for ``STAT_ABSMAX``, sum of squares for ``STAT_RMS``): one streaming pass."""
+    return native.ops().normalize_apply(x, stat, float(peak), int(mode), bool(per_row))
 
 
 def fir_stream_forward(x: Tensor, kernel, hist: Tensor | None, direct: bool = False) -> tuple[Tensor, Tensor]:

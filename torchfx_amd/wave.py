@@ -36,21 +36,24 @@ from torchfx_amd.effect import FX
 from torchfx_amd.filter._base import AbstractFilter
 
 
-def _fusion_defaults() -> tuple[bool, bool, bool]:
-    """(fuse_fir, fuse_spectral, fuse_gain) of a new ``Wave``.
+def _fusion_defaults() -> tuple[bool, bool, bool, bool]:
+    """(fuse_fir, fuse_spectral, fuse_gain, fuse_epilogue) of a new ``Wave``.
 
     ``TORCHFX_AMD_FUSION`` = ``auto`` (default) turns on the two fusions whose result stays within the
     FIR/FFT tolerance of the staged reference chain (1e-5 relative, checked against the reference's
     staged output in ``tests/golden/chain*.npz`` and at full size): merging runs of FFT-mode FIRs and
     folding a fresh IIR cascade into the FIR run that follows it.  ``reference`` stages every step
     exactly as ``src/torchfx/wave.py:207-239`` does.  The per-feature variables
-    ``TORCHFX_AMD_FUSE_{FIR,SPECTRAL,GAIN}`` (0/1) override either way; gain folding stays opt-in."""
+    ``TORCHFX_AMD_FUSE_{FIR,SPECTRAL,GAIN,EPILOGUE}`` (0/1) override either way.  ``auto`` also attaches a
+    ``Gain`` / ``Normalize`` that follows a filter to that filter's kernel as an epilogue (bit-identical for
+    the gain and the clamp; ``effect.Epilogued``); folding a gain into the coefficients stays opt-in."""
     auto = os.environ.get("TORCHFX_AMD_FUSION", "auto").lower() != "reference"
 
     def flag(name: str, dflt: bool) -> bool:
         v = os.environ.get(name)
         return dflt if v is None or v == "" else v == "1"
-    return flag("TORCHFX_AMD_FUSE_FIR", auto), flag("TORCHFX_AMD_FUSE_SPECTRAL", auto), flag("TORCHFX_AMD_FUSE_GAIN", False)
+    return (flag("TORCHFX_AMD_FUSE_FIR", auto), flag("TORCHFX_AMD_FUSE_SPECTRAL", auto), flag("TORCHFX_AMD_FUSE_GAIN", False),
+            flag("TORCHFX_AMD_FUSE_EPILOGUE", auto))
 
 
 def _merge_fir_run(run: list) -> nn.Module:
@@ -103,7 +106,7 @@ class Wave:
         self._pipeline: list[nn.Module] = []
         self._ys = ys if isinstance(ys, Tensor) else Tensor(ys)   # Tensor(ys): float32, as wave.py:137
         self.metadata = metadata or {}
-        self.fuse_fir, self.fuse_spectral, self.fuse_gain = _fusion_defaults()
+        self.fuse_fir, self.fuse_spectral, self.fuse_gain, self.fuse_epilogue = _fusion_defaults()
         self.to(device)
 
     # ------------------------------------------------------------------ lazy data
@@ -187,7 +190,40 @@ class Wave:
         plan.extend(lead)
         if getattr(self, "fuse_spectral", False):
             plan = self._spectral_plan(plan, int(self._ys.shape[-1]) if self._ys.dim() else 0)
+        if getattr(self, "fuse_epilogue", False):
+            plan = self._epilogue_plan(plan)
         return plan
+
+    @staticmethod
+    def _epilogue_plan(plan: list[nn.Module]) -> list[nn.Module]:
+        """``fuse_epilogue``: ``filter | Gain`` , ``filter | Normalize`` and ``filter | Gain | Normalize`` run as
+        the filter's kernel with an epilogue (``effect.Epilogued``) when the filter is an SOS module / cascade or
+        an FFT-mode FIR and the normalisation strategy is one with a streaming reduction (peak, RMS, per
+        channel)."""
+        from torchfx_amd.effect import Epilogued, Gain, Normalize
+        from torchfx_amd.filter.biquad import Biquad
+        from torchfx_amd.filter.fir import FIR
+        from torchfx_amd.filter.fused import FusedSOSCascade
+        from torchfx_amd.filter.iir import IIR
+
+        out: list[nn.Module] = []
+        i = 0
+        while i < len(plan):
+            m = plan[i]
+            producer = isinstance(m, (IIR, Biquad, FusedSOSCascade)) or (isinstance(m, FIR) and m._conv_mode != "direct")
+            gain = norm = None
+            j = i + 1
+            if producer and j < len(plan) and isinstance(plan[j], Gain):
+                gain, j = plan[j], j + 1
+            if producer and j < len(plan) and isinstance(plan[j], Normalize) and Epilogued.norm_kind(plan[j]) is not None:
+                norm, j = plan[j], j + 1
+            if gain is not None or norm is not None:
+                out.append(Epilogued(m, gain, norm))
+                i = j
+            else:
+                out.append(m)
+                i += 1
+        return out
 
     @staticmethod
     def _ols_bytes_per_sample(taps: int, length: int) -> float:
@@ -246,11 +282,13 @@ class Wave:
 
     @classmethod
     def _deferred(cls, ys: Tensor, fs: int, device, metadata, pipeline: list[nn.Module],
-                  fuse_fir: bool = False, fuse_spectral: bool = False, fuse_gain: bool = False) -> "Wave":
+                  fuse_fir: bool = False, fuse_spectral: bool = False, fuse_gain: bool = False,
+                  fuse_epilogue: bool = False) -> "Wave":
         w = object.__new__(cls)
         w._ys, w.fs, w._device, w.metadata, w._pipeline, w.fuse_fir = ys, fs, device, metadata, pipeline, fuse_fir
         w.fuse_spectral = fuse_spectral
         w.fuse_gain = fuse_gain
+        w.fuse_epilogue = fuse_epilogue
         return w
 
     # ------------------------------------------------------------------ device
@@ -281,7 +319,7 @@ class Wave:
         steps = list(f.children()) if isinstance(f, nn.Sequential) else [f]
         return Wave._deferred(self._ys, self.fs, self._device, self.metadata,
                               self._pipeline + steps, self.fuse_fir, getattr(self, "fuse_spectral", False),
-                              getattr(self, "fuse_gain", False))
+                              getattr(self, "fuse_gain", False), getattr(self, "fuse_epilogue", False))
 
     # ------------------------------------------------------------------ files
     _SUBTYPE_BY_ENCODING = {"PCM_S": lambda b: f"PCM_{b}", "PCM_U": lambda b: "PCM_U8" if b == 8 else f"PCM_{b}",
@@ -313,7 +351,7 @@ class Wave:
             w = object.__new__(cls)
             w._ys = _io.upload_interleaved(data_np, device)
             w.fs, w._device, w.metadata, w._pipeline = fs, device, metadata, []
-            w.fuse_fir, w.fuse_spectral, w.fuse_gain = _fusion_defaults()
+            w.fuse_fir, w.fuse_spectral, w.fuse_gain, w.fuse_epilogue = _fusion_defaults()
             return w
         return cls(torch.from_numpy(np.ascontiguousarray(data_np.T)), fs, metadata=metadata)
 
