@@ -100,6 +100,11 @@ def make_step(workload: str, x: torch.Tensor):
     sos = torch.cat([f1._sos, f2._sos]).contiguous()
     if workload == "sos":
         return (lambda: E.sos_forward(x, None, sos, None, None)[0]), "cfg2: fused 4-section SOS cascade (LoButterworth-6 | ParametricEQ), float64 recursion", None
+    if workload == "sos_auto":
+        info = E.sos_plan_info(sos)
+        return (lambda: E.sos_forward(x, None, sos, None, None, precision="auto")[0]), (
+            f"cfg2 cascade with precision='auto' (opt-in): {info['auto_precision']} recursion, estimated largest error "
+            f"{info['f32_error_bound']:.2e} of max(1, max|y|), bound 2e-5"), None
     if workload == "fir":
         k = fir.kernel.reshape(-1)
         return (lambda: E.fir_direct_forward(x, k)), "cfg3: direct FIR, 1024 taps (exact-f32 MFMA Toeplitz)", None
@@ -381,7 +386,8 @@ def main() -> None:
         # configs[1..3] of BASELINE.json, timed by this same driver-run process (wall clock, see batch_timed),
         # kernel time from the library's HIP events beside it
         stages = {}
-        for key, wl, sec, bound in (("cfg2", "sos", 60.0, "hbm"), ("cfg3", "fir", 60.0, "mfma"), ("cfg4", "fftconv", 600.0, "hbm")):
+        for key, wl, sec, bound in (("cfg2", "sos", 60.0, "hbm"), ("cfg2_precision_auto", "sos_auto", 60.0, "hbm"),
+                                    ("cfg3", "fir", 60.0, "mfma"), ("cfg4", "fftconv", 600.0, "hbm")):
             try:
                 xs = x if sec == seconds else x[:, : int(sec * FS)].contiguous()
                 sstep, sdesc, _ = make_step(wl, xs)

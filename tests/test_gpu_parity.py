@@ -1198,3 +1198,36 @@ def test_epilogue_statistics_and_golden_mix(golden):
         w = w | m
     assert [type(m).__name__ for m in w.plan()] == ["Epilogued", "FusedSOSCascade"]
     close(w.ys, g["mix_y"], TOL_IIR_F32OUT * 2, "reference mixed pipeline, gain as an epilogue")
+
+
+@pytest.mark.parametrize("case", ["cfg2", "butter4@2k", "hp4@300", "notchQ30", "peq100"])
+def test_precision_auto_estimate_bounds_the_measured_float32_error(case):
+    """precision="auto": the host-side estimate (replay of the float32 kernel arithmetic, x 2.5) must bound the
+    error the float32 recursion really makes on the device, and "auto" must pick float32 only below 2e-5."""
+    from scipy.signal import butter
+    from torchfx_amd import filter as F
+
+    def sos_of(*fs):
+        for f in fs:
+            f.fs = 48000
+            f.compute_coefficients()
+        return torch.cat([f._sos for f in fs])
+    sos = {"cfg2": lambda: sos_of(F.LoButterworth(2000, order=6), F.ParametricEQ(frequency=1000, q=2.0, gain=3.0)),
+           "butter4@2k": lambda: torch.from_numpy(butter(4, 2000 / 24000, output="sos")),
+           "hp4@300": lambda: sos_of(F.HiButterworth(300, order=4)),
+           "notchQ30": lambda: sos_of(F.Notch(1000, 30.0)),
+           "peq100": lambda: sos_of(F.ParametricEQ(frequency=100, q=4.0, gain=12.0))}[case]()
+    info = ext().sos_plan_info(sos)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.rand(8, 1_500_000, device=DEV, generator=g) * 2 - 1
+    y64 = ext().sos_forward(x, None, sos, None, None, out_dtype=torch.float64, precision="f64")[0]
+    y32 = ext().sos_forward(x, None, sos, None, None, precision="f32")[0]
+    ya = ext().sos_forward(x, None, sos, None, None, precision="auto")[0]
+    scale = max(1.0, float(y64.abs().max()))
+    err32 = float((y32.double() - y64).abs().max()) / scale
+    assert err32 <= info["f32_error_bound"], (case, err32, info)
+    erra = float((ya.double() - y64).abs().max()) / scale
+    if info["auto_precision"] == "f32":
+        assert info["f32_error_bound"] <= 2e-5 and torch.equal(ya, y32)
+    else:
+        assert erra <= 1.5e-7                      # auto stayed in float64: one ulp of the float32 output

@@ -414,3 +414,20 @@ def test_parallel_combination_routing(oracle_backend):
     oracle_backend.calls.clear()
     mixed(x)
     assert [k[0] for k in oracle_backend.calls][-1] == "sum_forward"
+
+
+def test_precision_auto_estimate_is_a_replay_of_the_float32_kernel():
+    """tfx_sos_plan_info's float32 error estimate (host replay of the kernel's float32 arithmetic): tiny for
+    well-conditioned cascades, enormous for poles next to z = 1, and 'auto' draws the line at 2e-5."""
+    import scipy.signal as sg
+    from torchfx_amd import torchfx_ext as E
+    easy = E.sos_plan_info(sg.butter(4, 2000 / 24000, output="sos"))
+    assert easy["auto_precision"] == "f32" and 1e-7 < easy["f32_error_bound"] < 5e-6
+    dc = E.sos_plan_info(sg.butter(2, 20 / 24000, "highpass", output="sos"))          # poles at radius 0.998, 20 Hz
+    assert dc["auto_precision"] == "f64" and dc["f32_error_bound"] > 1e-2
+    f1, f2 = F.LoButterworth(2000, order=6, fs=48000), F.ParametricEQ(frequency=1000, q=2.0, gain=3.0, fs=48000)
+    f1.compute_coefficients(), f2.compute_coefficients()
+    cfg2 = E.sos_plan_info(torch.cat([f1._sos, f2._sos]))
+    assert cfg2["auto_precision"] == "f32" and 5e-6 < cfg2["f32_error_bound"] < 2e-5   # measured on the device: 6.2e-6
+    unstable = E.sos_plan_info(np.array([[1.0, 0, 0, 1, -2.1, 1.2]]))
+    assert unstable["auto_precision"] == "f64"
