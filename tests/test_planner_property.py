@@ -45,8 +45,8 @@ def build(spec):
 
 @settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
 @given(specs=st.lists(step, min_size=1, max_size=7), fuse_fir=st.booleans(), fuse_gain=st.booleans(),
-       fuse_spectral=st.booleans(), seed=st.integers(0, 1000))
-def test_planned_pipeline_equals_stepwise(oracle_backend, specs, fuse_fir, fuse_gain, fuse_spectral, seed):
+       fuse_spectral=st.booleans(), fuse_epilogue=st.booleans(), seed=st.integers(0, 1000))
+def test_planned_pipeline_equals_stepwise(oracle_backend, specs, fuse_fir, fuse_gain, fuse_spectral, fuse_epilogue, seed):
     x = torch.from_numpy(np.random.default_rng(seed).standard_normal((2, 600)).astype(np.float32))
     # reference semantics: every module applied in order, fresh state
     cur = x
@@ -59,7 +59,7 @@ def test_planned_pipeline_equals_stepwise(oracle_backend, specs, fuse_fir, fuse_
         cur = m(cur)
         staged_calls += len(oracle_backend.calls)
     w = fx.Wave(x, FS)
-    w.fuse_fir, w.fuse_gain, w.fuse_spectral = fuse_fir, fuse_gain, fuse_spectral
+    w.fuse_fir, w.fuse_gain, w.fuse_spectral, w.fuse_epilogue = fuse_fir, fuse_gain, fuse_spectral, fuse_epilogue
     for s in specs:
         w = w | build(s)
     plan = w.plan()
@@ -69,7 +69,7 @@ def test_planned_pipeline_equals_stepwise(oracle_backend, specs, fuse_fir, fuse_
     assert y.shape == cur.shape and y.dtype == cur.dtype
     assert float((y - cur).abs().max()) <= 3e-6 * scale, [type(m).__name__ for m in plan]
     assert len(oracle_backend.calls) <= staged_calls
-    if not fuse_fir and not fuse_gain and not fuse_spectral:
+    if not fuse_fir and not fuse_gain and not fuse_spectral and not fuse_epilogue:
         # default plan: only IIR runs are fused, exactly like the reference's _materialize
         kinds = ["i" if s[0] in ("lo", "hi", "peq", "bq") else "o" for s in specs]
         runs = sum(1 for i, k in enumerate(kinds) if k == "i" and (i == 0 or kinds[i - 1] != "i"))

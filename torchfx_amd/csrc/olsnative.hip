@@ -624,6 +624,8 @@ struct NativePlan {
 };
 static std::mutex g_np_mu;
 static std::map<std::vector<char>, NativePlan *> g_nplans;
+static NativePlan *g_last_plan[TFX_MAX_DEVICES] = {};          // per device: the plan used last and its key
+static std::vector<char> g_last_key[TFX_MAX_DEVICES];
 
 static void host_fft(std::vector<double> &re, std::vector<double> &im)   // in-place radix-2, forward
 {
@@ -669,13 +671,26 @@ static std::vector<cpx> twiddles(int64_t n, int64_t count, int64_t step)   // W_
 
 static NativePlan *get_native_plan(const float *kf, int64_t K, int64_t N, int64_t lead)
 {
+    // steady state (the same filter call after call, e.g. streaming chunks): one memcmp against the plan
+    // used last, no key construction
+    NativePlan **last = g_last_plan;
+    std::vector<char> *last_key = g_last_key;
+    const int dev_ = current_device();
+    {
+        const std::vector<char> &lk = last_key[dev_];
+        const size_t nb = (size_t)K * sizeof(float);
+        if (last[dev_] && lk.size() == nb + 2 * sizeof(int64_t) + 1 && memcmp(lk.data(), kf, nb) == 0 &&
+            memcmp(lk.data() + nb, &N, sizeof(N)) == 0 && memcmp(lk.data() + nb + sizeof(N), &lead, sizeof(lead)) == 0)
+            return last[dev_];
+    }
     std::vector<char> key((const char *)kf, (const char *)kf + K * sizeof(float));
     key.insert(key.end(), (const char *)&N, (const char *)&N + sizeof(N));
     key.insert(key.end(), (const char *)&lead, (const char *)&lead + sizeof(lead));
     key.push_back((char)current_device());
     auto it = g_nplans.find(key);
-    if (it != g_nplans.end()) return it->second;
+    if (it != g_nplans.end()) { last[dev_] = it->second; last_key[dev_] = key; return it->second; }
     if (g_nplans.size() > 16) {
+        for (int d = 0; d < TFX_MAX_DEVICES; ++d) last[d] = nullptr;
         (void)hipDeviceSynchronize();
         for (auto &kv : g_nplans) {
             NativePlan *p = kv.second;
@@ -718,6 +733,7 @@ static NativePlan *get_native_plan(const float *kf, int64_t K, int64_t N, int64_
     }
     pl->t4hi = upload_cpx(twiddles(4096, 64, 64));
     g_nplans[key] = pl;
+    last[dev_] = pl; last_key[dev_] = key;
     return pl;
 }
 
@@ -731,6 +747,7 @@ void olsnative_clear()
         delete p;
     }
     g_nplans.clear();
+    for (int d = 0; d < TFX_MAX_DEVICES; ++d) g_last_plan[d] = nullptr;
 }
 
 static int64_t envi(const char *name, int64_t dflt)
