@@ -1231,3 +1231,26 @@ def test_precision_auto_estimate_bounds_the_measured_float32_error(case):
         assert info["f32_error_bound"] <= 2e-5 and torch.equal(ya, y32)
     else:
         assert erra <= 1.5e-7                      # auto stayed in float64: one ulp of the float32 output
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_non_finite_input_poisons_the_rest_of_the_row_like_the_sequential_recursion(bad, monkeypatch):
+    """iir_cpu.cpp:132-147: once a NaN / Inf is in the state it never leaves.  The time-segmented launch must give
+    the same picture -- finite before the bad sample, non-finite from it to the end of the row and in the
+    returned state, other rows untouched -- for any number of segments."""
+    from scipy.signal import butter
+    sos = torch.from_numpy(np.vstack([butter(6, 2000 / 24000, output="sos"), [[1.0089, -1.9636, 0.9695, 1, -1.9636, 0.9784]]]))
+    x = rnd((3, 400_000), 31)
+    pos = 123_457
+    x[1, pos] = bad
+    ref, _, refs = O.sos_forward(x, sos.numpy())
+    for nseg in ("1", "8", "0"):                                   # 0 = the launch's own choice
+        monkeypatch.setenv("TFX_SOS_NSEG", nseg)
+        y, sx, sy = ext().sos_forward(dev(x), None, sos, None, None)
+        y = y.cpu().numpy()
+        assert np.isfinite(y[0]).all() and np.isfinite(y[2]).all() and np.isfinite(y[1, :pos]).all(), nseg
+        assert not np.isfinite(y[1, pos:]).any(), nseg
+        assert not np.isfinite(sy[:, 1].cpu().numpy()).any() and np.isfinite(sy[:, 0].cpu().numpy()).all(), nseg
+        for c in (0, 2):
+            assert np.abs(y[c] - ref[c].astype(np.float32)).max() <= 1.5e-7 * max(1.0, np.abs(ref[c]).max())
+    assert not np.isfinite(ref[1, pos:]).any() and not np.isfinite(refs[:, 1]).any()     # the oracle agrees

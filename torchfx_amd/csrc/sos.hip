@@ -462,6 +462,41 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
     }
 }
 
+// Non-finite samples and time segmentation.  In the sequential recursion a NaN / Inf never leaves: once the
+// state is non-finite every later output of the row is (iir_cpu.cpp:132-147).  A segment that starts from its
+// warm-up halo does not see what happened before the halo, so after the main launch every segment g > 0 checks
+// whether an earlier segment of its row ENDED non-finite and, if so, overwrites itself (and, for the last
+// segment, the returned states) with NaN -- "non-finite from the first bad sample to the end of the row",
+// independent of how many segments the launch used.  Finite signals: one tiny launch that reads nseg samples
+// per workgroup and exits.
+template <typename TOut>
+__global__ void __launch_bounds__(256) sos_nonfinite_fix_kernel(TOut *__restrict__ y, int64_t C, int64_t T, int64_t seg_len,
+                                                                int nseg, double *sx_out, double *sy_out, int K)
+{
+    __shared__ int bad;
+    const int64_t row = blockIdx.x / (nseg - 1);
+    const int g = (int)(blockIdx.x % (nseg - 1)) + 1;
+    const int64_t begin = (int64_t)g * seg_len;
+    if (begin >= T) return;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    for (int q = threadIdx.x; q < g; q += 256) {
+        const int64_t e = (int64_t)(q + 1) * seg_len - 1;
+        const double v = (double)y[row * T + (e < T ? e : T - 1)];
+        if (!(fabs(v) <= 1.79e308)) bad = 1;             // NaN or Inf
+    }
+    __syncthreads();
+    if (!bad) return;
+    const int64_t end = begin + seg_len < T ? begin + seg_len : T;
+    const TOut nanv = (TOut)__builtin_nan("");
+    for (int64_t n = begin + threadIdx.x; n < end; n += 256) y[row * T + n] = nanv;
+    if (end == T && threadIdx.x < 2 * K) {
+        const int sct = threadIdx.x >> 1, f = threadIdx.x & 1;
+        if (sx_out) sx_out[((int64_t)sct * C + row) * 2 + f] = __builtin_nan("");
+        if (sy_out) sy_out[((int64_t)sct * C + row) * 2 + f] = __builtin_nan("");
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Host side: tables and plan cache
 // ------------------------------------------------------------------------------------------
@@ -874,6 +909,11 @@ static void launch_one(SosParams p, int64_t plan_warm, hipStream_t stream)
     {
         ProfScope ps(sizeof(TC) == 8 ? "sos_stream_kernel<f64>" : "sos_stream_kernel<f32>", stream);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, stream, p);
+        TFX_HIP(hipGetLastError());
+    }
+    if (p.nseg > 1 && !TAPS && !SUMB && p.C == p.C_in) {       // see sos_nonfinite_fix_kernel
+        hipLaunchKernelGGL(sos_nonfinite_fix_kernel<TOut>, dim3((unsigned)(p.C * (p.nseg - 1))), dim3(256), 0, stream, (TOut *)p.y,
+                           p.C, p.T, p.seg_len, p.nseg, p.sx_out, p.sy_out, p.K);
         TFX_HIP(hipGetLastError());
     }
     if (p.ep_stat >= 0) {
