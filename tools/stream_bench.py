@@ -18,7 +18,8 @@ def make():
             StatefulFIR(taps, "fft"), E.Gain(0.8, clamp=True)]
 
 
-for C, chunk in ((2, 512), (2, 4096), (2, 65536), (16, 4096)):
+print("StreamProcessor: LoButterworth-4 | ParametricEQ | StatefulFIR-301 (fft) | Gain(clamp), per-chunk latency")
+for C, chunk in ((2, 512), (2, 1024), (2, 2048), (2, 4096), (2, 8192), (2, 16384), (2, 32768), (2, 65536), (16, 4096), (64, 4096)):
     x = torch.randn(C, chunk * 400, device="cuda:0")
     res = {}
     for g in (False, True):
