@@ -1039,11 +1039,16 @@ def test_bench_two_ranks_on_one_device(tmp_path):
     import os
     import subprocess
     import sys
+    import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, TFX_BENCH_SHARE_DEVICE="1")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = str(sock.getsockname()[1])
+    sock.close()
     for extra, scaling, chans in ((["--channels", "4"], "weak", 4), (["--scaling", "strong", "--total-channels", "6"], "strong", 3)):
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                            "127.0.0.1", "--master-port", "29653", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+                            "127.0.0.1", "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
                             "--warmup", "1", "--seconds", "30", "--gather"] + extra,
                            env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
