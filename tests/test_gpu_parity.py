@@ -1259,3 +1259,25 @@ def test_non_finite_input_poisons_the_rest_of_the_row_like_the_sequential_recurs
         for c in (0, 2):
             assert np.abs(y[c] - ref[c].astype(np.float32)).max() <= 1.5e-7 * max(1.0, np.abs(ref[c]).max())
     assert not np.isfinite(ref[1, pos:]).any() and not np.isfinite(refs[:, 1]).any()     # the oracle agrees
+
+
+def test_two_devices_in_one_process_keep_their_own_caches():
+    """Every device-side cache is keyed by the device ordinal (plans, taps, spectra, scratch, internal streams):
+    the same filters driven alternately on cuda:0 and cuda:1 from ONE process give the single-device results.
+    Needs two visible devices; on the one-GPU builder box it is skipped (the driver's multi-GPU node runs it)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two devices")
+    from scipy.signal import butter
+    sos = torch.from_numpy(butter(6, 2000 / 24000, output="sos"))
+    k = torch.from_numpy((np.hanning(513) / np.hanning(513).sum()).astype(np.float32))
+    x = torch.from_numpy(rnd((4, 200_000), 41))
+    ref = None
+    for rep in range(2):
+        for d in ("cuda:0", "cuda:1", "cuda:0"):
+            xd = x.to(d)
+            y = ext().fft_conv_forward(ext().sos_forward(xd, None, sos, None, None)[0], k, (512, 0))
+            yd = ext().fir_direct_forward(xd, k)
+            out = torch.cat([y, yd]).cpu()
+            if ref is None:
+                ref = out
+            assert torch.equal(out, ref), (rep, d)
