@@ -43,7 +43,7 @@ def main():
         sos_t = torch.from_numpy(sos)
         print("plan", E.sos_plan_info(sos))
         for prec in ("f64", "f32"):
-            for var in (0, 1, 2, 3):
+            for var in (0, 1, 2, 3, 4, 5):
                 for wpc in (0, 8):
                     os.environ["TFX_SOS_VARIANT"] = str(var)
                     os.environ["TFX_SOS_WAVES_PER_CU"] = str(wpc)

@@ -505,13 +505,15 @@ typedef long double ld;
 struct SosPlan {
     int K = 0;          // sections per band
     int NB = 1;         // bands (filter-bank mode: independent SOS sets sharing the input)
-    int nsteps32 = 6, nsteps16 = 6;
+    int nsteps32 = 6, nsteps16 = 6, nsteps64 = 6;
     int64_t warm = -1;            // samples; -1 = too long / not decaying
     double err_bound_f32 = -1.0;  // worst-case |err| of f32 arithmetic for |x| <= 1 (lazy)
     void *tab_f64_lc32 = nullptr; // device
     void *tab_f32_lc32 = nullptr;
     void *tab_f64_lc16 = nullptr;
     void *tab_f32_lc16 = nullptr;
+    void *tab_f64_lc64 = nullptr;
+    void *tab_f32_lc64 = nullptr;
     std::vector<double> sos;
 };
 
@@ -746,7 +748,7 @@ static double f32_error_bound(const std::vector<double> &sos, int K)
 
 static void free_plan(SosPlan *pl)
 {
-    void *t[4] = {pl->tab_f64_lc32, pl->tab_f32_lc32, pl->tab_f64_lc16, pl->tab_f32_lc16};
+    void *t[6] = {pl->tab_f64_lc32, pl->tab_f32_lc32, pl->tab_f64_lc16, pl->tab_f32_lc16, pl->tab_f64_lc64, pl->tab_f32_lc64};
     for (void *q : t) if (q) (void)hipFree(q);
     delete pl;
 }
@@ -938,14 +940,17 @@ static void launch_main(const SosParams &p, bool vec, int variant, int64_t nstre
         }
         return;
     }
-    if (p.ep_fused) {          // epilogue instantiation: one register-budget step below the plain kernel
-        launch_one<TIn, TOut, TC, 32, true, false, true, 2, false, true>(p, nstreams, stream);
+    if (p.ep_fused) {          // epilogue instantiation: same tile geometry as the plain kernel (bit-identical cascade output)
+        if (variant >= 4) launch_one<TIn, TOut, TC, 64, true, false, false, F32 ? 3 : 2, false, true>(p, nstreams, stream);
+        else launch_one<TIn, TOut, TC, 32, true, false, true, 2, false, true>(p, nstreams, stream);
         return;
     }
     switch (variant) {
     case 1: launch_one<TIn, TOut, TC, 16, true, false, false, F32 ? 8 : 5>(p, nstreams, stream); break;
     case 2: launch_one<TIn, TOut, TC, 32, true, false, true, F32 ? 4 : 2>(p, nstreams, stream); break;
     case 3: launch_one<TIn, TOut, TC, 16, true, false, true, F32 ? 6 : 4>(p, nstreams, stream); break;
+    case 4: launch_one<TIn, TOut, TC, 64, true, false, false, F32 ? 3 : 2>(p, nstreams, stream); break;   // 64 samples per lane: half the scan per sample
+    case 5: launch_one<TIn, TOut, TC, 64, true, false, true, F32 ? 3 : 1>(p, nstreams, stream); break;
     default: launch_one<TIn, TOut, TC, 32, true, false, false, F32 ? 5 : 3>(p, nstreams, stream); break;
     }
 }
@@ -1014,8 +1019,18 @@ void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C_in,
     if (x_dtype == TFX_F64 || y_dtype == TFX_F64) prec = TFX_PREC_F64;   // f64 signals: always f64 math
     const bool rare = !(x_dtype == TFX_F32 && y_dtype == TFX_F32);
 
-    const int variant = (rare || sum_bands) ? 1 : env_int("TFX_SOS_VARIANT", 2);   // 2 = LC32 + register prefetch: measured best
-    const int LC = (variant & 1) ? 16 : 32;
+    // float32 arithmetic: LC = 32 + register prefetch (4 waves per SIMD); float64: LC = 64 -- the kernel is bound by VALU
+    // issue (1440 instructions per 2048-sample tile, ~100 % busy at 3 waves per SIMD), and 64 samples per lane halve the
+    // scan's share per sample (0.352 vs 0.38-0.42 ms at cfg 2 on the same box)
+    int variant = (rare || sum_bands) ? 1 : env_int("TFX_SOS_VARIANT", -1);
+    if (variant < 0) variant = (prec == TFX_PREC_F32) ? 2 : 4;
+    {
+        const int xs_ = x_dtype == TFX_F32 ? 4 : 8, ys_ = y_dtype == TFX_F32 ? 4 : 8;
+        const bool vec_ = (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0) && ((T * xs_) % 16 == 0) && ((T * ys_) % 16 == 0);
+        if (variant >= 4 && (y_sections || !vec_)) variant = 2;               // LC = 64 exists for the aligned path without taps
+        if (variant >= 4 && ep->any()) variant = 4;                           // (its epilogue instantiation: no register prefetch)
+    }
+    const int LC = variant >= 4 ? 64 : ((variant & 1) ? 16 : 32);
     SosParams p{};
     p.x = x; p.y = y; p.taps = y_sections;
     p.sx_in = sx_in; p.sy_in = sy_in; p.sx_out = sx_out; p.sy_out = sy_out;
@@ -1037,15 +1052,15 @@ void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C_in,
                      ((T * xsz) % 16 == 0) && ((T * ysz) % 16 == 0);
 
     if (prec == TFX_PREC_F32) {
-        p.tab = ensure_table<float>(pl, LC == 32 ? &pl->tab_f32_lc32 : &pl->tab_f32_lc16, LC,
-                                    LC == 32 ? &pl->nsteps32 : &pl->nsteps16, stream);
-        p.nsteps = LC == 32 ? pl->nsteps32 : pl->nsteps16;
+        p.tab = ensure_table<float>(pl, LC == 64 ? &pl->tab_f32_lc64 : (LC == 32 ? &pl->tab_f32_lc32 : &pl->tab_f32_lc16), LC,
+                                    LC == 64 ? &pl->nsteps64 : (LC == 32 ? &pl->nsteps32 : &pl->nsteps16), stream);
+        p.nsteps = LC == 64 ? pl->nsteps64 : (LC == 32 ? pl->nsteps32 : pl->nsteps16);
         if (sum_bands) launch_sum<float, float, float>(p, vec, nstreams, stream);
         else launch_main<float, float, float>(p, vec, variant, nstreams, stream);
     } else {
-        p.tab = ensure_table<double>(pl, LC == 32 ? &pl->tab_f64_lc32 : &pl->tab_f64_lc16, LC,
-                                     LC == 32 ? &pl->nsteps32 : &pl->nsteps16, stream);
-        p.nsteps = LC == 32 ? pl->nsteps32 : pl->nsteps16;
+        p.tab = ensure_table<double>(pl, LC == 64 ? &pl->tab_f64_lc64 : (LC == 32 ? &pl->tab_f64_lc32 : &pl->tab_f64_lc16), LC,
+                                     LC == 64 ? &pl->nsteps64 : (LC == 32 ? &pl->nsteps32 : &pl->nsteps16), stream);
+        p.nsteps = LC == 64 ? pl->nsteps64 : (LC == 32 ? pl->nsteps32 : pl->nsteps16);
         if (sum_bands) {
             if (x_dtype == TFX_F32 && y_dtype == TFX_F32) launch_sum<float, float, double>(p, vec, nstreams, stream);
             else if (x_dtype == TFX_F64 && y_dtype == TFX_F64) launch_sum<double, double, double>(p, vec, nstreams, stream);
