@@ -131,11 +131,16 @@ fir_direct_mfma_kernel(const float *__restrict__ x, float *__restrict__ y,
                             (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pw);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             (void *)pu, 0, __builtin_amdgcn_readfirstlane((int)((gend - gstart) * 4)), 0x00020000);
+        // Interior tiles (window entirely inside the row: all but the first and last tile or two of a row): ONE
+        // per-lane offset and a scalar offset per load -- no 68 address registers (the per-load clamped offsets of
+        // the general form made this kernel spill 292 VGPRs = 4.6 x the output bytes of scratch traffic).  The scalar
+        // offset is not part of the hardware range check, so tiles that touch either end of the row take the
+        // partially unrolled loop below, where the range check and the clamp do their work.
+        const bool interior = (shift == 0) && (gend0 <= T);  // workgroup-uniform
+        if (interior) {
 #pragma unroll
-        for (int r = 0; r < XV; ++r) {
-            const int e = shift + tid + 256 * r;
-            xv[r] = (DBG & 2) ? 1.0f
-                              : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (e < 0 ? 0 : e) * 4, 0, 0));
+            for (int r = 0; r < XV; ++r)
+                xv[r] = (DBG & 2) ? 1.0f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, tid * 4, r * 1024, 0));
         }
 #pragma unroll
         for (int r = 0; r < KV; ++r) {
@@ -145,16 +150,23 @@ fir_direct_mfma_kernel(const float *__restrict__ x, float *__restrict__ y,
         }
         __builtin_amdgcn_sched_barrier(0);   // keep every load above, every use below
         __syncthreads();    // previous chunk's readers are done
+        if (interior) {
 #pragma unroll
-        for (int r = 0; r < XV; ++r) {
-            const int m = tid + 256 * r;
-            if (m < XW) {
-                float v = xv[r];
-                if (shift + m < 0) {                         // before the row start (first tiles only)
+            for (int r = 0; r < XV; ++r) {
+                const int m = tid + 256 * r;
+                if (m < XW) xw[xpad33(m)] = xv[r];
+            }
+        } else {
+#pragma unroll 2
+            for (int r = 0; r < XV; ++r) {
+                const int m = tid + 256 * r;
+                const int e = shift + m;
+                float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (e < 0 ? 0 : e) * 4, 0, 0));
+                if (e < 0) {                                 // before the row start (first tiles only)
                     const int64_t g = base + m;              // < 0
                     v = (hist && g >= -(int64_t)H) ? hist[c * H + H + g] : 0.0f;
                 }
-                xw[xpad33(m)] = v;
+                if (m < XW) xw[xpad33(m)] = v;
             }
         }
 #pragma unroll
