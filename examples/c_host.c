@@ -1,0 +1,70 @@
+/* A non-torch host of the C ABI (include/torchfx_hip.h), plain C99: what a cgo / JNI / FFI binding would call.
+ *
+ *   gcc -std=c99 -I include examples/c_host.c -L torchfx_amd -ltorchfx_hip -Wl,-rpath,$PWD/torchfx_amd -o c_host
+ *
+ * Without arguments it only uses the host-side entry points (plan queries; runs on a machine without a GPU --
+ * tests/test_capi_exports.py builds and runs it that way).  With `--gpu` it also filters a buffer on device 0
+ * through tfx_sos_forward using the HIP runtime for memory (link with -lamdhip64 and define WITH_HIP).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "torchfx_hip.h"
+
+#ifdef WITH_HIP
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#endif
+
+/* 2nd-order Butterworth low-pass at fc/fs = 1/12 and a peaking section, [K, 6] rows b0 b1 b2 1 a1 a2 */
+static const double SOS[2][6] = {
+    {0.0495329964, 0.0990659928, 0.0495329964, 1.0, -1.2796324250, 0.4777644106},
+    {1.0089, -1.9636, 0.9695, 1.0, -1.9636, 0.9784},
+};
+
+int main(int argc, char **argv)
+{
+    int precision = -1, native = -1;
+    int64_t warm = 0, N = 0, S = 0, F = 0;
+    double bound = 0.0;
+    printf("tfx_version %d\n", tfx_version());
+    if (tfx_sos_plan_info(&SOS[0][0], 2, &precision, &warm, &bound) != 0) {
+        fprintf(stderr, "tfx_sos_plan_info: %s\n", tfx_last_error());
+        return 1;
+    }
+    printf("cascade plan: auto precision %s, warm-up halo %lld samples, float32 error estimate %.3g\n",
+           precision == TFX_PREC_F32 ? "f32" : "f64", (long long)warm, bound);
+    if (tfx_ols_plan_info(65536, 28800000, 65535, 0, &N, &S, &F, &native) != 0) {
+        fprintf(stderr, "tfx_ols_plan_info: %s\n", tfx_last_error());
+        return 1;
+    }
+    printf("overlap-save plan: N %lld hop %lld blocks/row %lld native %d\n", (long long)N, (long long)S, (long long)F, native);
+    /* error path: a null coefficient pointer is an error code, not a crash */
+    if (tfx_sos_plan_info(NULL, 2, &precision, &warm, &bound) == 0) {
+        fprintf(stderr, "expected an error for a null SOS pointer\n");
+        return 1;
+    }
+    printf("null pointer -> \"%s\"\n", tfx_last_error());
+#ifdef WITH_HIP
+    if (argc > 1 && strcmp(argv[1], "--gpu") == 0) {
+        const int64_t C = 2, T = 48000;
+        float *hx = (float *)malloc(sizeof(float) * C * T), *hy = (float *)malloc(sizeof(float) * C * T);
+        float *dx = NULL, *dy = NULL;
+        for (int64_t i = 0; i < C * T; ++i) hx[i] = (i % T == 0) ? 1.0f : 0.0f;      /* unit impulses */
+        if (hipMalloc((void **)&dx, sizeof(float) * C * T) != hipSuccess || hipMalloc((void **)&dy, sizeof(float) * C * T) != hipSuccess) return 2;
+        hipMemcpy(dx, hx, sizeof(float) * C * T, hipMemcpyHostToDevice);
+        if (tfx_sos_forward(dx, TFX_F32, dy, TFX_F32, C, T, &SOS[0][0], 2, NULL, NULL, NULL, NULL, NULL, TFX_PREC_F64, NULL) != 0) {
+            fprintf(stderr, "tfx_sos_forward: %s\n", tfx_last_error());
+            return 1;
+        }
+        hipDeviceSynchronize();
+        hipMemcpy(hy, dy, sizeof(float) * C * T, hipMemcpyDeviceToHost);
+        printf("impulse response head: %.6f %.6f %.6f %.6f\n", hy[0], hy[1], hy[2], hy[3]);
+        hipFree(dx); hipFree(dy); free(hx); free(hy);
+    }
+#else
+    (void)argc; (void)argv;
+#endif
+    return 0;
+}

@@ -134,3 +134,26 @@ def test_bad_arguments_are_errors_not_crashes():
     # empty work is fine and touches nothing
     assert lib.tfx_gain_forward(None, None, 0, 0, 1.0, 0, None) == 0
     assert lib.tfx_sos_forward(None, 0, None, 0, 0, 100, sos, 1, None, None, None, None, None, 2, None) == 0
+
+
+def _build_c_host(tmp_path, with_hip=False):
+    """examples/c_host.c: a plain-C99 host of the C ABI, compiled with gcc against include/torchfx_hip.h."""
+    from torchfx_amd import _lib
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = str(tmp_path / "c_host")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include")]
+    if with_hip:
+        cmd += ["-DWITH_HIP", "-I", "/opt/rocm/include"]
+    cmd += [os.path.join(ROOT, "examples", "c_host.c"), "-L", libdir, "-ltorchfx_hip", f"-Wl,-rpath,{libdir}"]
+    if with_hip:
+        cmd += ["-L", "/opt/rocm/lib", "-lamdhip64"]
+    cmd += ["-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    return exe
+
+
+def test_plain_c_host_builds_and_runs_without_a_gpu(tmp_path):
+    exe = _build_c_host(tmp_path)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert "tfx_version" in out and "overlap-save plan: N 1048576" in out
+    assert "null pointer ->" in out            # error code + message instead of a crash

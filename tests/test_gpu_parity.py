@@ -1281,3 +1281,17 @@ def test_two_devices_in_one_process_keep_their_own_caches():
             if ref is None:
                 ref = out
             assert torch.equal(out, ref), (rep, d)
+
+
+def test_plain_c_host_filters_on_the_device(tmp_path):
+    """examples/c_host.c --gpu: hipMalloc + tfx_sos_forward from C99, no torch in the process."""
+    import subprocess
+    from scipy.signal import sosfilt
+    from tests.test_capi_exports import _build_c_host
+    exe = _build_c_host(tmp_path, with_hip=True)
+    out = subprocess.run([exe, "--gpu"], check=True, capture_output=True, text=True).stdout
+    head = [float(v) for v in out.split("impulse response head:")[1].split()[:4]]
+    sos = np.array([[0.0495329964, 0.0990659928, 0.0495329964, 1.0, -1.2796324250, 0.4777644106],
+                    [1.0089, -1.9636, 0.9695, 1.0, -1.9636, 0.9784]])
+    imp = np.zeros(8); imp[0] = 1.0
+    np.testing.assert_allclose(head, sosfilt(sos, imp)[:4], rtol=0, atol=2e-6)
