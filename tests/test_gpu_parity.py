@@ -185,6 +185,28 @@ def test_time_segmentation_is_exact(monkeypatch):
         close(sy2, sy1.cpu().numpy(), 1e-13, f"nseg={nseg} state")
 
 
+@pytest.mark.parametrize("T", [257, 300, 2304, 4351, 4353, 10_000, 12_345, 65_536, 100_003])
+def test_time_segmentation_geometry_edges(T, monkeypatch):
+    """The halo is part of every stream's tile grid (stream g starts at g * (tiles * TILE - warm)): lengths around the
+    halo / tile boundaries, rows that are not 16-byte aligned (dword path), carried-in states, every tile size."""
+    from scipy.signal import butter
+    rng = np.random.default_rng(T)
+    sos = np.vstack([butter(4, 0.2, output="sos"), butter(2, 0.05, "highpass", output="sos")])
+    K = sos.shape[0]
+    x = dev(rnd((3, T), T).astype(np.float64))
+    sx0, sy0 = dev(rng.standard_normal((K, 3, 2))), dev(rng.standard_normal((K, 3, 2)))
+    for variant in ("2", "4", "1"):
+        monkeypatch.setenv("TFX_SOS_VARIANT", variant)
+        monkeypatch.setenv("TFX_SOS_NSEG", "1")
+        y1, sx1, sy1 = ext().sos_forward(x, None, torch.from_numpy(sos), sx0, sy0)
+        for nseg in ("2", "3", "5", "17", "64"):
+            monkeypatch.setenv("TFX_SOS_NSEG", nseg)
+            y2, sx2, sy2 = ext().sos_forward(x, None, torch.from_numpy(sos), sx0, sy0)
+            close(y2, y1.cpu().numpy(), 1e-13, f"T={T} variant={variant} nseg={nseg}")
+            close(sx2, sx1.cpu().numpy(), 1e-13, f"T={T} variant={variant} nseg={nseg} state_x")
+            close(sy2, sy1.cpu().numpy(), 1e-13, f"T={T} variant={variant} nseg={nseg} state_y")
+
+
 def test_long_memory_filter_falls_back_to_sequential():
     """A pole pair at radius 0.999999 never decays within 2^26 samples -> nseg = 1, still exact."""
     r, th = 0.999999, 0.01
