@@ -983,6 +983,60 @@ def test_stream_processor_graph_replay_equals_eager(chunk, overlap):
     assert torch.equal(again, eager2.process_tensor(x, 48000))
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_realtime_processor_callback_on_device(use_graph):
+    """RealtimeProcessor (realtime/processor.py:253-292): host blocks from a backend callback go through pinned staging
+    to the device, through the chain (eager, or one replayed HIP graph per block) and back; consecutive callbacks
+    are one continuous signal (== the oracle on the whole signal), a staged parameter lands at the next boundary."""
+    from scipy.signal import firwin
+    from torchfx_amd import effect as E
+    from torchfx_amd import filter as F
+    from torchfx_amd.realtime import RealtimeProcessor, StatefulFIR, StreamConfig
+
+    class Backend:
+        def open_stream(self, config, callback=None):
+            self.config, self.callback = config, callback
+
+        def start(self): pass
+
+        def stop(self): pass
+
+        def close(self): pass
+
+        def fire(self, block):
+            out = torch.zeros(self.config.channels_out, block.shape[-1])
+            self.callback(block, out, block.shape[-1])
+            return out
+
+    B, nblocks = 512, 24
+    taps = firwin(257, 0.25).astype(np.float32)
+    lpf, fir, gain = F.LoButterworth(2000, order=4), StatefulFIR(taps.tolist(), "fft"), E.Gain(0.5)
+    be = Backend()
+    cfg = StreamConfig(sample_rate=48000, buffer_size=B, channels_in=2, channels_out=2)
+    x = rnd((2, B * nblocks + 200), 33)                      # the last block is ragged
+    xt = torch.from_numpy(x)
+    with RealtimeProcessor([lpf, fir, gain], be, cfg, device=DEV, use_graph=use_graph) as p:
+        outs = [be.fire(xt[:, i:i + B]) for i in range(0, B * 12, B)]
+        p.set_parameter("2.gain", 2.0)                        # lands at the next buffer boundary
+        outs += [be.fire(xt[:, i:i + B]) for i in range(B * 12, x.shape[-1], B)]
+        if use_graph:
+            assert p._runner._graph is not None
+    y = torch.cat(outs, dim=-1).numpy()
+    sos = lpf._sos.cpu().numpy()
+    e, _, _ = O.iir_module_forward(x, sos)                    # float32 in, float32 out
+    e = O.fir_direct(e.astype(np.float64), O.flipped_kernel(taps).astype(np.float64))
+    e[:, :B * 12] *= 0.5
+    e[:, B * 12:] *= 2.0
+    close(y, e.astype(np.float32), 2e-6, "callback stream")
+    # device tensors are taken as they are (no staging), mono goes to every output channel
+    be2 = Backend()
+    with RealtimeProcessor([E.Gain(2.0)], be2, StreamConfig(48000, 256, channels_in=1, channels_out=2), device=DEV):
+        m = dev(rnd((1, 256), 5))
+        out = torch.zeros(2, 256, device=DEV)
+        be2.callback(m, out, 256)
+        assert torch.equal(out[0], m[0] * 2.0) and torch.equal(out[1], m[0] * 2.0)
+
+
 def test_fft_conv_kernel_longer_than_the_native_limit():
     """600 001 taps is beyond the hand-written path (K <= 2^19): the rocFFT path takes over."""
     from scipy.signal import fftconvolve

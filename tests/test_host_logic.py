@@ -307,6 +307,118 @@ def test_stream_processor_chunked_equals_contiguous(oracle_backend):
         StreamProcessor([nn.Identity()])
 
 
+class _MockBackend:
+    """The reference's test double (tests/test_realtime.py:46-120): records the stream, lets the test fire callbacks."""
+
+    def __init__(self):
+        from torchfx_amd.realtime import AudioBackend
+        assert {"open_stream", "start", "stop", "close"} <= AudioBackend.__abstractmethods__
+        self.config = self.callback = None
+        self.start_count = self.stop_count = 0
+        self.closed = False
+
+    def open_stream(self, config, callback=None):
+        self.config, self.callback = config, callback
+
+    def start(self):
+        self.start_count += 1
+
+    def stop(self):
+        self.stop_count += 1
+
+    def close(self):
+        self.closed = True
+
+    def simulate_callback(self, x):
+        out = torch.zeros(self.config.channels_out, x.shape[-1], dtype=x.dtype)
+        self.callback(x, out, x.shape[-1])
+        return out
+
+
+def test_realtime_processor_surface_and_callback(oracle_backend):
+    """tests/test_realtime.py:376-575 of the reference, on the host mirror (device='cpu')."""
+    from torchfx_amd.effect import Gain
+    from torchfx_amd.realtime import RealtimeError, RealtimeProcessor, StreamConfig, StreamDirection
+    cfg = StreamConfig(sample_rate=48000, buffer_size=512, channels_in=2, channels_out=2)
+    assert cfg.direction is StreamDirection.DUPLEX and abs(cfg.latency_ms - 512 / 48000 * 1000) < 1e-9
+    assert StreamConfig(channels_in=0).direction is StreamDirection.OUTPUT
+    be = _MockBackend()
+    p = RealtimeProcessor([Gain(2.0)], be, cfg, device="cpu")
+    assert not p.is_running and len(p.effects) == 1 and p.config is cfg
+    assert abs(p.latency_ms - cfg.latency_ms) < 1e-12
+    with pytest.raises(RealtimeError, match="not running"):
+        p.stop()
+    p.start()
+    assert p.is_running and be.start_count == 1 and be.callback is not None
+    with pytest.raises(RealtimeError, match="already running"):
+        p.start()
+    x = torch.randn(2, 512)
+    close(be.simulate_callback(x), (x * 2.0).numpy(), 1e-7)
+    p.stop()
+    assert not p.is_running and be.stop_count == 1 and be.closed
+    # chains, nn.Sequential, the context manager (stops on exceptions too)
+    be = _MockBackend()
+    with RealtimeProcessor(nn.Sequential(Gain(2.0), Gain(0.5)), be, cfg, device="cpu") as p:
+        assert p.is_running and len(p.effects) == 2
+        close(be.simulate_callback(x), x.numpy(), 1e-7)
+    assert not p.is_running
+    be = _MockBackend()
+    with pytest.raises(RuntimeError, match="test error"):
+        with RealtimeProcessor([Gain(1.0)], be, cfg, device="cpu"):
+            raise RuntimeError("test error")
+    assert be.stop_count == 1
+    with pytest.raises(TypeError, match="inherit from FX"):
+        RealtimeProcessor([nn.Identity()], be, cfg, device="cpu")
+    # parameters are staged and applied at the next buffer boundary
+    g = Gain(1.0)
+    be = _MockBackend()
+    with RealtimeProcessor([g], be, cfg, device="cpu") as p:
+        p.set_parameter("0.gain", 0.5)
+        assert g.gain == 1.0
+        close(be.simulate_callback(x), (x * 0.5).numpy(), 1e-7)
+        assert g.gain == 0.5
+        p.set_parameter("7.gain", 3.0)          # bad index: ignored
+        be.simulate_callback(x)
+    # channel mismatch: mono to every output channel, truncation
+    be = _MockBackend()
+    with RealtimeProcessor([Gain(1.0)], be, StreamConfig(48000, 256, channels_in=1, channels_out=2), device="cpu"):
+        m = torch.randn(1, 256)
+        out = be.simulate_callback(m)
+        close(out[0], m[0].numpy(), 1e-7)
+        close(out[1], m[0].numpy(), 1e-7)
+    be = _MockBackend()
+    with RealtimeProcessor([Gain(1.0)], be, StreamConfig(48000, 256, channels_in=3, channels_out=2), device="cpu"):
+        m = torch.randn(3, 256)
+        close(be.simulate_callback(m), m[:2].numpy(), 1e-7)
+
+
+def test_realtime_processor_blocks_are_one_continuous_signal(oracle_backend):
+    """fs propagation, coefficient design at construction, carried state across callbacks, redesign + reset on a
+    filter parameter change (processor.py:96-101, 231-250)."""
+    from scipy.signal import firwin
+    from torchfx_amd.realtime import RealtimeProcessor, StatefulFIR, StreamConfig
+    cfg = StreamConfig(sample_rate=44100, buffer_size=256, channels_in=2, channels_out=2)
+    lpf = F.LoButterworth(2000, order=4)
+    fir = StatefulFIR(firwin(65, 0.3))
+    assert lpf.fs is None
+    be = _MockBackend()
+    p = RealtimeProcessor([lpf, fir], be, cfg, device="cpu")
+    assert lpf.fs == 44100 and lpf._has_computed_coeff
+    x = torch.randn(2, 256 * 9 + 100, generator=torch.Generator().manual_seed(9), dtype=torch.float64)
+    ref_l = F.LoButterworth(2000, order=4, fs=44100)
+    whole = StatefulFIR(firwin(65, 0.3))(ref_l(x))
+    with p:
+        blocks = [be.simulate_callback(x[:, i:i + 256]) for i in range(0, x.shape[-1], 256)]     # the last one is ragged
+        close(torch.cat(blocks, dim=-1), whole.numpy(), 1e-11)
+        # a new cutoff: redesigned, state cleared -> equals a fresh filter on the next block
+        p.set_parameter("0.cutoff", 500)
+        p.reset_state()
+        y = be.simulate_callback(x[:, :256])
+        fresh = StatefulFIR(firwin(65, 0.3))(F.LoButterworth(500, order=4, fs=44100)(x[:, :256]))
+        close(y, fresh.numpy(), 1e-11)
+        assert lpf.cutoff == 500
+
+
 def test_spectral_fusion_matches_staged(oracle_backend, golden):
     g = golden("chain")
     from scipy.signal import firwin

@@ -32,3 +32,39 @@ for C, chunk in ((2, 512), (2, 1024), (2, 2048), (2, 4096), (2, 8192), (2, 16384
         res[g] = (time.perf_counter() - t0) / 400 * 1e6
     print(f"[{C} x {chunk}] eager {res[False]:7.1f} us/chunk   graph {res[True]:7.1f} us/chunk   x{res[False] / res[True]:.2f}"
           f"   real-time factor at 48 kHz: {chunk / 48000 * 1e6 / res[True]:.0f}x", flush=True)
+
+
+# ---- RealtimeProcessor: round trip of one backend callback (host block in -> host block out) ----------------
+from torchfx_amd.realtime import RealtimeProcessor, StreamConfig  # noqa: E402
+
+
+class _Backend:
+    def open_stream(self, config, callback=None):
+        self.config, self.callback = config, callback
+
+    def start(self): pass
+
+    def stop(self): pass
+
+    def close(self): pass
+
+
+print("RealtimeProcessor callback (pinned staging in, chain, pinned staging out, one host wait), same chain, 2 channels")
+for B in (128, 256, 512, 1024, 2048, 4096):
+    res = {}
+    for g in (False, True):
+        be = _Backend()
+        cfg = StreamConfig(sample_rate=48000, buffer_size=B, channels_in=2, channels_out=2)
+        with RealtimeProcessor(make(), be, cfg, device="cuda:0", use_graph=g):
+            xin, out = torch.randn(2, B), torch.zeros(2, B)
+            for _ in range(30):
+                be.callback(xin, out, B)
+            ts = []
+            for _ in range(300):
+                t0 = time.perf_counter()
+                be.callback(xin, out, B)
+                ts.append(time.perf_counter() - t0)
+        ts = np.array(ts) * 1e6
+        res[g] = (np.median(ts), np.percentile(ts, 99))
+    print(f"[2 x {B}] eager median {res[False][0]:6.1f} us  p99 {res[False][1]:6.1f}   graph median {res[True][0]:6.1f} us  p99 {res[True][1]:6.1f}"
+          f"   buffer period at 48 kHz {B / 48000 * 1e6:7.0f} us", flush=True)

@@ -19,6 +19,10 @@ into a HIP graph and replays it per chunk (the ragged last chunk runs eagerly).
 """
 from __future__ import annotations
 
+import abc
+import dataclasses
+import enum
+import threading
 from collections.abc import Generator, Sequence
 
 import torch
@@ -257,3 +261,208 @@ class StreamProcessor:
                     sink.write(_io.download_interleaved(w))           # [n, C], interleaved on the device
                 else:
                     sink.write(w.cpu().numpy().T)
+
+
+# ---------------------------------------------------------------------------------------------------
+# The sound-card side of the same hot path: RealtimeProcessor (``src/torchfx/realtime/processor.py:46-325``)
+# ---------------------------------------------------------------------------------------------------
+class RealtimeError(RuntimeError):
+    """``realtime/exceptions.py``: message plus an optional suggestion."""
+
+    def __init__(self, message: str, suggestion: str | None = None) -> None:
+        self.suggestion = suggestion
+        super().__init__(message if suggestion is None else f"{message} ({suggestion})")
+
+
+class StreamDirection(enum.Enum):
+    INPUT = "input"
+    OUTPUT = "output"
+    DUPLEX = "duplex"
+
+
+@dataclasses.dataclass(frozen=True)
+class StreamConfig:
+    """``realtime/backend.py:67-137``: the stream a backend opens."""
+
+    sample_rate: int = 48000
+    buffer_size: int = 512
+    channels_in: int = 0
+    channels_out: int = 2
+    dtype: str = "float32"
+    device_in: int | str | None = None
+    device_out: int | str | None = None
+    latency: str | float = "low"
+
+    @property
+    def direction(self) -> StreamDirection:
+        if self.channels_in > 0 and self.channels_out > 0:
+            return StreamDirection.DUPLEX
+        return StreamDirection.INPUT if self.channels_in > 0 else StreamDirection.OUTPUT
+
+    @property
+    def latency_ms(self) -> float:
+        return self.buffer_size / self.sample_rate * 1000.0
+
+
+class AudioBackend(abc.ABC):
+    """What the processor needs from an audio I/O backend (``realtime/backend.py:140-268``, reduced to the four calls
+    the processor makes).  A backend calls ``callback(input [channels_in, frames], output [channels_out, frames],
+    frames)`` once per buffer; the sound-device backends themselves are out of scope here."""
+
+    @abc.abstractmethod
+    def open_stream(self, config: StreamConfig, callback=None) -> None: ...
+
+    @abc.abstractmethod
+    def start(self) -> None: ...
+
+    @abc.abstractmethod
+    def stop(self) -> None: ...
+
+    @abc.abstractmethod
+    def close(self) -> None: ...
+
+
+class RealtimeProcessor:
+    """A backend's per-buffer callback run through the effect chain on the GPU.
+
+    Same surface as the reference's ``RealtimeProcessor`` (construction, ``start`` / ``stop`` / context manager,
+    ``set_parameter`` staged until the next buffer boundary, ``reset_state``, ``latency_ms``).  The callback is where the
+    device comes in: the host block goes through a pinned staging buffer to a persistent device buffer on the
+    processor's own stream, the chain runs there -- from the second full-size block on as ONE replayed HIP graph when
+    ``use_graph`` (a 512-sample block is launch-bound: tens of microseconds of launches for a few of GPU work) --
+    and the result comes back through a second pinned buffer; the only host wait is the one before the block is
+    handed back.  Device tensors are processed in place of the staging.  The carried IIR states / FIR histories make
+    consecutive callbacks one continuous signal.
+    """
+
+    def __init__(self, effects: Sequence[FX] | nn.Sequential, backend: AudioBackend, config: StreamConfig,
+                 buffer_capacity: int = 8192, device: str = "cuda", use_graph: bool = False) -> None:
+        if not isinstance(config.sample_rate, int) or config.sample_rate <= 0:
+            raise ValueError(f"sample_rate must be a positive integer, got {config.sample_rate!r}")
+        if config.buffer_size <= 0:
+            raise ValueError(f"buffer_size must be positive, got {config.buffer_size}")
+        modules = list(effects)
+        for e in modules:
+            if not isinstance(e, FX):
+                raise TypeError("All effects must inherit from FX when used in RealtimeProcessor")
+        self._runner = StreamProcessor(modules, chunk_size=config.buffer_size, overlap=0, device=device, use_graph=use_graph)
+        self._backend, self._config, self._running = backend, config, False
+        self._buffer_capacity = buffer_capacity
+        for e in modules:                                      # same pattern as Wave.__or__
+            if hasattr(e, "fs") and e.fs is None:
+                e.fs = config.sample_rate
+            if isinstance(e, AbstractFilter) and not e._has_computed_coeff:
+                e.compute_coefficients()
+        self._pending: dict[str, object] = {}
+        self._param_lock = threading.Lock()
+        self._primed = False
+        self._stage = None           # (pinned in, device in, pinned out, stream) for the current block geometry
+
+    # ---- life cycle ----------------------------------------------------------------------------------
+    def __enter__(self) -> "RealtimeProcessor":
+        self.start()
+        return self
+
+    def __exit__(self, *exc) -> None:
+        if self._running:
+            self.stop()
+
+    def start(self) -> None:
+        if self._running:
+            raise RealtimeError("Processor is already running", suggestion="Call stop() before starting again")
+        self._backend.open_stream(self._config, callback=self._audio_callback)
+        self._backend.start()
+        self._running = True
+
+    def stop(self) -> None:
+        if not self._running:
+            raise RealtimeError("Processor is not running", suggestion="Call start() first")
+        self._running = False
+        self._backend.stop()
+        self._backend.close()
+
+    # ---- parameters: staged by any thread, applied at the next buffer boundary ---------------------
+    def set_parameter(self, name: str, value) -> None:
+        with self._param_lock:
+            self._pending[name] = value
+
+    def _apply_pending_params(self) -> None:
+        if not self._pending:
+            return
+        with self._param_lock:
+            params, self._pending = self._pending, {}
+        effects = self._runner.effects
+        for key, value in params.items():
+            idx, _, attr = key.partition(".")
+            i = int(idx)
+            if not (0 <= i < len(effects)) or not attr:
+                continue                                            # the reference logs a warning and goes on
+            e = effects[i]
+            setattr(e, attr, value)
+            if isinstance(e, AbstractFilter):                       # redesign, start from silence
+                e.compute_coefficients()
+                if callable(getattr(e, "reset_state", None)):
+                    e.reset_state()
+                self._primed = False                                # the captured step holds the old tables / states
+                self._runner._graph = None
+            elif self._runner._graph is not None:                   # a scalar baked into captured kernels (Gain, ...)
+                self._runner._graph = None
+
+    # ---- the callback --------------------------------------------------------------------------------
+    def _staging(self, rows: int, frames: int, rows_out: int, dev: torch.device):
+        key = (rows, frames, rows_out, str(dev))
+        if self._stage is None or self._stage[0] != key:
+            self._stage = (key, torch.empty(rows, frames, dtype=torch.float32).pin_memory(),
+                           torch.empty(rows, frames, dtype=torch.float32, device=dev),
+                           torch.empty(rows_out, frames, dtype=torch.float32).pin_memory(), torch.cuda.Stream(dev))
+        return self._stage[1:]
+
+    def _chain(self, w: Tensor) -> Tensor:
+        full = w.shape[-1] == self._config.buffer_size
+        if self._runner._use_graph and w.is_cuda and full and self._primed:
+            return self._runner._graph_step(w)
+        y = self._runner._run(w)             # the first block creates the carried states; ragged blocks run eagerly
+        self._primed = self._primed or full
+        return y
+
+    @staticmethod
+    def _fit_channels(y: Tensor, rows_out: int) -> Tensor:
+        if y.shape[0] == rows_out:
+            return y
+        if y.shape[0] == 1 and rows_out > 1:                          # mono to every output channel
+            return y.expand(rows_out, -1)
+        return y[:rows_out]                                           # else truncate (processor.py:283-291)
+
+    @torch.no_grad()
+    def _audio_callback(self, input_data: Tensor, output_data: Tensor, frame_count: int) -> None:  # noqa: ARG002
+        self._apply_pending_params()
+        on_gpu = torch.device(self._runner._device).type == "cuda"
+        if not on_gpu or input_data.is_cuda:                          # host-only mirror / device tensors: no staging
+            y = self._chain(input_data if input_data.is_cuda or not on_gpu else input_data.to(self._runner._device))
+            if output_data.numel() > 0:
+                output_data.copy_(self._fit_channels(y, output_data.shape[0]))
+            return
+        dev = torch.device(self._runner._device)
+        rows_out = output_data.shape[0] if output_data.numel() > 0 else input_data.shape[0]
+        pin_in, dev_in, pin_out, stream = self._staging(input_data.shape[0], input_data.shape[-1], rows_out, dev)
+        pin_in.copy_(input_data)
+        with torch.cuda.stream(stream):
+            dev_in.copy_(pin_in, non_blocking=True)
+            y = self._fit_channels(self._chain(dev_in), rows_out)
+            if output_data.numel() > 0:
+                pin_out.copy_(y, non_blocking=True)
+        stream.synchronize()                                          # the block is due now
+        if output_data.numel() > 0:
+            output_data.copy_(pin_out)
+
+    # ---- the rest of the surface -------------------------------------------------------------------
+    def reset_state(self) -> None:
+        for e in self._runner.effects:
+            if callable(getattr(e, "reset_state", None)):
+                e.reset_state()
+        self._primed = False
+
+    latency_ms = property(lambda self: self._config.latency_ms)
+    is_running = property(lambda self: self._running)
+    effects = property(lambda self: self._runner.effects)
+    config = property(lambda self: self._config)
