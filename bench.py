@@ -219,13 +219,17 @@ def cpu_baseline(workload: str, seconds: float, channels: int) -> dict:
 
 
 def source_digest() -> str:
-    """Identifies the kernels that were profiled: sha256 over the HIP sources (profiles/*_traffic.json
-    records the digest of the build its PMC numbers were taken from)."""
+    """Identifies the kernels that were profiled: sha256 over the HIP sources with comments and whitespace removed
+    (profiles/*_traffic.json records the digest of the build its PMC numbers were taken from)."""
+    import re
     h = hashlib.sha256()
     d = os.path.join(ROOT, "torchfx_amd", "csrc")
     for name in sorted(os.listdir(d)):
         if name.endswith((".hip", ".h")):
-            h.update(open(os.path.join(d, name), "rb").read())
+            src = open(os.path.join(d, name), encoding="utf-8", errors="replace").read()
+            src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)          # the code, not its comments or layout
+            src = re.sub(r"//[^\n]*", " ", src)
+            h.update(name.encode() + b"\0" + " ".join(src.split()).encode())
     return h.hexdigest()[:16]
 
 
