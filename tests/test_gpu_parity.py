@@ -207,6 +207,26 @@ def test_time_segmentation_geometry_edges(T, monkeypatch):
             close(sy2, sy1.cpu().numpy(), 1e-13, f"T={T} variant={variant} nseg={nseg} state_y")
 
 
+def test_empty_inputs():
+    """No rows ([0, T]) or no samples ([C, 0]): empty outputs, the state passes through (iir_cpu.cpp writes back what it
+    loaded); the overlap-save op keeps the reference's "kernel size" error for a signal shorter than the taps."""
+    sos = torch.tensor([[0.2, 0.4, 0.2, 1.0, -0.5, 0.2], [0.3, 0.1, 0.2, 1.0, -0.3, 0.1]], dtype=torch.float64)
+    for shape in ((0, 100), (2, 0), (0, 0)):
+        x = torch.zeros(*shape, device=DEV)
+        y, sx, sy = ext().sos_forward(x, None, sos, None, None)
+        assert y.shape == shape and sx.shape == (2, shape[0], 2) and sy.shape == (2, shape[0], 2)
+        assert ext().biquad_forward(x, sos[0, :3], -0.5, 0.2, None, None)[0].shape == shape
+        assert ext().fir_direct_forward(x, torch.ones(5)).shape == shape
+        assert ext().gain_forward(x, 0.5).shape == shape
+    sx0 = torch.full((2, 2, 2), 3.0, dtype=torch.float64, device=DEV)
+    sy0 = torch.full((2, 2, 2), 4.0, dtype=torch.float64, device=DEV)
+    y, sx, sy = ext().sos_forward(torch.zeros(2, 0, device=DEV), None, sos, sx0, sy0)
+    assert torch.equal(sx, sx0) and torch.equal(sy, sy0) and sx.data_ptr() != sx0.data_ptr()
+    assert ext().fft_conv_forward(torch.zeros(0, 100, device=DEV), torch.ones(5), (4, 0)).shape == (0, 100)
+    with pytest.raises(RuntimeError, match="kernel size"):
+        ext().fft_conv_forward(torch.zeros(2, 0, device=DEV), torch.ones(5), (4, 0))
+
+
 def test_long_memory_filter_falls_back_to_sequential():
     """A pole pair at radius 0.999999 never decays within 2^26 samples -> nseg = 1, still exact."""
     r, th = 0.999999, 0.01

@@ -1008,7 +1008,7 @@ void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C_in,
     TFX_CHECK(x_dtype == TFX_F32 || x_dtype == TFX_F64, "sos_forward: bad x dtype %d", x_dtype);
     TFX_CHECK(y_dtype == TFX_F32 || y_dtype == TFX_F64, "sos_forward: bad y dtype %d", y_dtype);
     if (C == 0) return;
-    TFX_CHECK(x && y && (K == 0 || sos_host), "sos_forward: null signal or coefficient pointer");
+    TFX_CHECK((T == 0 || (x && y)) && (K == 0 || sos_host), "sos_forward: null signal or coefficient pointer");   // an empty tensor has no storage
     const size_t st_bytes = (size_t)K * C_in * NB * 2 * sizeof(double);   // [K, NB * C_in, 2] in every mode
     TFX_CHECK(!(sum_bands && K == 0), "sos_forward: sum mode needs at least one section");
     if (T == 0 || K == 0) {
