@@ -227,6 +227,31 @@ def test_empty_inputs():
         ext().fft_conv_forward(torch.zeros(2, 0, device=DEV), torch.ones(5), (4, 0))
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.int16])
+def test_narrow_signal_dtypes_round_once_like_the_reference(dtype):
+    """float16 / bfloat16 / integer signals: the reference computes in float64 and casts back (`_ops.py:95,149`,
+    `iir.py:176`); here the float64 result is rounded once to the signal's dtype."""
+    from torchfx_amd import filter as F
+    f = F.LoButterworth(3000, order=4, fs=48000)
+    if dtype.is_floating_point:
+        x = torch.from_numpy(rnd((3, 5000), 17)).to(dtype)
+    else:
+        x = (torch.from_numpy(rnd((3, 5000), 17)) * 20000).to(dtype)
+    y = f(x.to(DEV))
+    assert y.dtype == dtype and y.shape == x.shape
+    e, _, _ = O.sos_forward(x.to(torch.float64).numpy(), f._sos.cpu().numpy())
+    want = torch.from_numpy(e).to(dtype)
+    if dtype.is_floating_point:
+        ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
+        diff = (y.cpu().double() - want.double()).abs()
+        assert (diff <= ulp * want.double().abs().clamp_min(1e-3)).all()          # at most the last bit (a tie the other way)
+        assert (diff > 0).double().mean().item() < 0.01
+    else:
+        assert (y.cpu().int() - want.int()).abs().max().item() <= 1
+    b = F.BiquadLPF(cutoff=1000, q=0.7, fs=48000)
+    assert b(x.to(DEV)).dtype == dtype
+
+
 def test_long_memory_filter_falls_back_to_sequential():
     """A pole pair at radius 0.999999 never decays within 2^26 samples -> nseg = 1, still exact."""
     r, th = 0.999999, 0.01

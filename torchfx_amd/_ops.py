@@ -40,6 +40,20 @@ def is_native_available() -> bool:
         return False
 
 
+def _wide(x: Tensor, out_dtype: torch.dtype | None):
+    """Signals that are neither float32 nor float64 (float16 / bfloat16 / integers).  The reference upcasts every
+    signal to float64 and casts the result back (``_ops.py:95,149``, ``iir.py:176``); the kernels take float32 and
+    float64 only, so 16-bit floats travel as float32 (exact), integers as float64, the result is produced in float64
+    and rounded ONCE to the requested dtype -- the same single rounding as the reference's ``out.to(x.dtype)``.
+    Returns (signal for the kernel, dtype for the kernel's store, dtype to cast the result to or None)."""
+    want = x.dtype if out_dtype is None else out_dtype
+    if x.dtype not in (torch.float32, torch.float64):
+        x = x.to(torch.float32 if x.dtype in (torch.float16, torch.bfloat16) else torch.float64)
+    if want in (torch.float32, torch.float64):
+        return x, want, None
+    return x, torch.float64, want
+
+
 def biquad_forward(
     x: Tensor,
     b: Tensor,
@@ -57,8 +71,9 @@ def biquad_forward(
         a_host = a.detach().to(device="cpu", dtype=torch.float64)
         a1_f64 = float(a_host[1])
         a2_f64 = float(a_host[2])
-    return _ext.biquad_forward(x, b, a1_f64, a2_f64, state_x, state_y,
-                               out_dtype=out_dtype, precision=precision)
+    x, store, cast = _wide(x, out_dtype)
+    y, sx, sy = _ext.biquad_forward(x, b, a1_f64, a2_f64, state_x, state_y, out_dtype=store, precision=precision)
+    return (y if cast is None else y.to(cast)), sx, sy
 
 
 def parallel_iir_forward(
@@ -76,9 +91,12 @@ def parallel_iir_forward(
     (``:144-147``).  Returns ``(y, new_state_x [K,C,2], new_state_y [K,C,2])``."""
     if sos_cpu is None:
         sos_cpu = sos.detach().to(dtype=torch.float64, device="cpu") if sos.is_cuda else sos
+    x, store, cast = _wide(x, out_dtype)
     if epilogue is not None:
-        return _ext.sos_forward(x, sos, sos_cpu, state_x, state_y, out_dtype=out_dtype, precision=precision, epilogue=epilogue)
-    return _ext.sos_forward(x, sos, sos_cpu, state_x, state_y, out_dtype=out_dtype, precision=precision)
+        y, sx, sy = _ext.sos_forward(x, sos, sos_cpu, state_x, state_y, out_dtype=store, precision=precision, epilogue=epilogue)
+    else:
+        y, sx, sy = _ext.sos_forward(x, sos, sos_cpu, state_x, state_y, out_dtype=store, precision=precision)
+    return (y if cast is None else y.to(cast)), sx, sy
 
 
 def delay_line_forward(x: Tensor, delay_samples: int, decay: float, mix: float) -> Tensor:
