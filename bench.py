@@ -234,8 +234,12 @@ def source_digest() -> str:
 
 
 def timed_region(step, steps: int, warmup: int, sync, lib):
+    """W untimed steps, then exactly K timed ones.  The previous step's result is dropped BEFORE the next step runs
+    (a caller that is done with it): the caching allocator then hands the same 7.4 GB block to every step, so no
+    step of the timed region -- not even the first one after a single warm-up -- contains a fresh hipMalloc."""
     out = None
     for _ in range(warmup):
+        out = None
         out = step()
     sync()
     lib.tfx_prof_enable(1)
@@ -243,6 +247,7 @@ def timed_region(step, steps: int, warmup: int, sync, lib):
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
+        out = None
         out = step()
     sync()
     elapsed = time.perf_counter() - t0
@@ -258,6 +263,7 @@ def batch_timed(step, sync, lib, batches: int, per_batch: int, warmup: int = 2):
     allocator stall (a fresh multi-GB hipMalloc inside torch.empty) out of a 5-step figure."""
     out = None
     for _ in range(warmup):
+        out = None
         out = step()
     sync()
     lib.tfx_prof_enable(1)
@@ -267,6 +273,7 @@ def batch_timed(step, sync, lib, batches: int, per_batch: int, warmup: int = 2):
         sync()
         t0 = time.perf_counter()
         for _ in range(per_batch):
+            out = None
             out = step()
         sync()
         groups.append((time.perf_counter() - t0) / per_batch * 1e3)

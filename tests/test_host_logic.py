@@ -543,3 +543,20 @@ def test_precision_auto_estimate_is_a_replay_of_the_float32_kernel():
     assert cfg2["auto_precision"] == "f32" and 5e-6 < cfg2["f32_error_bound"] < 2e-5   # measured on the device: 6.2e-6
     unstable = E.sos_plan_info(np.array([[1.0, 0, 0, 1, -2.1, 1.2]]))
     assert unstable["auto_precision"] == "f64"
+
+
+def test_host_taps_are_converted_once_per_module_buffer():
+    """FIR.forward hands `self.kernel.reshape(-1)` (a new view object per call) to the backend; the host copy in the
+    signal's dtype must be made once per buffer, not once per call (a fresh quarter-megabyte host allocation per step
+    stalls the GPU queues of the process)."""
+    from torchfx_amd.torchfx_ext import _kernel_host
+    buf = torch.randn(1, 1, 70000, dtype=torch.float64)
+    a = _kernel_host(buf.reshape(-1), torch.float32)
+    b = _kernel_host(buf.reshape(-1), torch.float32)
+    assert a is b and a.dtype == torch.float32 and a.data_ptr() != buf.data_ptr()
+    assert _kernel_host(buf.reshape(-1), torch.float64).data_ptr() == buf.data_ptr()      # nothing to convert: no copy at all
+    buf.mul_(2.0)                                                                          # in-place edit: new copy
+    c = _kernel_host(buf.reshape(-1), torch.float32)
+    assert c is not a and torch.equal(c, buf.reshape(-1).float())
+    half = _kernel_host(buf.reshape(-1)[:100], torch.float32)                              # another window of the same buffer
+    assert half.numel() == 100 and torch.equal(half, buf.reshape(-1)[:100].float())

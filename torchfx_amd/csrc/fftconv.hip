@@ -125,6 +125,8 @@ static std::mutex g_fft_mu;
 static bool g_rocfft_up = false;
 static std::map<FftKey, FftPlan> g_fft_plans;
 static std::map<SpecKey, void *> g_specs;
+static const SpecKey *g_spec_last_key[TFX_MAX_DEVICES] = {};      // per device: the entry used last (std::map nodes are stable)
+static void *g_spec_last[TFX_MAX_DEVICES] = {};
 
 static FftPlan &get_fft_plan(int dtype, int64_t N, int64_t batch)
 {
@@ -164,13 +166,27 @@ static void exec_fft(rocfft_plan plan, void *in, void *out, void *work, size_t w
 template <typename T, typename T2>
 static void *get_spectrum(int dtype, const void *kernel_host, int64_t K, int64_t N, hipStream_t stream)
 {
-    SpecKey key{current_device(), dtype, N, std::vector<char>((const char *)kernel_host, (const char *)kernel_host + K * sizeof(T))};
+    // steady state: the spectrum used last on this device, recognised by one memcmp (no key, no allocation per call)
+    const SpecKey **last_key = g_spec_last_key;
+    void **last_spec = g_spec_last;
+    const int dev_ = current_device();
+    if (const SpecKey *lk_ = last_key[dev_]) {
+        if (lk_->dtype == dtype && lk_->N == N && lk_->taps.size() == (size_t)K * sizeof(T) &&
+            memcmp(lk_->taps.data(), kernel_host, lk_->taps.size()) == 0)
+            return last_spec[dev_];
+    }
+    SpecKey key{dev_, dtype, N, std::vector<char>((const char *)kernel_host, (const char *)kernel_host + K * sizeof(T))};
     auto it = g_specs.find(key);
-    if (it != g_specs.end()) return it->second;
+    if (it != g_specs.end()) {
+        last_key[dev_] = &it->first;
+        last_spec[dev_] = it->second;
+        return it->second;
+    }
     if (g_specs.size() > 64) {
         for (auto &kv : g_specs) (void)hipFree(kv.second);
         g_specs.clear();
     }
+    for (int d2 = 0; d2 < TFX_MAX_DEVICES; ++d2) { last_key[d2] = nullptr; last_spec[d2] = nullptr; }   // nodes may go / move
     // one-time per (filter, N): pad taps, forward transform, conjugate + scale.  Blocking.
     const int64_t bins = N / 2 + 1;
     std::vector<T> hp((size_t)N, (T)0);
@@ -192,7 +208,9 @@ static void *get_spectrum(int dtype, const void *kernel_host, int64_t K, int64_t
     TFX_HIP(hipMemcpy(dspec, hs.data(), (size_t)bins * sizeof(T2), hipMemcpyHostToDevice));
     (void)hipFree(dpad);
     if (work) (void)hipFree(work);
-    g_specs[key] = dspec;
+    auto ins = g_specs.emplace(std::move(key), (void *)dspec).first;
+    last_key[dev_] = &ins->first;
+    last_spec[dev_] = dspec;
     return dspec;
 }
 
@@ -201,6 +219,7 @@ void fftconv_clear()
     std::lock_guard<std::mutex> lk(g_fft_mu);
     for (auto &kv : g_specs) (void)hipFree(kv.second);
     g_specs.clear();
+    for (int d = 0; d < TFX_MAX_DEVICES; ++d) { g_spec_last_key[d] = nullptr; g_spec_last[d] = nullptr; }
     for (auto &kv : g_fft_plans) {
         if (kv.second.fwd) rocfft_plan_destroy(kv.second.fwd);
         if (kv.second.inv) rocfft_plan_destroy(kv.second.inv);

@@ -33,25 +33,41 @@ namespace tfx {
 // is seen, then reused -- no host sync on the steady-state path.
 static std::mutex g_taps_mu;
 static std::map<std::vector<char>, void *> g_taps;
+static const std::vector<char> *g_taps_last_key[TFX_MAX_DEVICES] = {};   // per device: the entry used last
+static const void *g_taps_last[TFX_MAX_DEVICES] = {};
 static const void *cached_taps(const void *host, size_t bytes, size_t padded)
 {
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lk(g_taps_mu);
+    // steady state (the same filter call after call): one memcmp, no key construction -- a long tap vector would
+    // otherwise cost a heap allocation of its size per call
+    if (const std::vector<char> *lk_ = g_taps_last_key[dev]) {
+        if (lk_->size() == bytes + 2 && memcmp(lk_->data(), host, bytes) == 0 && (*lk_)[bytes] == (char)(padded & 0xff))
+            return g_taps_last[dev];
+    }
     std::vector<char> key((const char *)host, (const char *)host + bytes);
     key.push_back((char)(padded & 0xff));
-    key.push_back((char)current_device());
-    std::lock_guard<std::mutex> lk(g_taps_mu);
+    key.push_back((char)dev);
     auto it = g_taps.find(key);
-    if (it != g_taps.end()) return it->second;
+    if (it != g_taps.end()) {
+        g_taps_last_key[dev] = &it->first;
+        g_taps_last[dev] = it->second;
+        return it->second;
+    }
     if (g_taps.size() > 128) {
         (void)hipDeviceSynchronize();
         for (auto &kv : g_taps) (void)hipFree(kv.second);
         g_taps.clear();
+        for (int d2 = 0; d2 < TFX_MAX_DEVICES; ++d2) { g_taps_last_key[d2] = nullptr; g_taps_last[d2] = nullptr; }
     }
     std::vector<char> h(padded, 0);
     memcpy(h.data(), host, bytes);
     void *d = nullptr;
     TFX_HIP(hipMalloc(&d, padded));
     TFX_HIP(hipMemcpy(d, h.data(), padded, hipMemcpyHostToDevice));
-    g_taps[key] = d;
+    auto ins = g_taps.emplace(std::move(key), d).first;
+    g_taps_last_key[dev] = &ins->first;                 // std::map nodes are stable
+    g_taps_last[dev] = d;
     return d;
 }
 void fir_clear()
@@ -60,6 +76,7 @@ void fir_clear()
     (void)hipDeviceSynchronize();
     for (auto &kv : g_taps) (void)hipFree(kv.second);
     g_taps.clear();
+    for (int d = 0; d < TFX_MAX_DEVICES; ++d) { g_taps_last_key[d] = nullptr; g_taps_last[d] = nullptr; }
 }
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));

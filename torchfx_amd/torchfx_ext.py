@@ -121,24 +121,32 @@ def delay_line_forward(x: Tensor, delay_samples: int, decay: float, mix: float) 
     return native.ops().delay_line_forward(x, int(delay_samples), float(decay), float(mix))
 
 
-_TAPS_HOST: dict = {}        # id(tensor) -> (weakref, version, dtype, host tensor)
+_TAPS_HOST: dict = {}        # (id(base tensor), offset, numel, dtype wanted) -> (weakref to base, version, host tensor)
 
 
 def _kernel_host(kernel, dtype: torch.dtype) -> Tensor:
     """Flat host copy of the taps in the signal's dtype.  The C ABI takes the taps as a host array (they
-    key its device-side caches), so a filter that was moved to the GPU would otherwise pay a blocking
-    device-to-host copy on every forward: the copy is cached per tensor object and invalidated by its
-    version counter (in-place edits) or its death."""
+    key its device-side caches), so a filter whose taps live on the GPU, or in another dtype (the planner's merged
+    kernels are float64), would otherwise pay a copy on every forward -- a blocking device-to-host copy in the first
+    case, a fresh quarter-megabyte host allocation in the second (and a process that keeps mapping and unmapping
+    host memory while kernels are in flight gets its GPU queues stalled by the driver for tens of milliseconds:
+    measured, `profiles/r02_experiments.txt`).  The copy is cached per BASE tensor object -- modules hand in
+    `self.kernel.reshape(-1)`, a new view object per call -- and invalidated by the version counter (in-place
+    edits) or the tensor's death."""
     if not isinstance(kernel, Tensor):
         return torch.from_numpy(np.ascontiguousarray(np.asarray(kernel).reshape(-1))).to(dtype)
-    ent = _TAPS_HOST.get(id(kernel))
-    if ent is not None and ent[0]() is kernel and ent[1] == kernel._version and ent[2] == dtype:
-        return ent[3]
+    base = kernel._base if kernel._base is not None else kernel
+    key = (id(base), kernel.storage_offset(), kernel.numel(), tuple(kernel.stride()), dtype)
+    ent = _TAPS_HOST.get(key)
+    if ent is not None and ent[0]() is base and ent[1] == kernel._version:
+        return ent[2]
     k = kernel.detach().to(device="cpu").reshape(-1).to(dtype).contiguous()
+    if k.data_ptr() == kernel.data_ptr():          # nothing was copied: nothing to cache (and nothing allocated per call)
+        return k
     if len(_TAPS_HOST) > 64:
-        for key in [key for key, e in _TAPS_HOST.items() if e[0]() is None] or list(_TAPS_HOST)[:32]:
-            _TAPS_HOST.pop(key, None)
-    _TAPS_HOST[id(kernel)] = (weakref.ref(kernel), kernel._version, dtype, k)
+        for dead in [kk for kk, e in _TAPS_HOST.items() if e[0]() is None] or list(_TAPS_HOST)[:32]:
+            _TAPS_HOST.pop(dead, None)
+    _TAPS_HOST[key] = (weakref.ref(base), kernel._version, k)
     return k
 
 
