@@ -17,6 +17,26 @@ from torch import Tensor
 PCM16_SCALE = 1.0 / 32768.0          # libsndfile's normalisation of 16-bit PCM read as float
 
 
+# Staging buffers live as long as the process: a streaming caller (StreamProcessor.process_file) uploads and downloads
+# one chunk after the other, and fresh pinned / pageable host buffers per chunk are exactly the host-side churn that
+# makes the driver hold the process's GPU queues.  One set per (device, geometry); a call leaves
+# them idle (it waits for its last kernel / copy before returning).
+_UP: dict = {}
+_DOWN: dict = {}
+
+
+def _upload_staging(dev: torch.device, tdt: torch.dtype, chunk: int, C: int):
+    key = (str(dev), tdt, chunk, C)
+    st = _UP.get(key)
+    if st is None:
+        if len(_UP) > 8:
+            _UP.clear()
+        st = _UP[key] = ([torch.empty((chunk, C), dtype=tdt, pin_memory=True) for _ in range(2)],
+                         [torch.empty((chunk, C), dtype=tdt, device=dev) for _ in range(2)],
+                         torch.cuda.Stream(dev), [torch.cuda.Event() for _ in range(2)], [torch.cuda.Event() for _ in range(2)])
+    return st
+
+
 def upload_interleaved(frames: np.ndarray, device, chunk_frames: int = 1 << 22) -> Tensor:
     """Host ``[F, C]`` float32 or int16 -> device planar float32 ``[C, F]``.
 
@@ -29,6 +49,8 @@ def upload_interleaved(frames: np.ndarray, device, chunk_frames: int = 1 << 22) 
     dev = torch.device(device)
     if dev.type != "cuda":
         raise RuntimeError("upload_interleaved: target must be a ROCm device")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
     F, C = frames.shape
     tdt = torch.float32 if frames.dtype == np.float32 else torch.int16
     out = torch.empty((C, F), dtype=torch.float32, device=dev)
@@ -36,15 +58,11 @@ def upload_interleaved(frames: np.ndarray, device, chunk_frames: int = 1 << 22) 
         return out
     chunk = max(1, min(int(chunk_frames), F))
     src = torch.from_numpy(np.ascontiguousarray(frames))
-    pinned = [torch.empty((chunk, C), dtype=tdt).pin_memory() for _ in range(2)]
-    staged = [torch.empty((chunk, C), dtype=tdt, device=dev) for _ in range(2)]
+    pinned, staged, copy, done_copy, done_use = _upload_staging(dev, tdt, chunk, C)
     compute = torch.cuda.current_stream(dev)
-    copy = torch.cuda.Stream(dev)
-    # `staged` was allocated on the compute stream: the caching allocator may have handed out blocks that
-    # still have work queued there, so the copy stream must not touch them before that work has run
+    # the staging blocks may have been used on another compute stream by an earlier call; that call waited for its
+    # last kernel before it returned, so only this call's own ordering matters: copy stream after compute stream
     copy.wait_stream(compute)
-    done_copy = [torch.cuda.Event() for _ in range(2)]
-    done_use = [torch.cuda.Event() for _ in range(2)]
     for i, f0 in enumerate(range(0, F, chunk)):
         b = i & 1
         n = min(chunk, F - f0)
@@ -57,21 +75,41 @@ def upload_interleaved(frames: np.ndarray, device, chunk_frames: int = 1 << 22) 
         compute.wait_event(done_copy[b])
         torchfx_ext.deinterleave_forward(staged[b][:n], out, frame_base=f0, scale=PCM16_SCALE)
         done_use[b].record(compute)
-    for e in done_use:
-        e.synchronize()                                  # staging buffers may be freed after this
+    for b in range(min(2, -(-F // chunk))):
+        done_use[b].synchronize()                        # the staging buffers are idle again when we return
     return out
 
 
-def download_interleaved(x: Tensor, chunk_frames: int = 1 << 22) -> np.ndarray:
-    """Device planar float32 ``[C, F]`` -> host interleaved ``[F, C]`` (what ``soundfile.write`` takes)."""
+def download_interleaved(x: Tensor, chunk_frames: int = 1 << 22, out: np.ndarray | None = None) -> np.ndarray:
+    """Device planar float32 ``[C, F]`` -> host interleaved ``[F, C]`` (what ``soundfile.write`` takes).  Interleaving
+    runs on the device, chunks come back through one pinned buffer; ``out`` (a float32 array with at least ``F`` rows
+    of ``C``) lets a streaming caller reuse its host buffer -- the first ``F`` rows are filled and returned."""
     from torchfx_amd import torchfx_ext
 
     if x.dim() != 2:
         raise ValueError(f"expected [channels, frames], got {tuple(x.shape)}")
     C, F = x.shape
-    out = np.empty((F, C), dtype=np.float32)
+    if out is None:
+        out = np.empty((F, C), dtype=np.float32)
+    elif out.dtype != np.float32 or out.ndim != 2 or out.shape[1] != C or out.shape[0] < F or not out.flags.c_contiguous:
+        raise ValueError(f"out must be a C-contiguous float32 [>= {F}, {C}] array")
+    res = out[:F]
     if F == 0:
-        return out
+        return res
+    xf = x if x.dtype == torch.float32 else x.to(torch.float32)
+    chunk = max(1, min(int(chunk_frames), F))
+    key = (str(x.device), chunk, C)
+    pin = _DOWN.get(key)
+    if pin is None:
+        if len(_DOWN) > 8:
+            _DOWN.clear()
+        pin = _DOWN[key] = torch.empty((chunk, C), dtype=torch.float32, pin_memory=True)
+    for f0 in range(0, F, chunk):
+        n = min(chunk, F - f0)
+        pin[:n].copy_(torchfx_ext.interleave_forward(xf, f0, n), non_blocking=True)
+        torch.cuda.current_stream(x.device).synchronize()
+        res[f0:f0 + n] = pin[:n].numpy()
+    return res
     xf = x if x.dtype == torch.float32 else x.to(torch.float32)
     chunk = max(1, min(int(chunk_frames), F))
     for f0 in range(0, F, chunk):

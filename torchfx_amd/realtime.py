@@ -256,9 +256,13 @@ class StreamProcessor:
             subtype = "FLOAT" if format == "WAV" else None
         with sf.SoundFile(str(out), mode="w", samplerate=info.samplerate, channels=info.channels, format=format,
                           subtype=subtype) as sink:
+            hostbuf = None                                            # one host buffer for every chunk on its way out
             for w, _ in self._file_steps(input_path):
                 if w.is_cuda and w.dim() == 2 and w.dtype == torch.float32:
-                    sink.write(_io.download_interleaved(w))           # [n, C], interleaved on the device
+                    if hostbuf is None or hostbuf.shape[0] < w.shape[1] or hostbuf.shape[1] != w.shape[0]:
+                        import numpy as np
+                        hostbuf = np.empty((max(self._chunk_size, w.shape[1]), w.shape[0]), dtype=np.float32)
+                    sink.write(_io.download_interleaved(w, out=hostbuf))   # [n, C], interleaved on the device
                 else:
                     sink.write(w.cpu().numpy().T)
 
