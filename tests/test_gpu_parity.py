@@ -1416,3 +1416,26 @@ def test_plain_c_host_filters_on_the_device(tmp_path):
                     [1.0089, -1.9636, 0.9695, 1.0, -1.9636, 0.9784]])
     imp = np.zeros(8); imp[0] = 1.0
     np.testing.assert_allclose(head, sosfilt(sos, imp)[:4], rtol=0, atol=2e-6)
+
+
+def test_planned_chain_steps_have_no_periodic_host_stall():
+    """Regression: the planner's merged FIR taps are a float64 host buffer; converting them per call (a fresh 276 KB
+    host allocation per step) made the driver hold the GPU queues for ~70 ms on every third synchronised step.  The
+    host copy is cached per buffer now: 30 synchronised steps must all take about the same time."""
+    import time
+    import bench
+    x = dev(rnd((16, 1_500_000), 3))
+    plan, names = bench.plan_chain(x)
+    assert "68977 taps" in names
+    for _ in range(3):
+        bench.run_plan(plan, x)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        y = bench.run_plan(plan, x)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+        del y
+    ts = np.array(ts) * 1e3
+    assert ts.max() < 10 * np.median(ts) + 5.0, f"step times (ms): {np.round(ts, 2).tolist()}"
