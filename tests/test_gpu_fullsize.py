@@ -162,6 +162,37 @@ def test_cfg5_chain_per_gpu_64ch_600s(workload):
     assert maxerr(ys, y[:2]) <= 1e-5
 
 
+def test_cfg5_all_512_channels_in_one_call_equal_the_eight_shards():
+    """cfg 5 at its full size -- 512 ch x 600 s, 14.7 G samples, 59 GB in and 59 GB out -- fits one MI355X: the
+    whole batch in ONE call must equal, bit for bit, what the eight 64-channel shards produce on their own (rows are
+    independent and frames pair up inside a row), and the oracle on the head of three rows of the last shard.  This is
+    the data path of the 8-GPU run minus the gather."""
+    from scipy.signal import firwin
+    import bench
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150 * 2**30:
+        pytest.skip("needs ~125 GB of free HBM")
+    C, T, S = 512, 600 * FS, 64
+    x = torch.empty(C, T, device=DEV)
+    for s0 in range(0, C, S):                         # every shard has its own seed, like the ranks of bench.py
+        x[s0:s0 + S] = signal(S, T, 100 + s0 // S)
+    plan, names = bench.plan_chain(x)
+    y = bench.run_plan(plan, x)
+    assert y.shape == x.shape
+    for s0 in (0, 64, 448):                           # three of the eight shards, each run alone
+        ys = bench.run_plan(plan, x[s0:s0 + S])
+        assert torch.equal(ys, y[s0:s0 + S]), f"shard {s0 // S} differs from the same rows of the full batch"
+        del ys
+    sos = cfg2_sos().numpy()
+    kf = firwin(1024, 5000, fs=FS).astype(np.float32)[::-1].copy()
+    kr = reverb_ir()[::-1].copy()
+    n = 4 * FS
+    for c in (448, 480, 511):
+        head = _staged_oracle_window(x[c:c + 1].cpu().numpy(), sos, kf, kr, 0, n)
+        assert np.abs(y[c, :n].cpu().numpy() - head[0]).max() <= 1e-5 * max(1.0, float(np.abs(head).max())), c
+    assert bool(torch.isfinite(y[::37, ::4099]).all())
+
+
 def test_more_than_2_31_samples_in_one_call():
     """80 ch x 30 M samples = 2.4e9 elements per tensor: every kernel's index math beyond 2^31
     (the reference's CUDA kernels index C*T with `int`, parallel_scan.cu:293).  The last row sits
