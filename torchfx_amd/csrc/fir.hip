@@ -308,7 +308,11 @@ void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
     const void *kdev = cached_taps(kernel_host, (size_t)K * esz, (size_t)Kpad * esz);
     // rows much shorter than one 16384-sample MFMA tile (streaming chunks): the plain LDS-tiled kernel
     // has 1024-sample tiles and finishes in a few microseconds instead of a full tile's ~60
-    const bool short_rows = dtype == TFX_F32 && T < envi_fir("TFX_FIR_MFMA_MIN_T", FIR_NOUT / 4);
+    // ... and so does any job whose 1024-sample tiles are all resident at once (8 workgroups per CU): one round of
+    // the plain kernel costs ~40 clocks per tap, one MFMA workgroup walks its 16384-sample tile for ~128 clocks per
+    // tap -- the MFMA kernel wins on throughput (2.5 x), not on latency (streaming chunks, 64 x 4096 and the like)
+    const bool few_tiles = C * ceil_div(T, (int64_t)1024) <= 2048;
+    const bool short_rows = dtype == TFX_F32 && (T < envi_fir("TFX_FIR_MFMA_MIN_T", FIR_NOUT / 4) || few_tiles);
     if (dtype == TFX_F32 && !short_rows) {
         const int64_t tiles = ceil_div(T, FIR_NOUT);
         TFX_CHECK(C * tiles < (1ll << 31), "fir_direct_forward: grid too large");

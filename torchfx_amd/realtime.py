@@ -37,6 +37,8 @@ class StatefulFIR(FIR):
     """FIR whose K-1 sample input history survives between calls (``reset_state()`` clears it):
     filtering a signal chunk by chunk equals filtering it in one piece."""
 
+    DIRECT_BELOW_MACS = 1 << 31          # rows x samples x taps of a chunk below which the direct kernel is used
+
     def __init__(self, b, conv_mode: str = "fft") -> None:
         super().__init__(b, conv_mode)
         self._hist: Tensor | None = None
@@ -59,8 +61,11 @@ class StatefulFIR(FIR):
         h = self._hist
         if h is not None and (h.shape[0] != rows.shape[0] or h.dtype != rows.dtype or h.device != rows.device):
             h = None                                          # row count / dtype / device changed: start from silence
-        # history and chunk stay in their own buffers (tfx_fir_stream_forward reads both); no torch.cat
-        y, self._hist = torchfx_ext.fir_stream_forward(rows, taps, h, self._conv_mode == "direct")
+        # history and chunk stay in their own buffers (tfx_fir_stream_forward reads both); no torch.cat.
+        # Small chunks take the one-launch direct kernel whatever the mode (a 2 x 512 chunk through the FFT path is
+        # half a dozen launches for a microsecond of arithmetic); both paths meet the same 1e-5 bar.
+        direct = self._conv_mode == "direct" or rows.shape[0] * rows.shape[1] * k <= self.DIRECT_BELOW_MACS
+        y, self._hist = torchfx_ext.fir_stream_forward(rows, taps, h, direct)
         return y.reshape(shape)
 
 
