@@ -295,15 +295,26 @@ def test_errors_are_runtime_errors():
 
 
 # ------------------------------------------------------------------------------------- FIR
+@pytest.fixture(params=["dispatch", "mfma"])
+def fir_kernel(request, monkeypatch):
+    """The direct FIR has two float32 kernels: the exact-f32 MFMA Toeplitz kernel (throughput) and the plain LDS-tiled
+    one (short rows, launches whose tiles are all resident at once).  "dispatch" = the library's choice (mostly the plain
+    kernel at test sizes), "mfma" = the MFMA kernel wherever it can run."""
+    if request.param == "mfma":
+        monkeypatch.setenv("TFX_FIR_ONE_ROUND_TILES", "0")
+        monkeypatch.setenv("TFX_FIR_MFMA_MIN_T", "0")
+    return request.param
+
+
 @pytest.mark.parametrize("K", [5, 32, 1024])
-def test_fir_golden(golden, K):
+def test_fir_golden(golden, K, fir_kernel):
     g = golden("fir")
     x = dev(g["x"])
     close(ext().fir_direct_forward(x, g[f"k{K}"]), g[f"direct{K}"], TOL_CONV_F32, "direct")
     close(ext().fft_conv_forward(x, g[f"k{K}"], (K - 1, 0)), g[f"fft{K}"], TOL_CONV_F32, "fft")
 
 
-def test_fir_short_and_f64_golden(golden):
+def test_fir_short_and_f64_golden(golden, fir_kernel):
     g = golden("fir")
     close(ext().fir_direct_forward(dev(g["xs"]), g["ks"]), g["ys_direct"], TOL_CONV_F32)
     close(ext().fft_conv_forward(dev(g["xs"]), g["ks"], (31, 0)), g["ys_fft"], TOL_CONV_F32)
@@ -312,7 +323,7 @@ def test_fir_short_and_f64_golden(golden):
 
 
 @pytest.mark.parametrize("C,T,K", [(1, 1, 1), (2, 100, 3), (3, 5000, 1025), (1, 40000, 2500), (5, 16385, 64)])
-def test_fir_direct_shapes_vs_f64(C, T, K):
+def test_fir_direct_shapes_vs_f64(C, T, K, fir_kernel):
     from scipy.signal import lfilter
     rng = np.random.default_rng(K)
     b = (rng.standard_normal(K) / K).astype(np.float32)
@@ -332,7 +343,8 @@ def test_fir_direct_chunk_sizes_vs_oracle(C, T, K, kc, monkeypatch):
     oracle's float32 direct form: tile edges, rows shorter than the filter, K on chunk borders."""
     if kc is not None:
         monkeypatch.setenv("TFX_FIR_KC", str(kc))
-        monkeypatch.setenv("TFX_FIR_MFMA_MIN_T", "0")      # short rows too go through the MFMA kernel here
+        monkeypatch.setenv("TFX_FIR_MFMA_MIN_T", "0")      # short rows and small launches too go through the MFMA kernel here
+        monkeypatch.setenv("TFX_FIR_ONE_ROUND_TILES", "0")
     rng = np.random.default_rng(1000 * K + T)
     kf = (rng.standard_normal(K) / np.sqrt(K)).astype(np.float32)
     x = rnd((C, T), K * 7 + T)
@@ -1188,7 +1200,7 @@ def test_bench_two_ranks_on_one_device(tmp_path):
     (200, [70_000, 66_000, 131_072]),              # LDS-resident overlap-save path, one and two blocks
     (5000, [140_000, 70_001]),                     # long taps through the native path with history
 ])
-def test_fir_stream_forward_chunks_equal_one_shot(K, chunks, direct):
+def test_fir_stream_forward_chunks_equal_one_shot(K, chunks, direct, fir_kernel):
     """tfx_fir_stream_forward: every chunk continues the previous one through a [C, K-1] history buffer the
     kernels read beside the chunk; concatenated outputs == one-shot float64 lfilter of the whole signal."""
     rng = np.random.default_rng(K)

@@ -311,7 +311,7 @@ void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
     // ... and so does any job whose 1024-sample tiles are all resident at once (8 workgroups per CU): one round of
     // the plain kernel costs ~40 clocks per tap, one MFMA workgroup walks its 16384-sample tile for ~128 clocks per
     // tap -- the MFMA kernel wins on throughput (2.5 x), not on latency (streaming chunks, 64 x 4096 and the like)
-    const bool few_tiles = C * ceil_div(T, (int64_t)1024) <= 2048;
+    const bool few_tiles = C * ceil_div(T, (int64_t)1024) <= envi_fir("TFX_FIR_ONE_ROUND_TILES", 2048);   // 0: MFMA whenever T allows (tests)
     const bool short_rows = dtype == TFX_F32 && (T < envi_fir("TFX_FIR_MFMA_MIN_T", FIR_NOUT / 4) || few_tiles);
     if (dtype == TFX_F32 && !short_rows) {
         const int64_t tiles = ceil_div(T, FIR_NOUT);
