@@ -1451,3 +1451,80 @@ def test_planned_chain_steps_have_no_periodic_host_stall():
         del y
     ts = np.array(ts) * 1e3
     assert ts.max() < 10 * np.median(ts) + 5.0, f"step times (ms): {np.round(ts, 2).tolist()}"
+
+
+@pytest.mark.parametrize("seed", range(64))
+def test_random_pipelines_planned_equals_staged_on_device(seed):
+    """Planner + kernels together: random pipelines of IIR / Biquad / FIR / Gain / Normalize / `+` steps under random
+    fusion flags, planned execution on the device == the same modules applied one after the other on the device with
+    every fusion off (the reference's definition of a pipeline) == the oracle applied step by step on the host."""
+    import random
+    import torchfx_amd as fx
+    from torchfx_amd import effect as E
+    from torchfx_amd import filter as F
+    rnd_ = random.Random(seed)
+    FS_ = 48000
+
+    def make(spec):
+        kind, a, b = spec
+        if kind == "lo":
+            return F.LoButterworth(a, order=b, fs=FS_)
+        if kind == "hi":
+            return F.HiButterworth(a, order=b, fs=FS_)
+        if kind == "peq":
+            return F.ParametricEQ(frequency=a, q=1.5, gain=b, fs=FS_)
+        if kind == "bq":
+            return F.BiquadLPF(cutoff=a, q=b, fs=FS_)
+        if kind == "fir":
+            return F.FIR((np.random.default_rng(b).standard_normal(a) / np.sqrt(a)).tolist())
+        if kind == "par":
+            return F.LoButterworth(a, order=2, fs=FS_) + F.HiButterworth(b, order=2, fs=FS_)
+        if kind == "gain":
+            return E.Gain(a, clamp=b)
+        return E.Normalize(peak=a)
+
+    def one():
+        k = rnd_.choice(["lo", "hi", "peq", "bq", "fir", "fir", "par", "gain", "norm"])
+        return {"lo": lambda: ("lo", rnd_.randint(200, 8000), rnd_.randint(1, 4)),
+                "hi": lambda: ("hi", rnd_.randint(50, 2000), rnd_.randint(1, 3)),
+                "peq": lambda: ("peq", rnd_.randint(100, 10000), rnd_.uniform(-6, 6)),
+                "bq": lambda: ("bq", rnd_.randint(200, 8000), rnd_.uniform(0.3, 4.0)),
+                "fir": lambda: ("fir", rnd_.choice([2, 17, 64, 300, 1500, 5000]), rnd_.randint(0, 1000)),
+                "par": lambda: ("par", rnd_.randint(1000, 6000), rnd_.randint(60, 900)),
+                "gain": lambda: ("gain", rnd_.uniform(0.2, 1.8), rnd_.random() < 0.3),
+                "norm": lambda: ("norm", rnd_.uniform(0.3, 1.0), None)}[k]()
+
+    specs = [one() for _ in range(rnd_.randint(1, 6))]
+    C, T = rnd_.choice([(1, 30011), (3, 70000), (2, 200000)])
+    x = rnd((C, T), 900 + seed)
+    # staged on the host through the oracle-backed module implementations (tests/_fake_backend.py)
+    from tests import _fake_backend as FB
+    from torchfx_amd import torchfx_ext as TE
+    names = ("sos_forward", "sos_bank_forward", "sos_bank_sum_forward", "biquad_forward", "fir_direct_forward", "fft_conv_forward",
+             "fir_stream_forward", "normalize_apply", "sum_forward", "delay_line_forward", "gain_forward", "stat_forward", "normalize_forward")
+    saved = {n: getattr(TE, n) for n in names}
+    try:
+        for n in names:
+            setattr(TE, n, getattr(FB, n))
+        ref = torch.from_numpy(x)
+        for sp in specs:
+            ref = make(sp)(ref)
+    finally:
+        for n in names:
+            setattr(TE, n, saved[n])
+    ref = ref.numpy()
+    # staged on the device, every fusion off
+    cur = dev(x)
+    for sp in specs:
+        cur = make(sp)(cur)
+    scale = max(1.0, float(np.abs(ref).max()))
+    assert float(np.abs(cur.cpu().numpy() - ref).max()) <= 1e-5 * scale, specs
+    # planned, random flags
+    w = fx.Wave(dev(x), FS_, device=DEV)
+    w.fuse_fir, w.fuse_gain, w.fuse_spectral, w.fuse_epilogue = (rnd_.random() < 0.5 for _ in range(4))
+    flags = (w.fuse_fir, w.fuse_gain, w.fuse_spectral, w.fuse_epilogue)
+    for sp in specs:
+        w = w | make(sp)
+    y = w.ys
+    assert y.shape == cur.shape and y.dtype == cur.dtype
+    assert float((y - cur).abs().max()) <= 1e-5 * scale, (specs, flags, [type(m).__name__ for m in w.plan()] if hasattr(w, "plan") else None)

@@ -485,10 +485,6 @@ Tensor fft_conv_meta(const Tensor &x, const Tensor &kernel, int64_t pad_left, in
 }
 
 // CPU tensors: an explicit error instead of the dispatcher's "no kernel for backend CPU"
-template <typename R, typename... A> R no_cpu(A...)
-{
-    TORCH_CHECK(false, "torchfx_amd: tensors must live on a ROCm device; this backend has no CPU path -- move them with .to('cuda').");
-}
 
 }  // namespace
 
@@ -561,17 +557,20 @@ TORCH_LIBRARY_IMPL(torchfx_hip, Meta, m)
     m.impl("normalize_forward", [](const Tensor &x, double, int64_t, bool) { return at::empty_like(x); });
 }
 
+// No CPU branch, by design: every op of the namespace answers a host tensor with the same error (one boxed function
+// registered for the CPU key of each op; per-namespace fallbacks are not supported by the dispatcher).
+static void no_cpu_boxed(const c10::OperatorHandle &op, c10::DispatchKeySet, torch::jit::Stack *)
+{
+    TORCH_CHECK(false, "torchfx_amd: ", op.schema().name(),
+                ": tensors must live on a ROCm device; this backend has no CPU path -- move them with .to('cuda').");
+}
 TORCH_LIBRARY_IMPL(torchfx_hip, CPU, m)
 {
-    m.impl("sos_forward", no_cpu<std::tuple<Tensor, Tensor, Tensor>, const Tensor &, const Tensor &, const OptTensor &, const OptTensor &,
-                                 std::optional<at::ScalarType>, int64_t>);
-    m.impl("biquad_forward", no_cpu<std::tuple<Tensor, Tensor, Tensor>, const Tensor &, const Tensor &, double, double, const OptTensor &,
-                                    const OptTensor &, std::optional<at::ScalarType>, int64_t>);
-    m.impl("delay_line_forward", no_cpu<Tensor, const Tensor &, int64_t, double, double>);
-    m.impl("fir_direct_forward", no_cpu<Tensor, const Tensor &, const Tensor &>);
-    m.impl("fft_conv_forward", no_cpu<Tensor, const Tensor &, const Tensor &, int64_t, int64_t>);
-    m.impl("gain_forward", no_cpu<Tensor, const Tensor &, double, bool>);
-    m.impl("normalize_forward", no_cpu<Tensor, const Tensor &, double, int64_t, bool>);
+    for (const char *name : {"sos_forward", "sos_forward_sections", "sos_bank_forward", "sos_bank_sum_forward", "biquad_forward",
+                             "delay_line_forward", "fir_direct_forward", "fft_conv_forward", "fir_stream_forward", "sos_forward_ep",
+                             "fft_conv_forward_ep", "normalize_apply", "sum_forward", "gain_forward", "stat_forward",
+                             "normalize_forward", "deinterleave_forward", "deinterleave_into", "interleave_forward"})
+        m.impl(name, torch::CppFunction::makeFromBoxedFunction<&no_cpu_boxed>());
 }
 
 // The reference's module surface (binding.cpp:83-96): exactly these three names and argument lists.
