@@ -501,6 +501,15 @@ def main() -> None:
         roof["frac"] = round(ach / roof["peak"], 4)
         roof["step_achieved"] = round(step_ach, 2)
         roof["step_frac"] = round(step_ach / roof["peak"], 4)
+        if dom and prof_serial and dom in prof_serial:
+            # the same kernel with nothing else on the chip (the untimed single-stream pass): in the timed region the
+            # three overlap-save passes of different slabs run concurrently, so every kernel's elapsed time there is
+            # stretched by its neighbours -- the wall clock gains, the per-kernel figure does not show the kernel alone
+            alone_ms = prof_serial[dom]["total_ms"] / prof_serial[dom]["calls"]
+            per_launch_alone = samples / max(prof_serial[dom]["calls"] / 2.0, 1e-9)
+            a1 = unit_work * per_launch_alone / (alone_ms * 1e-3)
+            roof["alone"] = {"avg_ms_per_launch": round(alone_ms, 4), "achieved": round(a1, 2), "frac": round(a1 / roof["peak"], 4),
+                             "what": "the dominant kernel on one internal stream, untimed extra pass (no concurrent kernels)"}
         # HBM bytes from rocprofv3 PMC passes of this same command (tools/profile_gpu.sh -> profiles/):
         # counters cannot be read from inside the process, so the file written by the last profiling
         # session is reported together with the digest of the HIP sources it was taken from
