@@ -560,3 +560,118 @@ def test_host_taps_are_converted_once_per_module_buffer():
     assert c is not a and torch.equal(c, buf.reshape(-1).float())
     half = _kernel_host(buf.reshape(-1)[:100], torch.float32)                              # another window of the same buffer
     assert half.numel() == 100 and torch.equal(half, buf.reshape(-1)[:100].float())
+
+
+# ------------------------------------------------------------------ plan cache and the ADVICE r2 planner fixes
+def _cfg5_members():
+    from scipy.signal import firwin
+    ir = np.random.default_rng(5).standard_normal(4097) * np.exp(-np.arange(4097) / 500.0)
+    return (F.LoButterworth(2000, order=4, fs=48000), F.ParametricEQ(frequency=1000, q=2.0, gain=3.0, fs=48000),
+            F.FIR(firwin(1024, 5000, fs=48000)), F.FIR(ir / np.abs(ir).sum()))
+
+
+def test_plan_cache_hits_and_invalidates():
+    from torchfx_amd import wave as W
+    W.plan_cache_clear()
+    f1, f2, fir, rev = _cfg5_members()
+    x = torch.zeros(2, 100_000)
+
+    def plan(members=(f1, f2, fir, rev), length=100_000):
+        w = fx.Wave(x[:, :length], 48000)
+        for m in members:
+            w = w | m
+        return w.plan()
+    p0 = plan()
+    assert [type(m).__name__ for m in p0] == ["FIR"] and len(W._PLANS) == 1
+    p1 = plan()
+    assert p1[0] is p0[0] and len(W._PLANS) == 1                  # same merged module, nothing re-derived
+    # another row length is another plan entry but re-uses the merged taps (content caches)
+    p2 = plan(length=90_000)
+    assert len(W._PLANS) == 2 and p2[0] is p0[0]
+    # re-design: compute_coefficients assigns a new SOS tensor -> miss, new taps
+    f1.cutoff = 3000
+    f1.compute_coefficients()
+    p3 = plan()
+    assert p3[0] is not p0[0] and not torch.equal(p3[0].kernel, p0[0].kernel)
+    # in-place edit of FIR taps bumps the version counter -> miss
+    rev.kernel.mul_(0.5)
+    p4 = plan()
+    assert p4[0] is not p3[0]
+    assert torch.allclose(p4[0].kernel, 0.5 * p3[0].kernel, rtol=1e-12, atol=1e-18)
+    # a Gain's settings are part of the key (fuse_gain bakes them into coefficients)
+    g = fx.effect.Gain(2.0)
+    w = fx.Wave(x, 48000); w.fuse_gain = True
+    a = (w | f1 | g | f2).plan()
+    g.gain = 4.0
+    w = fx.Wave(x, 48000); w.fuse_gain = True
+    b = (w | f1 | g | f2).plan()
+    assert not torch.equal(a[0]._sos, b[0]._sos)
+    # flags are part of the key
+    w = fx.Wave(x, 48000); w.fuse_spectral = False
+    assert [type(m).__name__ for m in (w | f1 | f2 | fir | rev).plan()] == ["FusedSOSCascade", "FIR"]
+
+
+def test_cached_plans_hand_out_fresh_cascades(oracle_backend):
+    """The reference builds a new FusedSOSCascade per materialisation (wave.py:216-233): a cached plan must not
+    carry the previous wave's state into the next one."""
+    from torchfx_amd import wave as W
+    W.plan_cache_clear()
+    f1, f2, _, _ = _cfg5_members()
+    x = torch.from_numpy(np.random.default_rng(0).standard_normal((2, 5000))).float()
+    w = fx.Wave(x, 48000); w.fuse_spectral = False
+    pa = (w | f1 | f2).plan()
+    ya = pa[0](x)
+    assert pa[0]._state_x is not None
+    w = fx.Wave(x, 48000); w.fuse_spectral = False
+    pb = (w | f1 | f2).plan()
+    assert pb[0] is not pa[0] and pb[0]._state_x is None and pb[0]._stream.table is pa[0]._stream.table
+    assert torch.equal(pb[0](x), ya)
+    y1 = (fx.Wave(x, 48000) | f1 | f2).ys
+    y2 = (fx.Wave(x, 48000) | f1 | f2).ys
+    assert torch.equal(y1, y2) and torch.equal(y1, ya)
+
+
+def test_steady_state_planning_is_cheap():
+    import time
+    from torchfx_amd import wave as W
+    W.plan_cache_clear()
+    f1, f2, fir, rev = _cfg5_members()
+    x = torch.zeros(2, 200_000)
+    (fx.Wave(x, 48000) | f1 | f2 | fir | rev).plan()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        (fx.Wave(x, 48000) | f1 | f2 | fir | rev).plan()
+    assert (time.perf_counter() - t0) / 20 < 1e-3            # VERDICT r2 #2: <= 1 ms host planning in steady state
+
+
+def test_user_held_cascade_and_stateful_fir_stay_staged(oracle_backend):
+    """(1) a FusedSOSCascade the user holds is stateful across waves and must never be folded into the
+    FIR behind it -- chunked use carries its state; (2) StatefulFIR (own forward, history, no epilogue kwarg) is
+    neither merged, nor folded into, nor given an epilogue."""
+    from torchfx_amd.effect import Gain, Normalize
+    from torchfx_amd.realtime import StatefulFIR
+    f1, f2, fir, rev = _cfg5_members()
+    held = F.FusedSOSCascade(f1, f2)
+    x = torch.from_numpy(np.random.default_rng(1).standard_normal((2, 40_000))).float()
+    w = fx.Wave(x, 48000)
+    assert w.fuse_spectral and w.fuse_fir and w.fuse_epilogue          # the default policy
+    plan = (w | held | fir).plan()
+    assert plan[0] is held and [type(m).__name__ for m in plan] == ["FusedSOSCascade", "FIR"]
+    # chunked == one shot through the default plan (state carried on the user's object)
+    whole = (fx.Wave(x, 48000) | F.FusedSOSCascade(f1, f2) | fir).ys
+    held.reset_state()
+    a = (fx.Wave(x[:, :25_000], 48000) | held).ys
+    b = (fx.Wave(x[:, 25_000:], 48000) | held).ys
+    y_iir = torch.cat([a, b], dim=1)
+    close(fir(y_iir), whole.numpy(), 1e-5)
+    s1, s2 = StatefulFIR(np.ones(8) / 8), StatefulFIR([0.5, 0.5])
+    plan = (fx.Wave(x, 48000) | s1 | s2 | Gain(0.5) | Normalize()).plan()
+    assert plan[0] is s1 and plan[1] is s2 and [type(m).__name__ for m in plan[2:]] == ["Gain", "Normalize"]
+    plan = (fx.Wave(x, 48000) | f1 | f2 | s1).plan()
+    assert [type(m).__name__ for m in plan] == ["FusedSOSCascade", "StatefulFIR"]
+    # ... and they run: history carried over two waves equals one shot
+    s1.reset_state()
+    ya = (fx.Wave(x[:, :10_000], 48000) | s1 | Gain(0.5)).ys
+    yb = (fx.Wave(x[:, 10_000:], 48000) | s1 | Gain(0.5)).ys
+    s1.reset_state()
+    close(torch.cat([ya, yb], dim=1), (fx.Wave(x, 48000) | s1 | Gain(0.5)).ys.numpy(), 1e-6)

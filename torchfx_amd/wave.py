@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import os
 import typing as tp
+from collections import OrderedDict
 
 import numpy as np
 import torch
@@ -56,44 +57,149 @@ def _fusion_defaults() -> tuple[bool, bool, bool, bool]:
             flag("TORCHFX_AMD_FUSE_EPILOGUE", auto))
 
 
-def _merge_fir_run(run: list) -> nn.Module:
-    """[FIR, FIR, ...] -> one FIR whose taps are the float64 convolution of the members'."""
+def _planner_fir(taps_flipped64: np.ndarray) -> nn.Module:
+    """A stateless FFT-mode FIR around float64 FLIPPED taps (rounded once, when the kernel casts to x.dtype)."""
     from torchfx_amd.filter.fir import FIR
 
-    taps = None
-    for f in run:
-        b = f.kernel.detach().cpu().reshape(-1).flip(0).to(torch.float64).numpy()
-        taps = b if taps is None else np.convolve(taps, b)
-    merged = FIR.__new__(FIR)
-    nn.Module.__init__(merged)
-    merged._conv_mode = "fft"
-    merged.a = [1.0]
-    # keep float64 taps: the merged filter is rounded once, when the kernel casts to x.dtype
-    merged.register_buffer("kernel", torch.from_numpy(taps[::-1].copy()).reshape(1, 1, -1))
-    return merged
-
-
-def _iir_as_fir(run: list, max_taps: int = 1 << 17) -> nn.Module | None:
-    """A *fresh* (stateless) run of IIR/Biquad steps as an equivalent FIR: the cascade's impulse
-    response truncated where the kernel planner says the filter has forgotten its past to float64
-    round-off (`warmup`: max|A^W| < 2^-60).  None when the memory is too long."""
-    import scipy.signal as sg
-
-    from torchfx_amd import torchfx_ext
-    from torchfx_amd.filter.fir import FIR
-
-    sos = torch.cat([f._sos for f in run]).numpy()
-    w = torchfx_ext.sos_plan_info(sos)["warmup"]
-    if w < 0 or w > max_taps:
-        return None
-    imp = np.zeros(int(w) + 1)
-    imp[0] = 1.0
-    h = sg.sosfilt(sos, imp)                       # float64 impulse response, |tail| < 1e-18
     fir = FIR.__new__(FIR)
     nn.Module.__init__(fir)
     fir._conv_mode, fir.a = "fft", [1.0]
-    fir.register_buffer("kernel", torch.from_numpy(h[::-1].copy()).reshape(1, 1, -1))
+    fir.register_buffer("kernel", torch.from_numpy(np.ascontiguousarray(taps_flipped64)).reshape(1, 1, -1))
     return fir
+
+
+def _convolve64(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """Float64 linear convolution; long operands go through one real FFT (error ~1e-16 of |a|·|b|, far
+    below the float32 rounding the taps get at launch) instead of an O(Ka·Kb) ``np.convolve``: merging a
+    2 419-tap impulse response into 66 559 taps costs 6 ms instead of 110."""
+    if min(a.size, b.size) < 64:
+        return np.convolve(a, b)
+    n = a.size + b.size - 1
+    nfft = 1 << (n - 1).bit_length()
+    return np.fft.irfft(np.fft.rfft(a, nfft) * np.fft.rfft(b, nfft), nfft)[:n]
+
+
+# merged FIRs by the identity + version of the member kernels (strong references keep the ids unique)
+_MERGED: "OrderedDict[tuple, tuple[list, nn.Module]]" = OrderedDict()
+# impulse responses of fresh cascades by SOS content
+_IIR_FIR: "OrderedDict[bytes, nn.Module | None]" = OrderedDict()
+_CACHE_MAX = 32
+
+
+def _lru_put(cache: OrderedDict, key, value) -> None:
+    cache[key] = value
+    while len(cache) > _CACHE_MAX:
+        cache.popitem(last=False)
+
+
+def _merge_fir_run(run: list) -> nn.Module:
+    """[FIR, FIR, ...] -> one FIR whose taps are the float64 convolution of the members'.  Cached per set of
+    member kernels (tensor identity + version counter), so a pipeline that is planned again -- another wave,
+    another length -- does not convolve again."""
+    kernels = [f.kernel for f in run]
+    key = tuple((id(k), k._version) for k in kernels)
+    hit = _MERGED.get(key)
+    if hit is not None:
+        _MERGED.move_to_end(key)
+        return hit[1]
+    taps = None
+    for k in kernels:
+        b = k.detach().cpu().reshape(-1).flip(0).to(torch.float64).numpy()
+        taps = b if taps is None else _convolve64(taps, b)
+    merged = _planner_fir(taps[::-1])
+    _lru_put(_MERGED, key, (kernels, merged))
+    return merged
+
+
+def _iir_as_fir(sos_t: Tensor, max_taps: int = 1 << 17) -> nn.Module | None:
+    """A *fresh* (stateless) SOS cascade as an equivalent FIR: its impulse response truncated where the
+    kernel planner says the filter has forgotten its past to float64 round-off (`warmup`:
+    max|A^W| < 2^-60).  None when the memory is too long.  Cached by coefficient content."""
+    import scipy.signal as sg
+
+    from torchfx_amd import torchfx_ext
+
+    sos = np.ascontiguousarray(sos_t.detach().cpu().numpy(), dtype=np.float64)
+    key = sos.tobytes()
+    if key in _IIR_FIR:
+        _IIR_FIR.move_to_end(key)
+        return _IIR_FIR[key]
+    w = torchfx_ext.sos_plan_info(sos)["warmup"]
+    fir = None
+    if 0 <= w <= max_taps:
+        imp = np.zeros(int(w) + 1)
+        imp[0] = 1.0
+        h = sg.sosfilt(sos, imp)                       # float64 impulse response, |tail| < 1e-18
+        fir = _planner_fir(h[::-1])
+    _lru_put(_IIR_FIR, key, fir)
+    return fir
+
+
+# ---- plan cache -----------------------------------------------------------------------------------
+# The reference's materialisation is a cheap ``torch.cat`` of SOS rows per ``.ys`` (wave.py:207-239).  Ours
+# derives merged taps and impulse responses, so the planned module list is cached per *pipeline*: the key is
+# the identity of every member plus what the planner reads from it (coefficient tensor identity + version
+# counter, fs, conv mode, gain settings, strategy type), the four fusion flags and the row length (the
+# spectral fold asks the overlap-save geometry whether it pays).  Redesigning a filter
+# (``compute_coefficients`` / ``set_parameter`` assign a new tensor), editing coefficients in place (version
+# counter) or changing a Gain therefore miss; ``reset_state`` never matters because cached plans hold no
+# state: planner-built cascades are re-instantiated around their cached table on every hit.  Entries keep
+# strong references to the members and their coefficient tensors, so an ``id`` cannot be recycled while its
+# entry lives; the cache is a 32-entry LRU.
+_PLANS: "OrderedDict[tuple, tuple[list, list]]" = OrderedDict()
+
+
+def plan_cache_clear() -> None:
+    _PLANS.clear()
+    _MERGED.clear()
+    _IIR_FIR.clear()
+
+
+def _member_key(m: nn.Module, guard: list) -> tuple:
+    from torchfx_amd.effect import Gain, Normalize
+
+    guard.append(m)
+    k: tuple = (id(m),)
+    sos = getattr(m, "_sos", None)
+    if isinstance(sos, Tensor):
+        guard.append(sos)
+        k += (id(sos), sos._version, getattr(m, "fs", None))
+    ker = getattr(m, "kernel", None)
+    if isinstance(ker, Tensor):
+        guard.append(ker)
+        k += (id(ker), ker._version, getattr(m, "_conv_mode", None))
+    if isinstance(m, Gain):
+        k += (m.gain, m.gain_type, m.clamp)
+    elif isinstance(m, Normalize):
+        guard.append(m.strategy)
+        k += (id(m.strategy),)
+    return k
+
+
+def _instantiate(cached: list) -> list:
+    """A runnable plan from a cached one: planner-built cascades carry state while they run, so every
+    materialisation gets its own (the reference builds a fresh ``FusedSOSCascade`` per ``.ys`` as well)."""
+    from torchfx_amd.effect import Epilogued
+    from torchfx_amd.filter.fused import FusedSOSCascade
+
+    def fresh(m):
+        if getattr(m, "_planner_built", False) and isinstance(m, FusedSOSCascade):
+            c = FusedSOSCascade.from_table(m._stream.table)
+            c._planner_built = True
+            return c
+        if isinstance(m, Epilogued) and getattr(m.producer, "_planner_built", False):
+            return Epilogued(fresh(m.producer), m.gain, m.norm)
+        return m
+    return [fresh(m) for m in cached]
+
+
+def _plain_fir(m) -> bool:
+    """FIR steps the planner may merge, fold into or attach an epilogue to: the stock stateless classes only.  A
+    subclass with its own ``forward`` (``realtime.StatefulFIR`` carries history and takes no ``epilogue``) is
+    staged as it is."""
+    from torchfx_amd.filter.fir import FIR, DesignableFIR
+
+    return isinstance(m, FIR) and type(m).forward in (FIR.forward, DesignableFIR.forward)
 
 
 class Wave:
@@ -121,7 +227,22 @@ class Wave:
         self._pipeline = []
 
     def plan(self) -> list[nn.Module]:
-        """The fused execution plan of the pending pipeline (``wave.py:216-233``)."""
+        """The fused execution plan of the pending pipeline (``wave.py:216-233``), from the plan cache when
+        this pipeline -- same members, same coefficients, same flags, same row length -- was planned before."""
+        flags = (self.fuse_fir, getattr(self, "fuse_spectral", False), getattr(self, "fuse_gain", False),
+                 getattr(self, "fuse_epilogue", False))
+        length = int(self._ys.shape[-1]) if self._ys.dim() else 0
+        guard: list = []
+        key = (tuple(_member_key(m, guard) for m in self._pipeline), flags, length)
+        hit = _PLANS.get(key)
+        if hit is not None:
+            _PLANS.move_to_end(key)
+            return _instantiate(hit[1])
+        built = self._build_plan(length)
+        _lru_put(_PLANS, key, (guard, built))
+        return _instantiate(built)
+
+    def _build_plan(self, length: int) -> list[nn.Module]:
         from torchfx_amd.filter.biquad import Biquad
         from torchfx_amd.filter.fir import FIR
         from torchfx_amd.filter._sos import CascadeTable
@@ -162,7 +283,9 @@ class Wave:
                     else:
                         nxt += 1
                 if kind == "iir":
-                    plan.append(FusedSOSCascade.from_table(CascadeTable.gather(filters, scales)))
+                    cascade = FusedSOSCascade.from_table(CascadeTable.gather(filters, scales))
+                    cascade._planner_built = True     # fresh per materialisation; the only cascades folded spectrally
+                    plan.append(cascade)
                 else:
                     mem = [scaled_fir(m, g) for m, g in zip(filters, scales)]
                     plan.append(_merge_fir_run(mem) if len(mem) >= 2 else mem[0])
@@ -173,7 +296,7 @@ class Wave:
                 (items if kind is not None else lead).append(m)
                 continue
             k = "iir" if isinstance(m, (IIR, Biquad)) else (
-                "fir" if (isinstance(m, FIR) and m._conv_mode != "direct" and (self.fuse_fir or fold)) else None)
+                "fir" if (_plain_fir(m) and m._conv_mode != "direct" and (self.fuse_fir or fold)) else None)
             if k is None or (kind is not None and k != kind) or (k == "fir" and kind == "fir" and not self.fuse_fir):
                 flush()
             if k is None:
@@ -189,7 +312,7 @@ class Wave:
         flush()
         plan.extend(lead)
         if getattr(self, "fuse_spectral", False):
-            plan = self._spectral_plan(plan, int(self._ys.shape[-1]) if self._ys.dim() else 0)
+            plan = self._spectral_plan(plan, length)
         if getattr(self, "fuse_epilogue", False):
             plan = self._epilogue_plan(plan)
         return plan
@@ -210,7 +333,7 @@ class Wave:
         i = 0
         while i < len(plan):
             m = plan[i]
-            producer = isinstance(m, (IIR, Biquad, FusedSOSCascade)) or (isinstance(m, FIR) and m._conv_mode != "direct")
+            producer = isinstance(m, (IIR, Biquad, FusedSOSCascade)) or (_plain_fir(m) and m._conv_mode != "direct")
             gain = norm = None
             j = i + 1
             if producer and j < len(plan) and isinstance(plan[j], Gain):
@@ -242,9 +365,10 @@ class Wave:
         impulse response, truncated where the cascade has forgotten its past to float64 round-off --
         the whole run becomes a single overlap-save pass (8 B/sample less HBM traffic, the recursive
         kernel is not launched).  The IIR part then runs in float32 FFT arithmetic like the FIR it
-        joins (error ~1e-6 of the output scale instead of 1 ulp).  Not applied when the cascade carries
-        state (a lone IIR step, a user-held ``FusedSOSCascade`` that has run), when the FIR is in direct
-        mode, or when the longer taps would cost the overlap-save pass more HBM bytes per sample (block
+        joins (error ~1e-6 of the output scale instead of 1 ulp).  Only cascades the planner built itself in
+        this plan are folded: a lone IIR step and a user-held ``FusedSOSCascade`` carry state from wave to
+        wave (``fused.py:120-131``) and stay staged, whether they have run yet or not.  Not applied when the
+        FIR is in direct mode or has its own ``forward`` (``StatefulFIR``), or when the longer taps would cost the overlap-save pass more HBM bytes per sample (block
         efficiency) than the 8 B/sample the recursive pass takes."""
         from torchfx_amd.filter.fir import FIR
         from torchfx_amd.filter.fused import FusedSOSCascade
@@ -254,9 +378,9 @@ class Wave:
         while i < len(plan):
             m = plan[i]
             nxt = plan[i + 1] if i + 1 < len(plan) else None
-            if (isinstance(m, FusedSOSCascade) and m._state_x is None and isinstance(nxt, FIR)
-                    and nxt._conv_mode != "direct"):
-                eq = _iir_as_fir([m])
+            if (isinstance(m, FusedSOSCascade) and getattr(m, "_planner_built", False) and m._state_x is None
+                    and _plain_fir(nxt) and nxt._conv_mode != "direct"):
+                eq = _iir_as_fir(m._sos)
                 if eq is not None:
                     k0, k1 = int(nxt.kernel.numel()), int(nxt.kernel.numel()) + int(eq.kernel.numel()) - 1
                     try:
