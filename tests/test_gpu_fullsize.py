@@ -96,6 +96,20 @@ def test_cfg3_fir_direct_64ch_60s():
     assert torch.equal(yi[0, 7:7 + 1024].cpu(), torch.from_numpy(kf[::-1].copy()))
 
 
+def _slab_seam(K, T):
+    """(channel, sample) of the first seam between two overlap-save slabs that falls inside a row: slab s covers
+    frame pairs [128 s, 128 s + 128) (1 GB of workspace per internal stream, N = 2^20), i.e. frames from 256 s on,
+    and consecutive slabs run on different internal streams -- the frames either side of the seam are computed by
+    different launches on different streams."""
+    info = ext().ols_plan_info(K, T, (K - 1, 0))
+    assert info["native"] and info["N"] == 1 << 20
+    F, S = info["F"], info["S"]
+    f = 256
+    while f % F == 0:
+        f += 256
+    return f // F, (f % F) * S
+
+
 def test_cfg4_fftconv_64ch_600s():
     C, T, K = 64, 600 * FS, 65536
     kf = reverb_ir()[::-1].copy()
@@ -110,6 +124,12 @@ def test_cfg4_fftconv_64ch_600s():
         assert np.abs(y[c, :n].cpu().numpy() - e0[0]).max() <= 1e-5
         e1 = O.fft_conv1d(xc[:, -n - (K - 1):], kf, (0, 0))
         assert np.abs(y[c, -n:].cpu().numpy() - e1[0]).max() <= 1e-5
+    # a mid-signal window straddling a slab / internal-stream seam
+    c, mid = _slab_seam(K, T)
+    lo, hi = mid - 8 * FS, mid + 8 * FS
+    assert 0 < c < C and K - 1 <= lo and hi <= T
+    em = O.fft_conv1d(x[c:c + 1, lo - (K - 1):hi].cpu().numpy(), kf, (0, 0))
+    assert np.abs(y[c, lo:hi].cpu().numpy() - em[0]).max() <= 1e-5
     # linearity at full size
     x2 = signal(C, T, 5)
     yb = ext().fft_conv_forward(x2, kf, (K - 1, 0))
@@ -155,6 +175,15 @@ def test_cfg5_chain_per_gpu_64ch_600s(workload):
         assert np.abs(y[c, :n].cpu().numpy() - head[0]).max() <= 1e-5 * scale, (desc, c, "head")
         tail = _staged_oracle_window(xrow, sos, kf, kr, T - n, T)
         assert np.abs(y[c, T - n:].cpu().numpy() - tail[0]).max() <= 1e-5 * scale, (desc, c, "tail")
+    # mid-signal: 15 s around the first slab / internal-stream seam that falls inside a row
+    taps = max(int(m.kernel.numel()) for m in bench.plan_chain(x[:1], *({"chain": (None, None), "chain_iir_kernel": (True, False)}[workload]))[0]
+               if hasattr(m, "kernel"))
+    c, mid = _slab_seam(taps, T)
+    lo, hi = mid - n // 2, mid + n // 2
+    assert 0 < c < C and 0 < lo and hi < T
+    xrow = x[c:c + 1].cpu().numpy()
+    win = _staged_oracle_window(xrow, sos, kf, kr, lo, hi)
+    assert np.abs(y[c, lo:hi].cpu().numpy() - win[0]).max() <= 1e-5 * max(1.0, float(np.abs(win).max())), (desc, c, "seam")
     # the whole length of two rows: staged GPU ops == this plan
     ys = ext().sos_forward(x[:2].contiguous(), None, torch.from_numpy(sos), None, None)[0]
     ys = ext().fft_conv_forward(ys, kf, (1023, 0))
@@ -221,3 +250,43 @@ def test_more_than_2_31_samples_in_one_call():
     for c in rows:
         ey = O.fft_conv1d(xh[c], kf, (K - 1, 0))
         assert np.abs(y[c].cpu().numpy() - ey[0]).max() <= 1e-5
+
+
+def test_wave_ys_runs_at_the_planned_rate():
+    """the product entry point ``(Wave(x) | f1 | f2 | fir | rev).ys`` must deliver the benchmarked
+    rate -- the plan (merged 68 977-tap kernel) comes from the plan cache, so ten repeated ``.ys`` on 64 ch x 600 s
+    average <= 1.1 x the step of the pre-planned modules, and planning costs <= 1 ms of host time per call."""
+    import time
+    import bench
+    from torchfx_amd import Wave
+    C, T = 64, 600 * FS
+    x = signal(C, T, 11)
+    f1, f2, fir, rev = bench.build_filters()
+
+    def ys():
+        return (Wave(x, FS, device=x.device) | f1 | f2 | fir | rev).ys
+    t0 = time.perf_counter()
+    y0 = ys()
+    torch.cuda.synchronize()
+    first_ms = (time.perf_counter() - t0) * 1e3
+    plan, _ = bench.plan_chain(x)
+
+    def timed(fn, n):
+        out = fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            out = None
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e3, out
+    planned_ms, yp = timed(lambda: bench.run_plan(plan, x), 10)
+    ys_ms, y1 = timed(ys, 10)
+    assert torch.equal(y1, y0) and torch.equal(y1, yp)
+    t = time.perf_counter()
+    for _ in range(20):
+        (Wave(x, FS, device=x.device) | f1 | f2 | fir | rev).plan()
+    plan_host_ms = (time.perf_counter() - t) / 20 * 1e3
+    print(f"\n.ys first {first_ms:.1f} ms, steady {ys_ms:.3f} ms, pre-planned step {planned_ms:.3f} ms, plan() {plan_host_ms:.3f} ms host")
+    assert plan_host_ms <= 1.0
+    assert ys_ms <= 1.1 * planned_ms

@@ -502,35 +502,90 @@ ols_row1024_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *_
 // 74.6 % at N = 2^18).  One workgroup per row, thread j owns elements n2 = j + 256 t: radix
 // (16, 16, 16) Stockham, three register stages and two LDS exchanges per direction.
 // ---------------------------------------------------------------------------------------------
-template <bool INV>
+// Exchange layout XCH (physical LDS position of logical p is p + p/16 in both):
+//   0  "write strided, read contiguous" (textbook Stockham): stage-1 butterfly j scatters output k to 16 j + k,
+//      stage 2 gathers j + 256 t.  The ds_write_b64 groups (16 contiguous lanes, banks mod 32 dwords) are
+//      conflict-free, but a ds_read_b64 group is 32 lanes and the 32 positions j + j/16 straddle one pad slot:
+//      lanes 0 and 31 of every group meet on one bank -> every read of stages 2 and 3 takes two LDS cycles per
+//      group instead of one (PMC round 2: SQ_LDS_BANK_CONFLICT = 54 % of the LDS-active cycles).
+//   1  "write contiguous, read strided": with digits n = n0 + 16 n1 + 256 n2, k = k0 + 16 k1 + 256 k2
+//        stage 1  thread j = n0 + 16 n1 : DFT over n2 -> A[k0] stored at  j + 256 k0
+//        stage 2  thread j = n0 + 16 k0 : reads (n0 + 256 k0) + 16 n1, * W256^(n1 k0), DFT over n1 -> B[k1] at j + 256 k1
+//        stage 3  thread j = k0 + 16 k1 : reads 16 j + n0 (its own 16 consecutive slots), * W4096^(n0 j), DFT over n0
+//      -> X[j + 256 k2], the same ownership as the input.  Physical addresses stay base + immediate:
+//      j + j/16 + 272 k (stores: 16 contiguous lanes -> 16 contiguous slots), (j & 15) + 272 (j >> 4) + 17 t
+//      (stage-2 loads: two runs of 16 slots 272 = 16 (mod 32) apart) and 17 j + t (stage-3 loads: 17 is odd, so 32
+//      consecutive j hit 32 different slots mod 32) -- no conflicts on either side.
+//   2  layout 1 with the sixteen loads of a stage issued as single ds_read_b64 from one asm statement (default): the
+//      compiler pairs them into ds_read2_b64, which the LDS serves at half the bytes per clock.
+// Measured on cfg 4 (one stream, same box, profiles/r03_experiments.txt): 4.01 / 3.73 / 3.69 ms for XCH 0 / 1 / 2.
+// Sixteen ds_read_b64 at base + t * STRIDE_B that the load/store optimiser cannot pair into ds_read2_b64 (two
+// 16-lane-group accesses with 32-dword banking at half the bytes per clock, MI355X_MICROARCH.md LDS table): the
+// reads are issued from one asm statement, which also waits for them (the compiler does not track asm loads).
+template <int STRIDE_B>
+__device__ __forceinline__ void lds_read16_b64(cpx (&v)[16], const cpx *p)
+{
+    typedef const char __attribute__((address_space(3))) *lds_ptr;
+    const unsigned a = (unsigned)(uintptr_t)(lds_ptr)(const char *)p;
+    double d[16];
+    asm volatile(
+        "ds_read_b64 %0, %16 offset:%17\n\tds_read_b64 %1, %16 offset:%18\n\tds_read_b64 %2, %16 offset:%19\n\t"
+        "ds_read_b64 %3, %16 offset:%20\n\tds_read_b64 %4, %16 offset:%21\n\tds_read_b64 %5, %16 offset:%22\n\t"
+        "ds_read_b64 %6, %16 offset:%23\n\tds_read_b64 %7, %16 offset:%24\n\tds_read_b64 %8, %16 offset:%25\n\t"
+        "ds_read_b64 %9, %16 offset:%26\n\tds_read_b64 %10, %16 offset:%27\n\tds_read_b64 %11, %16 offset:%28\n\t"
+        "ds_read_b64 %12, %16 offset:%29\n\tds_read_b64 %13, %16 offset:%30\n\tds_read_b64 %14, %16 offset:%31\n\t"
+        "ds_read_b64 %15, %16 offset:%32\n\ts_waitcnt lgkmcnt(0)"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]),
+          "=&v"(d[8]), "=&v"(d[9]), "=&v"(d[10]), "=&v"(d[11]), "=&v"(d[12]), "=&v"(d[13]), "=&v"(d[14]), "=&v"(d[15])
+        : "v"(a), "n"(0 * STRIDE_B), "n"(1 * STRIDE_B), "n"(2 * STRIDE_B), "n"(3 * STRIDE_B), "n"(4 * STRIDE_B),
+          "n"(5 * STRIDE_B), "n"(6 * STRIDE_B), "n"(7 * STRIDE_B), "n"(8 * STRIDE_B), "n"(9 * STRIDE_B), "n"(10 * STRIDE_B),
+          "n"(11 * STRIDE_B), "n"(12 * STRIDE_B), "n"(13 * STRIDE_B), "n"(14 * STRIDE_B), "n"(15 * STRIDE_B)
+        : "memory");
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = __builtin_bit_cast(cpx, d[t]);
+}
+
+template <bool INV, int XCH>
 __device__ __forceinline__ void row_fft4096(cpx (&v)[16], cpx *lds, const cpx *twB, const cpx *twA, int j)
 {
-    dft16<INV>(v);                                             // stage A, Ns = 1
+    dft16<INV>(v);                                             // stage 1
+    const int kb = j & 15, jh = j >> 4;
+    if (XCH == 0) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) lds[pad16(16 * j + k)] = v[DFT16_AT(k)];
+        for (int k = 0; k < 16; ++k) lds[pad16(16 * j + k)] = v[DFT16_AT(k)];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lds[j + jh + 272 * k] = v[DFT16_AT(k)];
+    }
     __syncthreads();
-    const int kb = j & 15;                                     // stage B, Ns = 16: twiddle W256^(t kb)
+    if (XCH == 2) lds_read16_b64<17 * 8>(v, lds + kb + 272 * jh);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        cpx x = lds[pad16(j + 256 * t)];
+    for (int t = 0; t < 16; ++t) {                             // stage 2: twiddle W256^(t k0)
+        cpx x = XCH == 0 ? lds[pad16(j + 256 * t)] : (XCH == 2 ? v[t] : lds[kb + 272 * jh + 17 * t]);
         if (t > 0) {
-            const cpx w = twB[16 * t + kb];                      // W256^(t kb), [t][kb]: conflict-free
+            const cpx w = twB[16 * t + (XCH == 0 ? kb : jh)];    // [t][k0]: broadcast within a group
             x = INV ? cmulc(x, w) : cmul(x, w);
         }
         v[t] = x;
     }
     __syncthreads();
     dft16<INV>(v);
-    const int j0 = (j >> 4) * 256 + kb;
+    if (XCH == 0) {
+        const int j0 = jh * 256 + kb;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) lds[pad16(j0 + 16 * k)] = v[DFT16_AT(k)];
+        for (int k = 0; k < 16; ++k) lds[pad16(j0 + 16 * k)] = v[DFT16_AT(k)];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) lds[j + jh + 272 * k] = v[DFT16_AT(k)];
+    }
     __syncthreads();
+    if (XCH == 2) lds_read16_b64<8>(v, lds + 17 * j);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {                             // stage C, Ns = 256: twiddle W4096^(t j)
-        cpx x = lds[pad16(j + 256 * t)];
+    for (int t = 0; t < 16; ++t) {                             // stage 3: twiddle W4096^(t j)
+        cpx x = XCH == 0 ? lds[pad16(j + 256 * t)] : (XCH == 2 ? v[t] : lds[17 * j + t]);
         if (t > 0) {
             // W4096^(t j) = W4096^(t (j & 15)) * W256^(t (j >> 4)): two [t][.] tables, conflict-free
-            const cpx w = cmul(twA[16 * t + kb], twB[16 * t + (j >> 4)]);
+            const cpx w = cmul(twA[16 * t + kb], twB[16 * t + jh]);
             x = INV ? cmulc(x, w) : cmul(x, w);
         }
         v[t] = x;
@@ -554,7 +609,7 @@ __device__ __forceinline__ void row_fft4096(cpx (&v)[16], cpx *lds, const cpx *t
 //      hit in that XCD's L2 by the other np - 1 rows (was: re-fetched for about every second pair,
 //      +25 % read traffic of this pass).
 // (Keeping Hp[k1] in registers and looping a workgroup over the pairs needs 168 VGPRs -> spills at 3 waves/SIMD.)
-template <int MAP>
+template <int MAP, int XCH>
 __global__ void __launch_bounds__(256, 4)
 ols_row4096_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *__restrict__ tw256g,
                    const cpx *__restrict__ t4log, const cpx *__restrict__ t4hig,
@@ -595,12 +650,12 @@ ols_row4096_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *_
             const cpx ut = make_float2(tuc[iu], tuc[iu + 1]);
             v[t] = cmul(base[j + 256 * t], cmul(wl, ut));
         }
-        row_fft4096<false>(v, lds, twB, twA, j);
+        row_fft4096<false, XCH>(v, lds, twB, twA, j);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 16; ++t) v[t] = cmul(v[t], hrow[j + 256 * t]);
         __builtin_amdgcn_sched_barrier(0);
-        row_fft4096<true>(v, lds, twB, twA, j);
+        row_fft4096<true, XCH>(v, lds, twB, twA, j);
         float wlx = wl.x, wly = wl.y;
         asm volatile("" : "+v"(wlx), "+v"(wly));     // recompute, do not keep 16 twiddles live (see row1024)
         const cpx wl2 = make_float2(wlx, wly);
@@ -841,15 +896,17 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     static const coli_t coli_tab[2][4] = {
         {ols_col_inv16_kernel<2, 0>, ols_col_inv16_kernel<2, 1>, ols_col_inv16_kernel<2, 2>, ols_col_inv16_kernel<2, 3>},
         {ols_col_inv16_kernel<1, 0>, ols_col_inv16_kernel<1, 1>, ols_col_inv16_kernel<1, 2>, ols_col_inv16_kernel<1, 3>}};
-    static const row_t row_tab[2] = {ols_row4096_kernel<0>, ols_row4096_kernel<1>};
+    static const row_t row_tab[6] = {ols_row4096_kernel<0, 0>, ols_row4096_kernel<1, 0>, ols_row4096_kernel<0, 1>, ols_row4096_kernel<1, 1>,
+                                     ols_row4096_kernel<0, 2>, ols_row4096_kernel<1, 2>};
     const colf_t colf = colf_tab[nbf == 1][probe & 3];
     const coli_t coli = coli_tab[nbf == 1][probe & 3];
-    const row_t rowk = row_tab[rowmap == 0 ? 0 : 1];
+    const int xch = (int)envi("TFX_OLS_ROW_XCH", 2);
+    const row_t rowk = row_tab[(rowmap == 0 ? 0 : 1) + 2 * (xch < 0 || xch > 2 ? 2 : xch)];
     static bool attr_tab[TFX_MAX_DEVICES] = {};
     const int dev = current_device();
     bool &attr = attr_tab[dev];
     if (!attr) {
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 6; ++a)
             TFX_HIP(hipFuncSetAttribute((const void *)row_tab[a], hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
         for (int a = 0; a < 2; ++a)
             for (int b = 0; b < 4; ++b) {
