@@ -47,14 +47,22 @@ def _worker(rank, world, port, C, out_dir):
         # no-gather mode returns only the local rows
         yl = D.filter_sharded([F.BiquadHPF(300, 0.7)], x, 48000, gather=False)
         assert yl.shape[0] == hi - lo
+        # the root's own preallocated output: blocks land in its row views, the very buffer comes back
+        buf = torch.full((C, 6000), float("nan")) if rank == 1 else None
+        yb = D.gather_rows(yl, C, dst=1, out=buf)
+        if rank == 1:
+            assert yb is buf and torch.isfinite(buf).all() and torch.equal(buf[lo:hi], yl)
+            torch.save(buf, os.path.join(out_dir, "hpf.pt"))
+        else:
+            assert yb is None
+        assert D.ranks_seen() == world
     finally:
         dist.barrier()
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("C", [4, 5])
-def test_sharded_equals_single_process(tmp_path, oracle_backend, C):
-    world = 2
+@pytest.mark.parametrize("C,world", [(4, 2), (5, 2), (7, 3), (2, 3)])
+def test_sharded_equals_single_process(tmp_path, oracle_backend, C, world):
     mp.spawn(_worker, args=(world, _free_port(), C, str(tmp_path)), nprocs=world, join=True)
     y = torch.load(os.path.join(tmp_path, "gathered.pt"))
     from torchfx_amd import Wave
@@ -65,6 +73,7 @@ def test_sharded_equals_single_process(tmp_path, oracle_backend, C):
            | F.FIR(np.hanning(65) / np.hanning(65).sum())).ys
     assert y.shape == ref.shape
     assert torch.equal(y, ref)       # rows are independent: sharding changes nothing, bit for bit
+    assert torch.equal(torch.load(os.path.join(tmp_path, "hpf.pt")), (Wave(x, 48000) | F.BiquadHPF(300, 0.7)).ys)
 
 
 def test_shard_bounds_cover_all_rows():

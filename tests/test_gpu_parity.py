@@ -54,7 +54,8 @@ def rnd(shape, seed, dtype=np.float32):
     return (x / np.abs(x).max()).astype(dtype)
 
 
-@pytest.fixture(params=[0, 1, 2, 3], ids=["lc32", "lc16", "lc32pf", "lc16pf"])
+# 4 = LC 64 (the float64 default that ships), 2 = LC 32 + prefetch (the float32 default); 5 = LC 64 + prefetch
+@pytest.fixture(params=[0, 1, 2, 3, 4, 5], ids=["lc32", "lc16", "lc32pf", "lc16pf", "lc64", "lc64pf"])
 def sos_variant(request, monkeypatch):
     monkeypatch.setenv("TFX_SOS_VARIANT", str(request.param))
     return request.param
@@ -444,6 +445,56 @@ def test_chain_with_iir_gain_golden(golden, policy):
          | F.HiButterworth(80, order=2) | F.FIR(firwin(257, 6000, fs=48000)) | F.FIR(8.0 * irg / np.abs(irg).sum()))
     assert len(w.plan()) == {"auto": 1, "fir_only": 2, "reference": 3}[policy]
     close(w.ys, g["y"], TOL_CONV_F32, f"chain with IIR gain, plan {policy}")
+
+
+@pytest.mark.parametrize("case", ["hp20", "shelf40", "hp20_shelf40", "lone_stateful", "held_cascade"])
+def test_spectral_fold_targeted_cases(case):
+    """the default plan against the STAGED oracle on the filters where folding an IIR run into the
+    FFT FIR behind it is least comfortable -- a 20 Hz high-pass (pole radius 0.998, 22 000-tap impulse response,
+    exact DC null the float32 FFT has to reproduce), a +40 dB shelf (gain 100) -- and the two runs the planner must
+    refuse: a lone IIR and a user-held FusedSOSCascade, both stateful across waves (chunked == one shot)."""
+    from scipy.signal import firwin
+    from torchfx_amd import Wave
+    from torchfx_amd import filter as F
+    x = rnd((3, 400_000), 77)
+    x += 0.25                                                      # a DC offset for the high-pass to remove
+    fir = F.FIR(firwin(513, 7000, fs=48000))
+    kf = fir.kernel.numpy().reshape(-1)
+    mk = {"hp20": lambda: [F.HiButterworth(20, order=2, fs=48000), F.LoButterworth(9000, order=2, fs=48000)],
+          "shelf40": lambda: [F.LoShelving(200, q=0.7, gain=40.0, gain_scale="db", fs=48000), F.HiButterworth(300, order=2, fs=48000)],
+          "hp20_shelf40": lambda: [F.HiButterworth(20, order=4, fs=48000), F.LoShelving(100, q=0.7, gain=40.0, gain_scale="db", fs=48000)],
+          "lone_stateful": lambda: [F.HiButterworth(20, order=2, fs=48000)],
+          "held_cascade": lambda: [F.FusedSOSCascade(F.HiButterworth(20, order=2, fs=48000), F.LoButterworth(9000, order=2, fs=48000))]}[case]
+    members = mk()
+    for m in members:
+        if hasattr(m, "compute_coefficients") and getattr(m, "_sos", None) is None:
+            m.compute_coefficients()
+    sos = np.vstack([m._sos.numpy() for m in members])
+    ref = O.chain_forward(x, sos, [kf])
+    scale = max(1.0, float(np.abs(ref).max()))
+
+    def pipe(xs):
+        w = Wave(xs, 48000, device=DEV)
+        for m in members:
+            w = w | m
+        return w | fir
+    w = pipe(x)
+    names = [type(m).__name__ for m in w.plan()]
+    if case in ("lone_stateful", "held_cascade"):
+        assert len(names) == 2 and names[1] == "FIR" and w.plan()[0] is members[0], names      # staged: the module itself runs
+    else:
+        assert names in (["FIR"], ["FusedSOSCascade", "FIR"]), names                                # folded only if it pays
+    y = w.ys
+    err = float(np.abs(y.cpu().numpy() - ref).max())
+    assert err <= 1e-5 * scale, (case, names, err, scale)
+    if case in ("lone_stateful", "held_cascade"):
+        # the state is carried on the user's object from wave to wave: two chunks == one shot (IIR part exactly;
+        # the stateless FIR is applied to the concatenated IIR output)
+        members[0].reset_state()
+        a = (Wave(x[:, :150_000], 48000, device=DEV) | members[0]).ys
+        b = (Wave(x[:, 150_000:], 48000, device=DEV) | members[0]).ys
+        yi = torch.cat([a, b], dim=1)
+        close(fir(yi), ref, 1e-5, "chunked " + case)
 
 
 def test_module_shapes_dtype_and_state_rules(golden):
@@ -1165,6 +1216,62 @@ def test_two_ranks_share_one_device_hip_kernels_sharded_and_gathered(tmp_path):
     assert torch.equal(loc, F.HiButterworth(300, order=4, fs=48000)(x).cpu())
 
 
+def _sharded_rccl_worker(rank, world, port, C, out_dir):
+    """One rank per GPU over backend "nccl" (= RCCL): uneven row blocks, the gather lands in row views of one
+    preallocated output on the root, ranks_seen counts the ranks on the collective itself."""
+    import os
+    import sys
+
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    devr = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=devr)
+    try:
+        from torchfx_amd import distributed as D
+        from torchfx_amd import filter as F
+        assert D.ranks_seen(device=devr) == world
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(C, 150_000, generator=g).to(devr)
+        pipe = [F.LoButterworth(2000, order=6), F.ParametricEQ(1000, 2.0, 3.0), F.FIR(np.hanning(301) / np.hanning(301).sum())]
+        root = world - 1                                     # not rank 0: the root index is honoured
+        out = torch.full((C, 150_000), float("nan"), device=devr) if rank == root else None
+        y = D.filter_sharded(pipe, x, 48000, gather=True, dst=root, out=out)
+        if rank == root:
+            assert y is out and bool(torch.isfinite(out).all())
+            torch.save(y.cpu(), os.path.join(out_dir, "gathered.pt"))
+        else:
+            assert y is None
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_sharded_over_rccl_on_two_or_more_devices(tmp_path):
+    """VERDICT r2 #5c: `filter_sharded` over backend "nccl" with uneven blocks -- runs whenever the box has at least
+    two devices (the builder's lease has one: skipped there, the driver's multi-GPU node runs it)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two devices")
+    import socket
+
+    import torch.multiprocessing as mp
+    from torchfx_amd import Wave
+    from torchfx_amd import filter as F
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = min(torch.cuda.device_count(), 8)
+    C = 2 * world + 1                                 # uneven blocks
+    mp.spawn(_sharded_rccl_worker, args=(world, port, C, str(tmp_path)), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(C, 150_000, generator=g).to(DEV)
+    one = (Wave(x, 48000, device=DEV) | F.LoButterworth(2000, order=6) | F.ParametricEQ(1000, 2.0, 3.0)
+           | F.FIR(np.hanning(301) / np.hanning(301).sum())).ys
+    close(torch.load(tmp_path / "gathered.pt"), one.cpu().numpy(), 2e-6, "RCCL-sharded chain vs one process")
+
+
 def test_bench_two_ranks_on_one_device(tmp_path):
     """bench.py's N > 1 control flow (barrier, max over ranks, gather, value_with_gather, strong scaling)
     with the real kernels: two ranks on cuda:0, gloo for the collectives (TFX_BENCH_SHARE_DEVICE=1)."""
@@ -1392,6 +1499,50 @@ def test_non_finite_input_poisons_the_rest_of_the_row_like_the_sequential_recurs
         for c in (0, 2):
             assert np.abs(y[c] - ref[c].astype(np.float32)).max() <= 1.5e-7 * max(1.0, np.abs(ref[c]).max())
     assert not np.isfinite(ref[1, pos:]).any() and not np.isfinite(refs[:, 1]).any()     # the oracle agrees
+
+
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_non_finite_input_with_epilogue_bank_and_taps_is_segment_independent(bad, monkeypatch):
+    """the poisoning of later segments must not depend on what an epilogue did to the stored
+    samples (clamp turns an Inf end sample into 1), must reach the statistic a following Normalize reads, and must
+    also hold for filter-bank, sum-mode and section-tap launches: every result equals the one-segment launch."""
+    from scipy.signal import butter
+    E = ext()
+    sos = torch.from_numpy(np.vstack([butter(4, 1500 / 24000, output="sos"), [[1.0089, -1.9636, 0.9695, 1, -1.9636, 0.9784]]]))
+    banks = torch.stack([sos, torch.from_numpy(np.vstack([butter(6, 3000 / 24000, output="sos")]))])
+    x = rnd((3, 300_000), 32)
+    x[1, 77_777] = bad
+    xd = dev(x)
+
+    def same(a, b, what):
+        assert np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True), what
+
+    def run():
+        out = {}
+        for stat in ("absmax", "sumsq"):
+            ep = E.Epilogue(gain=0.5, clamp=True, stat=stat, per_row=True)
+            y, _, sy = E.sos_forward(xd, None, sos, None, None, epilogue=ep)
+            out["ep_" + stat] = (y, sy, ep.stat_value.clone())
+        out["bank"] = E.sos_bank_forward(xd, banks, None, None)
+        out["sum"] = E.sos_bank_sum_forward(xd, banks, None, None)
+        out["taps"] = E.sos_forward(xd.double(), None, sos, None, None, return_sections=True)
+        return out
+    monkeypatch.setenv("TFX_SOS_NSEG", "1")
+    ref = run()
+    # the one-segment fused epilogue equals the staged passes (sequential recursion, then Gain, then the reduction)
+    ys = E.gain_forward(E.sos_forward(xd, None, sos, None, None)[0], 0.5, True)
+    same(ref["ep_absmax"][0], ys, "fused epilogue vs staged")
+    assert not np.isfinite(ref["ep_absmax"][2].cpu().numpy()[1]) and np.isfinite(ref["ep_absmax"][2].cpu().numpy()[[0, 2]]).all()
+    for nseg in ("7", "0"):
+        monkeypatch.setenv("TFX_SOS_NSEG", nseg)
+        got = run()
+        for key in ref:
+            for i, (a, b) in enumerate(zip(ref[key], got[key])):
+                a_, b_ = a.cpu().numpy(), b.cpu().numpy()
+                assert np.array_equal(np.isfinite(a_), np.isfinite(b_)), (key, i, nseg)
+                fin = np.isfinite(a_)
+                scale = max(1.0, float(np.abs(a_[fin]).max())) if fin.any() else 1.0
+                assert np.abs(a_[fin] - b_[fin]).max() <= (1e-6 if key.startswith("ep_") and i == 2 else 3e-7) * scale, (key, i, nseg)
 
 
 def test_two_devices_in_one_process_keep_their_own_caches():

@@ -873,7 +873,18 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     const int64_t pair_bytes = (int64_t)OLS_N1 * g.P2 * (int64_t)sizeof(cpx);
     int64_t slab = envi("TFX_OLS_PAIRS_PER_SLAB", 0);
     if (slab <= 0) {
-        const int64_t hi = std::max<int64_t>(1, (envi("TFX_OLS_SLAB_MB", 1024) << 20) / pair_bytes);
+        // The workspace lives outside PyTorch's caching allocator and is kept between calls (scratch(), released by
+        // tfx_clear_caches): 1 GB per internal stream by default, but never more than 1/8 of the memory that is free
+        // right now over all lanes, so a process that shares the device with large torch tensors is not pushed into OOM.
+        int64_t slab_mb = envi("TFX_OLS_SLAB_MB", 1024);
+        {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const int64_t cap_mb = (int64_t)(free_b >> 20) / (8 * nlanes);
+                if (slab_mb > cap_mb) slab_mb = std::max<int64_t>(cap_mb, 8);
+            }
+        }
+        const int64_t hi = std::max<int64_t>(1, (slab_mb << 20) / pair_bytes);
         const int64_t lo = std::max<int64_t>(1, (envi("TFX_OLS_SLAB_MIN_MB", 64) << 20) / pair_bytes);
         slab = ceil_div(npairs, 2 * nlanes);
         if (slab < lo) slab = lo;

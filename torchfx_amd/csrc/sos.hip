@@ -64,6 +64,7 @@ struct SosParams {
     double ep_gain;
     int ep_scale, ep_clamp, ep_stat;
     double *ep_partial;  // [C * nseg], one per stream (row-major over (row, segment)), pre-zeroed
+    int *nf_flag;        // [C * nseg]: stream ended with a non-finite carried state (nseg > 1 only, pre-zeroed)
     const void *ep_host; // host side only: the Epilogue this launch serves
     int ep_fused;        // host side only: the kernel applies it (else separate passes follow the launch)
 };
@@ -457,6 +458,14 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
             wave_sync();
         }
     }
+    if (p.nf_flag) {
+        // the carried state at the end of the stream (every band, every section: last two inputs and outputs);
+        // non-finite there = non-finite from some sample of this stream to the end of the row (iir_cpu.cpp:132-147),
+        // whatever an epilogue (clamp) made of the stored samples
+        int badc = 0;
+        for (int i = lane; i < nbl * K * 4; i += 64) badc |= !(fabs((double)carry[i]) <= 1.79e308);
+        if (__any(badc) && lane == 0) p.nf_flag[sid] = 1;
+    }
     if (EPI && p.ep_stat >= 0) {           // one partial per stream, lanes combined in a fixed order
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) ep_acc = red_comb_rt(p.ep_stat, ep_acc, __shfl_xor(ep_acc, off));
@@ -466,14 +475,19 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
 
 // Non-finite samples and time segmentation.  In the sequential recursion a NaN / Inf never leaves: once the
 // state is non-finite every later output of the row is (iir_cpu.cpp:132-147).  A segment that starts from its
-// warm-up halo does not see what happened before the halo, so after the main launch every segment g > 0 checks
-// whether an earlier segment of its row ENDED non-finite and, if so, overwrites itself (and, for the last
-// segment, the returned states) with NaN -- "non-finite from the first bad sample to the end of the row",
-// independent of how many segments the launch used.  Finite signals: one tiny launch that reads nseg samples
-// per workgroup and exits.
+// warm-up halo does not see what happened before the halo, so every stream leaves a flag "my carried state ended
+// non-finite" and, after the main launch, every segment g > 0 checks the flags of the earlier segments of its row
+// and, if one is set, overwrites itself with NaN -- its samples (and section taps), its statistic partial (so a
+// following Normalize sees NaN like the standalone reduction would) and, for the last segment, the returned
+// states: "non-finite from the first bad sample to the end of the row", independent of how many segments the
+// launch used and of what an epilogue (clamp) did to the stored samples.  Finite signals: one tiny launch that
+// reads nseg flags per workgroup and exits.
+//   y rows = C (output rows); state rows = st_rows with row c owning {b * C_in + c} for b < nbl in sum mode.
 template <typename TOut>
-__global__ void __launch_bounds__(256) sos_nonfinite_fix_kernel(TOut *__restrict__ y, int64_t C, int64_t T, int64_t seg_len, int64_t warm,
-                                                                int nseg, double *sx_out, double *sy_out, int K)
+__global__ void __launch_bounds__(256) sos_nonfinite_fix_kernel(TOut *__restrict__ y, TOut *__restrict__ taps, int64_t C, int64_t T,
+                                                                int64_t seg_len, int64_t warm, int nseg, const int *__restrict__ nf_flag,
+                                                                double *ep_partial, double *sx_out, double *sy_out, int K,
+                                                                int64_t st_rows, int64_t C_in, int nbl)
 {
     __shared__ int bad;
     const int64_t row = blockIdx.x / (nseg - 1);
@@ -482,20 +496,24 @@ __global__ void __launch_bounds__(256) sos_nonfinite_fix_kernel(TOut *__restrict
     if (begin >= T) return;
     if (threadIdx.x == 0) bad = 0;
     __syncthreads();
-    for (int q = threadIdx.x; q < g; q += 256) {
-        const int64_t e = (int64_t)(q + 1) * seg_len + warm - 1; // last sample segment q stores
-        const double v = (double)y[row * T + (e < T ? e : T - 1)];
-        if (!(fabs(v) <= 1.79e308)) bad = 1;             // NaN or Inf
-    }
+    for (int q = threadIdx.x; q < g; q += 256)
+        if (nf_flag[row * nseg + q]) bad = 1;
     __syncthreads();
     if (!bad) return;
     const int64_t end = (g == nseg - 1 || begin + seg_len > T) ? T : begin + seg_len;
     const TOut nanv = (TOut)__builtin_nan("");
     for (int64_t n = begin + threadIdx.x; n < end; n += 256) y[row * T + n] = nanv;
-    if (end == T && threadIdx.x < 2 * K) {
-        const int sct = threadIdx.x >> 1, f = threadIdx.x & 1;
-        if (sx_out) sx_out[((int64_t)sct * C + row) * 2 + f] = __builtin_nan("");
-        if (sy_out) sy_out[((int64_t)sct * C + row) * 2 + f] = __builtin_nan("");
+    if (taps)
+        for (int s = 0; s < K; ++s)
+            for (int64_t n = begin + threadIdx.x; n < end; n += 256) taps[((int64_t)s * C + row) * T + n] = nanv;
+    if (ep_partial && threadIdx.x == 0) ep_partial[row * nseg + g] = __builtin_nan("");
+    if (end == T) {
+        for (int i = threadIdx.x; i < nbl * K * 2; i += 256) {
+            const int b = i / (K * 2), sct = (i >> 1) % K, f = i & 1;
+            const int64_t o = ((int64_t)sct * st_rows + (nbl > 1 ? b * C_in + row : row)) * 2 + f;
+            if (sx_out && sct > 0) sx_out[o] = __builtin_nan("");   // section 0's input history is the signal itself: already exact
+            if (sy_out) sy_out[o] = __builtin_nan("");
+        }
     }
 }
 
@@ -923,14 +941,20 @@ static void launch_one(SosParams p, int64_t plan_warm, hipStream_t stream)
         p.ep_partial = (double *)scratch("sos_ep_partial", (size_t)nstreams * sizeof(double), stream);
         TFX_HIP(hipMemsetAsync(p.ep_partial, 0, (size_t)nstreams * sizeof(double), stream));
     }
+    p.nf_flag = nullptr;
+    if (p.nseg > 1) {                      // see sos_nonfinite_fix_kernel
+        p.nf_flag = (int *)scratch("sos_nf_flag", (size_t)nstreams * sizeof(int), stream);
+        TFX_HIP(hipMemsetAsync(p.nf_flag, 0, (size_t)nstreams * sizeof(int), stream));
+    }
     {
         ProfScope ps(sizeof(TC) == 8 ? "sos_stream_kernel<f64>" : "sos_stream_kernel<f32>", stream);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, stream, p);
         TFX_HIP(hipGetLastError());
     }
-    if (p.nseg > 1 && !TAPS && !SUMB && p.C == p.C_in) {       // see sos_nonfinite_fix_kernel
+    if (p.nseg > 1) {
         hipLaunchKernelGGL(sos_nonfinite_fix_kernel<TOut>, dim3((unsigned)(p.C * (p.nseg - 1))), dim3(256), 0, stream, (TOut *)p.y,
-                           p.C, p.T, p.seg_len, p.warm, p.nseg, p.sx_out, p.sy_out, p.K);
+                           (TOut *)p.taps, p.C, p.T, p.seg_len, p.warm, p.nseg, p.nf_flag, p.ep_stat >= 0 ? p.ep_partial : nullptr,
+                           p.sx_out, p.sy_out, p.K, SUMB ? p.C_in * nbl : p.C, p.C_in, nbl);
         TFX_HIP(hipGetLastError());
     }
     if (p.ep_stat >= 0) {
@@ -945,6 +969,10 @@ template <typename TIn, typename TOut, typename TC>
 static void launch_main(const SosParams &p, bool vec, int variant, int64_t nstreams, hipStream_t stream)   // nstreams = plan warm-up
 {
     constexpr bool F32 = sizeof(TC) == 4;
+    if (p.taps && vec && variant >= 4) {   // the shipping LC = 64 geometry with every section's output tapped (parity tests)
+        launch_one<TIn, TOut, TC, 64, true, true, false, F32 ? 3 : 2>(p, nstreams, stream);
+        return;
+    }
     if (p.taps || !vec) {     // debug taps / unaligned rows: plain dword path
         if (variant & 1) {
             if (p.taps) launch_one<TIn, TOut, TC, 16, false, true, false, F32 ? 5 : 3>(p, nstreams, stream);
@@ -1042,9 +1070,14 @@ void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C_in,
     {
         const int xs_ = x_dtype == TFX_F32 ? 4 : 8, ys_ = y_dtype == TFX_F32 ? 4 : 8;
         const bool vec_ = (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0) && ((T * xs_) % 16 == 0) && ((T * ys_) % 16 == 0);
-        if (variant >= 4 && (y_sections || !vec_)) variant = 2;               // LC = 64 exists for the aligned path without taps
+        if (variant >= 4 && !vec_) variant = 2;                               // LC = 64 exists for the aligned (16-byte) path only
         if (variant >= 4 && ep->any()) variant = 4;                           // (its epilogue instantiation: no register prefetch)
     }
+    // fused into the kernel on the main path (float32 I/O, aligned rows, no taps, single cascade); everything
+    // else runs the plain kernel and the same arithmetic as separate passes over y
+    const bool ep_fused = ep->any() && x_dtype == TFX_F32 && y_dtype == TFX_F32 && !sum_bands && !y_sections &&
+                          (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0) && ((T * 4) % 16 == 0);
+    if (ep_fused && variant < 4) variant = 2;      // the epilogue kernel exists for LC = 32 and LC = 64: table and kernel must agree
     const int LC = variant >= 4 ? 64 : ((variant & 1) ? 16 : 32);
     SosParams p{};
     p.x = x; p.y = y; p.taps = y_sections;
@@ -1053,10 +1086,6 @@ void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C_in,
     p.nsum = sum_bands ? (int)NB : 0;
     p.ep_gain = ep->gain; p.ep_scale = ep->scale; p.ep_clamp = ep->clamp; p.ep_stat = ep->stat_mode;
     p.ep_partial = nullptr; p.ep_host = ep;
-    // fused into the kernel on the main path (float32 I/O, aligned rows, no taps, single cascade); everything
-    // else runs the plain kernel and the same arithmetic as separate passes over y
-    const bool ep_fused = ep->any() && x_dtype == TFX_F32 && y_dtype == TFX_F32 && !sum_bands && !y_sections &&
-                          (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0) && ((T * 4) % 16 == 0);
     p.ep_fused = ep_fused ? 1 : 0;
     if (!ep_fused) { p.ep_scale = p.ep_clamp = 0; p.ep_stat = -1; }
 

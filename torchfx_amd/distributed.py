@@ -48,33 +48,67 @@ def run_sharded(pipeline: nn.Module | list, x_local: Tensor, fs: int | None = No
     return w.ys
 
 
-def gather_rows(y_local: Tensor, n_rows: int, dst: int = 0, group=None) -> Tensor | None:
+def gather_rows(y_local: Tensor, n_rows: int, dst: int = 0, group=None, out: Tensor | None = None) -> Tensor | None:
     """Single gather of the per-rank row blocks to ``dst`` -> ``[n_rows, T]`` there, None elsewhere.
-    Blocks may differ by one row; they are padded to the largest block for the collective."""
+
+    The root receives every peer's block straight into its row-block view of ONE preallocated ``[n_rows, T]``
+    output (``out``, if given, is that buffer): no ``world`` staging buffers and no ``torch.cat`` -- at cfg 5 the
+    root holds the 59 GB result once and pays no extra pass over it.  The transfers are one grouped batch of
+    point-to-point operations (``batch_isend_irecv``: on backend "nccl" = RCCL a single ncclGroup of send/recv,
+    which is what its gather is made of), so blocks need not be padded to a common size and each peer -> root
+    transfer rides that pair's own xGMI link."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     sizes = [shard_bounds(n_rows, world, r) for r in range(world)]
-    big = max(hi - lo for lo, hi in sizes)
     T = y_local.shape[1]
-    send = y_local
-    if y_local.shape[0] < big:
-        send = torch.zeros((big, T), dtype=y_local.dtype, device=y_local.device)
-        send[: y_local.shape[0]] = y_local
-    send = send.contiguous()
+    lo, hi = sizes[rank]
+    if y_local.shape[0] != hi - lo:
+        raise ValueError(f"rank {rank} holds {y_local.shape[0]} rows, its block of {n_rows} rows over {world} ranks has {hi - lo}")
+
+    def peer(r: int) -> int:
+        return r if group is None else dist.get_global_rank(group, r)
     # "nccl" (= RCCL) moves device buffers peer to root directly; a gloo group (CPU collectives: the
     # development set-up where several ranks share one GPU) stages device rows through host memory
-    staged = send.is_cuda and dist.get_backend(group) == "gloo"
-    wire = send.cpu() if staged else send
-    bufs = [torch.empty_like(wire) for _ in range(world)] if rank == dst else None
-    dist.gather(wire, bufs, dst=dst, group=group)
+    staged = y_local.is_cuda and dist.get_backend(group) == "gloo"
     if rank != dst:
+        if hi > lo:
+            wire = y_local.contiguous()
+            wire = wire.cpu() if staged else wire
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, wire, peer(dst), group)]):
+                w.wait()
         return None
-    out = torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], dim=0)
-    return out.to(y_local.device) if staged else out
+    if out is None:
+        out = torch.empty((n_rows, T), dtype=y_local.dtype, device=y_local.device)
+    elif tuple(out.shape) != (n_rows, T) or out.dtype != y_local.dtype or out.device != y_local.device or not out.is_contiguous():
+        raise ValueError(f"out must be a contiguous [{n_rows}, {T}] {y_local.dtype} tensor on {y_local.device}")
+    out[lo:hi].copy_(y_local)
+    ops, landing = [], {}
+    for r, (rlo, rhi) in enumerate(sizes):
+        if r == rank or rhi == rlo:
+            continue
+        landing[r] = torch.empty((rhi - rlo, T), dtype=y_local.dtype) if staged else out[rlo:rhi]
+        ops.append(dist.P2POp(dist.irecv, landing[r], peer(r), group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    if staged:
+        for r, buf in landing.items():
+            out[sizes[r][0]:sizes[r][1]].copy_(buf)
+    return out
 
 
 def filter_sharded(pipeline, x: Tensor, fs: int, gather: bool = True, dst: int = 0, group=None,
-                   fuse_fir: bool | None = None) -> Tensor | None:
+                   fuse_fir: bool | None = None, out: Tensor | None = None) -> Tensor | None:
     """shard -> run -> (optionally) gather.  ``x`` is the full ``[C, T]`` signal (each rank only
-    touches its own rows)."""
+    touches its own rows); ``out``: the root's preallocated ``[C, T]`` result buffer."""
     y = run_sharded(pipeline, shard_rows(x, group), fs, fuse_fir)
-    return gather_rows(y, x.shape[0], dst, group) if gather else y
+    return gather_rows(y, x.shape[0], dst, group, out) if gather else y
+
+
+def ranks_seen(group=None, device=None) -> int:
+    """How many ranks the process group really has: an all-reduce of ones on the group's own transport (RCCL for
+    "nccl"), not an environment variable."""
+    if not dist.is_initialized():
+        return 1
+    one = torch.ones(1, dtype=torch.int32, device=device if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(one, group=group)
+    return int(one.item())

@@ -110,9 +110,3 @@ def download_interleaved(x: Tensor, chunk_frames: int = 1 << 22, out: np.ndarray
         torch.cuda.current_stream(x.device).synchronize()
         res[f0:f0 + n] = pin[:n].numpy()
     return res
-    xf = x if x.dtype == torch.float32 else x.to(torch.float32)
-    chunk = max(1, min(int(chunk_frames), F))
-    for f0 in range(0, F, chunk):
-        n = min(chunk, F - f0)
-        out[f0:f0 + n] = torchfx_ext.interleave_forward(xf, f0, n).cpu().numpy()
-    return out
