@@ -68,3 +68,22 @@ def oracle_backend(monkeypatch):
                  "fir_stream_forward", "normalize_apply", "sum_forward", "delay_line_forward", "gain_forward", "stat_forward", "normalize_forward"):
         monkeypatch.setattr(torchfx_ext, name, getattr(_fake_backend, name))
     return _fake_backend
+
+
+# ---- fixtures shared by the -m gpu parity files ------------------------------------------------------------
+# 4 = LC 64 (the float64 default that ships), 2 = LC 32 + prefetch (the float32 default); 5 = LC 64 + prefetch
+@pytest.fixture(params=[0, 1, 2, 3, 4, 5], ids=["lc32", "lc16", "lc32pf", "lc16pf", "lc64", "lc64pf"])
+def sos_variant(request, monkeypatch):
+    monkeypatch.setenv("TFX_SOS_VARIANT", str(request.param))
+    return request.param
+
+
+@pytest.fixture(params=["dispatch", "mfma"])
+def fir_kernel(request, monkeypatch):
+    """The direct FIR has two float32 kernels: the exact-f32 MFMA Toeplitz kernel (throughput) and the plain LDS-tiled
+    one (short rows, launches whose tiles are all resident at once).  "dispatch" = the library's choice (mostly the plain
+    kernel at test sizes), "mfma" = the MFMA kernel wherever it can run."""
+    if request.param == "mfma":
+        monkeypatch.setenv("TFX_FIR_ONE_ROUND_TILES", "0")
+        monkeypatch.setenv("TFX_FIR_MFMA_MIN_T", "0")
+    return request.param

@@ -1,0 +1,173 @@
+"""GPU parity -- effects between filters and epilogues (8f rank 3).
+Tolerances and helpers: tests/gpu_common.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests.gpu_common import *  # noqa: F401,F403
+
+pytestmark = pytest.mark.gpu
+
+
+GAIN_CASES = {"amp": dict(gain=0.37, gain_type="amplitude"), "db": dict(gain=-4.5, gain_type="db"),
+              "db0": dict(gain=0.0, gain_type="db"), "pow": dict(gain=2.5, gain_type="power"),
+              "clamp": dict(gain=1.9, gain_type="amplitude", clamp=True)}
+
+
+def _strategies():
+    from torchfx_amd import effect as E
+    return {"peak": E.PeakNormalizationStrategy(), "rms": E.RMSNormalizationStrategy(),
+            "percentile": E.PercentileNormalizationStrategy(97.0), "per_channel": E.PerChannelNormalizationStrategy()}
+
+
+def test_gain_and_normalize_golden(golden):
+    """Gain is bit-exact (one rounding, same as torch); the normalisations are within 1e-6 of the
+    reference (the RMS is accumulated in float64 here, in float32 there)."""
+    from torchfx_amd import effect as E
+    g = golden("effects")
+    x, x64, z = dev(g["x"]), dev(g["x64"]), dev(g["zeros"])
+    for tag, kw in GAIN_CASES.items():
+        y = E.Gain(**kw)(x)
+        assert np.array_equal(y.cpu().numpy(), g["gain_" + tag]), tag
+    assert np.array_equal(E.Gain(3.0, "db")(x64).cpu().numpy(), g["gain64_db"])
+    for name, st in _strategies().items():
+        close(E.Normalize(0.8, st)(x), g["norm_" + name], 1e-6, name)
+        close(E.Normalize(1.25, st)(x64), g["norm64_" + name], 1e-14, name + " f64")
+        assert np.array_equal(E.Normalize(0.8, st)(z).cpu().numpy(), g["normz_" + name]), name
+    close(E.Normalize(0.5, E.PerChannelNormalizationStrategy())(dev(g["x3"])), g["norm3_per_channel"], 1e-6)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("C,T", [(1, 1), (3, 17), (2, 4097), (5, 100003), (2, 1 << 20)])
+def test_effect_kernels_ragged_shapes_vs_oracle(C, T, dtype):
+    e = ext()
+    x = (rnd((C, T), 31 * C + T, dtype) * 3).astype(dtype)
+    if C > 1:
+        x[1] = 0
+    xd = dev(x)
+    assert np.array_equal(e.gain_forward(xd, 0.731, True).cpu().numpy(), O.gain(x, 0.731, "amplitude", True))
+    st = e.stat_forward(xd, e.STAT_ABSMAX, per_row=True).cpu().numpy()
+    assert np.array_equal(st, np.abs(x).max(axis=1).astype(np.float64))
+    assert e.stat_forward(xd, e.STAT_ABSMAX).item() == np.abs(x).max()
+    rms = e.stat_forward(xd, e.STAT_RMS, per_row=True).cpu().numpy()
+    assert np.allclose(rms, np.sqrt((x.astype(np.float64) ** 2).mean(axis=1)), rtol=1e-13)
+    tol = 2e-7 if dtype == np.float32 else 1e-15
+    for strat, mode, per_row in (("peak", e.STAT_ABSMAX, False), ("per_channel", e.STAT_ABSMAX, True), ("rms", e.STAT_RMS, False)):
+        y = e.normalize_forward(xd, 0.9, mode, per_row).cpu().numpy()
+        exp = O.normalize(x, 0.9, strat)
+        assert np.abs(y - exp).max() <= tol * max(1.0, np.abs(exp).max()), strat
+    # rows that are not 16-byte aligned (a view shifted by one sample) take the scalar path
+    if T > 8:
+        xs = dev(x)[:, 1:]
+        assert not xs.is_contiguous()
+        y = e.normalize_forward(xs, 0.9, e.STAT_ABSMAX, True).cpu().numpy()
+        assert np.abs(y - O.normalize(x[:, 1:], 0.9, "per_channel")).max() <= tol * 3
+
+
+def test_effect_nan_and_aliasing_rules():
+    e = ext()
+    x = rnd((2, 5000), 5)
+    x[0, 1234] = np.nan
+    xd = dev(x)
+    st = e.stat_forward(xd, e.STAT_ABSMAX, per_row=True).cpu().numpy()
+    assert np.isnan(st[0]) and st[1] == np.abs(x[1]).max()             # NaN wins, like torch.max
+    y = e.normalize_forward(xd, 1.0, e.STAT_ABSMAX, False).cpu().numpy()
+    assert np.array_equal(np.isnan(y), np.isnan(x)) and np.array_equal(y[1], x[1])   # `nan > 0` is False: unchanged
+    g = e.gain_forward(xd, 2.0, True).cpu().numpy()
+    assert np.isnan(g[0, 1234]) and np.abs(g[1]).max() <= 1.0
+    assert xd.cpu().numpy()[1].tobytes() == x[1].tobytes()              # inputs never written
+
+
+def test_reverb_on_device(golden):
+    from torchfx_amd import effect as E
+    g = golden("delay")
+    rv = E.Reverb(delay=100, decay=0.5, mix=0.3)
+    close(rv(dev(g["x"])), g["y"], 1e-7, "reverb")
+    close(rv(dev(g["x"]).reshape(1, 2, -1))[0], g["y"], 1e-7, "reverb 3-D")
+    close(rv(dev(g["x"][0])), g["y"][0], 1e-7, "reverb 1-D")
+    s = dev(np.zeros((2, 50), np.float32))
+    assert rv(s) is s
+
+
+def _tails():
+    import torchfx_amd as fx
+    E = fx.effect
+    return {
+        "gain+clamp": lambda: [fx.Gain(1.7, clamp=True)],
+        "gain db": lambda: [fx.Gain(-3.0, "db")],
+        "peak": lambda: [fx.Normalize(0.8)],
+        "gain+peak": lambda: [fx.Gain(0.3), fx.Normalize(0.8)],
+        "rms": lambda: [fx.Normalize(0.5, E.RMSNormalizationStrategy())],
+        "clamp+per_channel": lambda: [fx.Gain(2.0, clamp=True), fx.Normalize(0.7, E.PerChannelNormalizationStrategy())],
+    }
+
+
+@pytest.mark.parametrize("producer", ["cascade f32", "cascade f64 io", "lone iir", "fir fft short rows", "fir fft long rows", "cascade unaligned"])
+@pytest.mark.parametrize("tail", ["gain+clamp", "gain db", "peak", "gain+peak", "rms", "clamp+per_channel"])
+def test_epilogue_equals_staged_passes(producer, tail):
+    """filter | Gain | Normalize as ONE kernel with an epilogue (+ one apply pass for Normalize) against the same
+    modules staged as separate HIP passes: bit-identical for gain / clamp, 1e-6 for the normalisations (the
+    statistic is reduced in another order).  Covers the fused epilogues (float32 cascade kernel, last pass of the
+    LDS-resident overlap-save) and the producers that run the epilogue as passes inside the call (float64 I/O,
+    unaligned rows, rocFFT path)."""
+    import torchfx_amd as fx
+    from torchfx_amd import filter as F
+    T = {"fir fft long rows": 200_000, "cascade unaligned": 30_001}.get(producer, 30_000)
+    dt = np.float64 if producer == "cascade f64 io" else np.float32
+    x = dev(rnd((3, T), 21, dt) * 0.9)
+
+    def filt():
+        if producer.startswith("cascade"):
+            return [F.LoButterworth(3000, order=4), F.HiShelving(2000, q=0.7, gain=2.0)]
+        if producer == "lone iir":
+            return [F.ParametricEQ(frequency=800, q=3.0, gain=6.0)]
+        return [F.FIR(np.hanning(129) / np.hanning(129).sum() * 1.5)]
+    outs = []
+    for ep in (False, True):
+        w = fx.Wave(x, 48000, device=DEV)
+        w.fuse_epilogue, w.fuse_fir, w.fuse_spectral = ep, False, False
+        for m in filt() + _tails()[tail]():
+            w = w | m
+        if ep:
+            assert [type(m).__name__ for m in w.plan()] == ["Epilogued"]
+        outs.append(w.ys)
+    staged, fused = outs
+    assert fused.dtype == staged.dtype and fused.shape == staged.shape
+    if "peak" in tail or "rms" in tail or "per_channel" in tail:
+        close(fused, staged.cpu().numpy(), 1e-6 if dt == np.float32 else 1e-13, f"{producer} | {tail}")
+    else:
+        assert torch.equal(fused, staged), f"{producer} | {tail}"
+
+
+def test_epilogue_statistics_and_golden_mix(golden):
+    """The raw statistic an epilogue leaves on the device == the statistic of the stored output; and the reference's
+    mixed pipeline (tests/golden/effects.npz, iir | iir | Gain | iir | iir) under the default plan."""
+    import torchfx_amd as fx
+    from torchfx_amd import filter as F
+    e = ext()
+    x = dev(rnd((4, 150_000), 22) * 0.9)
+    from scipy.signal import butter
+    sos = torch.from_numpy(butter(4, 3000 / 24000, output="sos"))
+    for stat, per_row in (("absmax", False), ("absmax", True), ("sumsq", False), ("sumsq", True)):
+        ep = e.Epilogue(gain=1.3, clamp=True, stat=stat, per_row=per_row)
+        y, _, _ = e.sos_forward(x, None, sos, None, None, epilogue=ep)
+        yd = y.double()
+        rows = yd if per_row else yd.reshape(1, -1)
+        ref = rows.abs().max(dim=1).values if stat == "absmax" else (rows * rows).sum(dim=1)
+        assert torch.allclose(ep.stat_value, ref, rtol=1e-12, atol=0), (stat, per_row)
+        assert float(y.abs().max()) <= 1.0
+        k = torch.from_numpy((np.hanning(301) / np.hanning(301).sum()).astype(np.float32))
+        ep2 = e.Epilogue(gain=0.5, stat=stat, per_row=per_row)
+        y2 = e.fft_conv_forward(x, k, (300, 0), epilogue=ep2)                  # LDS-resident path: fused into the last pass
+        assert torch.equal(y2, e.gain_forward(e.fft_conv_forward(x, k, (300, 0)), 0.5))
+        rows = y2.double() if per_row else y2.double().reshape(1, -1)
+        ref = rows.abs().max(dim=1).values if stat == "absmax" else (rows * rows).sum(dim=1)
+        assert torch.allclose(ep2.stat_value, ref, rtol=1e-12, atol=0), ("fft", stat, per_row)
+    g = golden("effects")
+    w = fx.Wave(g["mix_x"], 48000, device=DEV)
+    for m in (F.LoButterworth(4000, order=2), F.HiButterworth(200, order=2), fx.Gain(0.5), F.LoButterworth(6000, order=2),
+              F.HiButterworth(100, order=2)):
+        w = w | m
+    assert [type(m).__name__ for m in w.plan()] == ["Epilogued", "FusedSOSCascade"]
+    close(w.ys, g["mix_y"], TOL_IIR_F32OUT * 2, "reference mixed pipeline, gain as an epilogue")

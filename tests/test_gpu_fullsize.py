@@ -1,6 +1,6 @@
 """BASELINE.json's full sizes on the GPU, checked through size-independent properties plus the
 oracle on a channel subset (SURVEY.md 8d "parity at scale").  Tolerances as in
-test_gpu_parity.py."""
+gpu_common.py."""
 import numpy as np
 import pytest
 import torch

@@ -1,0 +1,226 @@
+"""GPU parity -- several host threads, ranks and devices (row e); the plain-C host.
+Tolerances and helpers: tests/gpu_common.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests.gpu_common import *  # noqa: F401,F403
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_host_threads_on_two_streams():
+    """ctypes releases the GIL, so two Python threads can be inside the library at once: enqueueing
+    is serialised by the API lock and every stream has its own workspaces, so concurrent pipelines on
+    different streams do not disturb each other."""
+    import threading
+    from scipy.signal import butter
+    e = ext()
+    sos = torch.from_numpy(butter(4, 0.1, output="sos"))
+    K = 4097
+    kf = (np.random.default_rng(1).standard_normal(K) / 64).astype(np.float32)
+    xs = [dev(rnd((6, 300_000), 100 + i)) for i in range(2)]
+
+    def run(x):
+        y, _, _ = e.sos_forward(x, None, sos, None, None)
+        y = e.fft_conv_forward(y, kf, (K - 1, 0))
+        return e.normalize_forward(y, 0.5, e.STAT_RMS, False)
+
+    refs = [run(x) for x in xs]
+    torch.cuda.synchronize()
+    outs, errs = [None, None], []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(10):
+                    outs[i] = run(xs[i])
+            st.synchronize()
+        except Exception as ex:  # pragma: no cover
+            errs.append(ex)
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        assert torch.equal(outs[i], refs[i]), i
+
+
+def _sharded_hip_worker(rank, world, port, C, out_dir):
+    """One of two ranks SHARING cuda:0 (the builder's lease is one GPU): real HIP kernels on this rank's
+    rows, one gather over gloo (host-staged; on a multi-GPU node the same call is an RCCL gather)."""
+    import os
+    import sys
+
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torchfx_amd import distributed as D
+        from torchfx_amd import filter as F
+        torch.cuda.set_device(0)
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(C, 150_000, generator=g).to("cuda:0")
+        pipe = [F.LoButterworth(2000, order=6), F.ParametricEQ(1000, 2.0, 3.0), F.FIR(np.hanning(301) / np.hanning(301).sum())]
+        y = D.filter_sharded(pipe, x, 48000, gather=True)
+        lo, hi = D.shard_bounds(C, world, rank)
+        if rank == 0:
+            assert y.is_cuda and y.shape == x.shape
+            torch.save(y.cpu(), os.path.join(out_dir, "gathered.pt"))
+        else:
+            assert y is None
+        yl = D.filter_sharded([F.HiButterworth(300, order=4)], x, 48000, gather=False)      # stateful lone IIR, rows stay local
+        assert yl.is_cuda and yl.shape[0] == hi - lo
+        torch.save(yl.cpu(), os.path.join(out_dir, f"local{rank}.pt"))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_ranks_share_one_device_hip_kernels_sharded_and_gathered(tmp_path):
+    import socket
+
+    import torch.multiprocessing as mp
+    from torchfx_amd import Wave
+    from torchfx_amd import filter as F
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    C, world = 5, 2                                   # uneven blocks: 3 + 2 rows
+    mp.spawn(_sharded_hip_worker, args=(world, port, C, str(tmp_path)), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(C, 150_000, generator=g).to(DEV)
+    one = (Wave(x, 48000, device=DEV) | F.LoButterworth(2000, order=6) | F.ParametricEQ(1000, 2.0, 3.0)
+           | F.FIR(np.hanning(301) / np.hanning(301).sum())).ys
+    y = torch.load(tmp_path / "gathered.pt")
+    # the overlap-save pass packs two real frames (of neighbouring rows) into one complex transform, so a
+    # row's float32 rounding noise depends on which row it is paired with: equal to one process within
+    # the FFT tolerance, not bit for bit (the recursive kernel below is row-independent: bit-identical)
+    close(y, one.cpu().numpy(), 2e-6, "sharded chain vs one process")
+    loc = torch.cat([torch.load(tmp_path / f"local{r}.pt") for r in range(world)])
+    assert torch.equal(loc, F.HiButterworth(300, order=4, fs=48000)(x).cpu())
+
+
+def _sharded_rccl_worker(rank, world, port, C, out_dir):
+    """One rank per GPU over backend "nccl" (= RCCL): uneven row blocks, the gather lands in row views of one
+    preallocated output on the root, ranks_seen counts the ranks on the collective itself."""
+    import os
+    import sys
+
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    devr = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=devr)
+    try:
+        from torchfx_amd import distributed as D
+        from torchfx_amd import filter as F
+        assert D.ranks_seen(device=devr) == world
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(C, 150_000, generator=g).to(devr)
+        pipe = [F.LoButterworth(2000, order=6), F.ParametricEQ(1000, 2.0, 3.0), F.FIR(np.hanning(301) / np.hanning(301).sum())]
+        root = world - 1                                     # not rank 0: the root index is honoured
+        out = torch.full((C, 150_000), float("nan"), device=devr) if rank == root else None
+        y = D.filter_sharded(pipe, x, 48000, gather=True, dst=root, out=out)
+        if rank == root:
+            assert y is out and bool(torch.isfinite(out).all())
+            torch.save(y.cpu(), os.path.join(out_dir, "gathered.pt"))
+        else:
+            assert y is None
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_sharded_over_rccl_on_two_or_more_devices(tmp_path):
+    """VERDICT r2 #5c: `filter_sharded` over backend "nccl" with uneven blocks -- runs whenever the box has at least
+    two devices (the builder's lease has one: skipped there, the driver's multi-GPU node runs it)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two devices")
+    import socket
+
+    import torch.multiprocessing as mp
+    from torchfx_amd import Wave
+    from torchfx_amd import filter as F
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = min(torch.cuda.device_count(), 8)
+    C = 2 * world + 1                                 # uneven blocks
+    mp.spawn(_sharded_rccl_worker, args=(world, port, C, str(tmp_path)), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(C, 150_000, generator=g).to(DEV)
+    one = (Wave(x, 48000, device=DEV) | F.LoButterworth(2000, order=6) | F.ParametricEQ(1000, 2.0, 3.0)
+           | F.FIR(np.hanning(301) / np.hanning(301).sum())).ys
+    close(torch.load(tmp_path / "gathered.pt"), one.cpu().numpy(), 2e-6, "RCCL-sharded chain vs one process")
+
+
+def test_bench_two_ranks_on_one_device(tmp_path):
+    """bench.py's N > 1 control flow (barrier, max over ranks, gather, value_with_gather, strong scaling)
+    with the real kernels: two ranks on cuda:0, gloo for the collectives (TFX_BENCH_SHARE_DEVICE=1)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TFX_BENCH_SHARE_DEVICE="1")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = str(sock.getsockname()[1])
+    sock.close()
+    for extra, scaling, chans in ((["--channels", "4"], "weak", 4), (["--scaling", "strong", "--total-channels", "6"], "strong", 3)):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                            "127.0.0.1", "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+                            "--warmup", "1", "--seconds", "30", "--gather"] + extra,
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["config"]["channels_per_gpu"] == chans
+        assert line["value"] > 0 and 0 < line["value_with_gather"] < line["value"] and line["gather_ms"] > 0
+        assert "cpu_baseline" not in line and "stages" not in line          # rank 0 at N = 1 only
+
+
+def test_two_devices_in_one_process_keep_their_own_caches():
+    """Every device-side cache is keyed by the device ordinal (plans, taps, spectra, scratch, internal streams):
+    the same filters driven alternately on cuda:0 and cuda:1 from ONE process give the single-device results.
+    Needs two visible devices; on the one-GPU builder box it is skipped (the driver's multi-GPU node runs it)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two devices")
+    from scipy.signal import butter
+    sos = torch.from_numpy(butter(6, 2000 / 24000, output="sos"))
+    k = torch.from_numpy((np.hanning(513) / np.hanning(513).sum()).astype(np.float32))
+    x = torch.from_numpy(rnd((4, 200_000), 41))
+    ref = None
+    for rep in range(2):
+        for d in ("cuda:0", "cuda:1", "cuda:0"):
+            xd = x.to(d)
+            y = ext().fft_conv_forward(ext().sos_forward(xd, None, sos, None, None)[0], k, (512, 0))
+            yd = ext().fir_direct_forward(xd, k)
+            out = torch.cat([y, yd]).cpu()
+            if ref is None:
+                ref = out
+            assert torch.equal(out, ref), (rep, d)
+
+
+def test_plain_c_host_filters_on_the_device(tmp_path):
+    """examples/c_host.c --gpu: hipMalloc + tfx_sos_forward from C99, no torch in the process."""
+    import subprocess
+    from scipy.signal import sosfilt
+    from tests.test_capi_exports import _build_c_host
+    exe = _build_c_host(tmp_path, with_hip=True)
+    out = subprocess.run([exe, "--gpu"], check=True, capture_output=True, text=True).stdout
+    head = [float(v) for v in out.split("impulse response head:")[1].split()[:4]]
+    sos = np.array([[0.0495329964, 0.0990659928, 0.0495329964, 1.0, -1.2796324250, 0.4777644106],
+                    [1.0089, -1.9636, 0.9695, 1.0, -1.9636, 0.9784]])
+    imp = np.zeros(8); imp[0] = 1.0
+    np.testing.assert_allclose(head, sosfilt(sos, imp)[:4], rtol=0, atol=2e-6)

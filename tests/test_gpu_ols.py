@@ -1,0 +1,122 @@
+"""GPU parity -- overlap-save FFT convolution (row a14): rocFFT path and the hand-written LDS-FFT passes.
+Tolerances and helpers: tests/gpu_common.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests.gpu_common import *  # noqa: F401,F403
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fftconv_golden(golden):
+    g = golden("fftconv")
+    x = dev(g["x"])
+    for K in (64, 4097):
+        close(ext().fft_conv_forward(x, g[f"k{K}"], (K - 1, 0)), g[f"y{K}"], TOL_CONV_F32, f"K={K}")
+    close(ext().fft_conv_forward(x, g["k16"], (8, 7)), g["y16_pad87"], TOL_CONV_F32, "pad (8,7)")
+
+
+def test_fftconv_65536_golden(golden, monkeypatch):
+    g = golden("fftconv")
+    kf = reverb_ir()[::-1].copy()
+    for lg in ("0", "17", "19"):
+        monkeypatch.setenv("TFX_FFT_LOG2N", lg)
+        y = ext().fft_conv_forward(dev(g["x_long"]), kf, (65535, 0))
+        close(y, g["y_long"], TOL_CONV_F32, f"log2N={lg}")
+
+
+def test_fftconv_slabbing(monkeypatch):
+    """Channel slabs (bounded workspace) give the same result as one slab."""
+    x = dev(rnd((6, 70000), 1))
+    k = rnd((300,), 2)
+    monkeypatch.setenv("TFX_FFT_WS_MB", "4096")
+    y1 = ext().fft_conv_forward(x, k, (299, 0))
+    monkeypatch.setenv("TFX_FFT_WS_MB", "1")
+    y2 = ext().fft_conv_forward(x, k, (299, 0))
+    assert torch.equal(y1, y2)
+
+
+@pytest.mark.parametrize("C,T,K", [(1, 70000, 4096), (3, 200001, 9000), (2, 300000, 16384),
+                                   (1, 262144, 65536), (3, 600000, 65536), (2, 700003, 66559),
+                                   (5, 400000, 40000), (2, 2500000, 65536), (3, 1100000, 5000),
+                                   (2, 200000, 1024), (1, 70000, 16), (3, 150016, 100)])
+def test_native_ols_vs_rocfft_and_f64(C, T, K, monkeypatch):
+    """The hand-written four-step pipeline (two frames per complex FFT) against the rocFFT path
+    and against a float64 FFT convolution; odd frame counts leave an unpaired frame."""
+    from scipy.signal import fftconvolve
+    rng = np.random.default_rng(K + T)
+    k = (rng.standard_normal(K) * np.exp(-np.arange(K) / (K / 6))).astype(np.float32)
+    k /= np.abs(k).sum()
+    x = rnd((C, T), T)
+    xd = dev(x)
+    monkeypatch.setenv("TFX_OLS_NATIVE", "1")
+    yn = ext().fft_conv_forward(xd, k[::-1].copy(), (K - 1, 0))
+    monkeypatch.setenv("TFX_OLS_NATIVE", "0")
+    yr = ext().fft_conv_forward(xd, k[::-1].copy(), (K - 1, 0))
+    exp = np.stack([fftconvolve(x[c].astype(np.float64), k.astype(np.float64))[:T] for c in range(C)])
+    close(yn, exp.astype(np.float32), 4e-6, "native vs f64")
+    close(yr, exp.astype(np.float32), 4e-6, "rocfft vs f64")
+    # and the native path is really the one that ran: different rounding than rocFFT
+    monkeypatch.setenv("TFX_OLS_PAIRS_PER_SLAB", "3")
+    monkeypatch.setenv("TFX_OLS_NATIVE", "1")
+    yn2 = ext().fft_conv_forward(xd, k[::-1].copy(), (K - 1, 0))
+    assert torch.equal(yn, yn2)          # slab size does not change results
+    # every block size the native path implements (256 x {256, 1024, 4096})
+    for lg in (16, 18, 20):
+        if (1 << lg) >= 2 * K and T + K - 1 >= (1 << lg):
+            monkeypatch.setenv("TFX_FFT_LOG2N", str(lg))
+            yl = ext().fft_conv_forward(xd, k[::-1].copy(), (K - 1, 0))
+            close(yl, exp.astype(np.float32), 4e-6, f"native log2N={lg} vs f64")
+    monkeypatch.setenv("TFX_OLS_ROW_R4", "1")          # the radix-4 row pass stays as a cross-check
+    monkeypatch.setenv("TFX_FFT_LOG2N", "18")
+    if (1 << 18) >= 2 * K and T + K - 1 >= (1 << 18):
+        close(ext().fft_conv_forward(xd, k[::-1].copy(), (K - 1, 0)), exp.astype(np.float32), 4e-6, "radix-4 rows")
+
+
+def test_native_ols_padding_variants(monkeypatch):
+    monkeypatch.setenv("TFX_OLS_NATIVE", "1")
+    K = 5000
+    k = rnd((K,), 1)
+    x = rnd((2, 150000), 2)
+    for pad in ((0, 0), (K - 1, 0), (100, 77), (0, K)):
+        y = ext().fft_conv_forward(dev(x), k, pad)
+        e = O.fft_conv1d(x.astype(np.float64), k.astype(np.float64), pad)
+        close(y, e.astype(np.float32), 2e-5, f"pad={pad}")
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fft_conv_random_geometry_vs_float64(seed):
+    """Random (C, T, K, left/right padding) through every overlap-save geometry decision (native vs
+    rocFFT path, block size, aligned / unaligned frames, ragged last block) against a float64
+    correlation computed with SciPy."""
+    from scipy.signal import fftconvolve
+    rng = np.random.default_rng(7000 + seed)
+    C = int(rng.integers(1, 5))
+    K = int(rng.choice([1, 2, 15, 16, 17, 100, 1000, 4097, 20000, 70000]))
+    T = int(rng.integers(max(1, K // 3), 400_000))
+    pl = int(rng.choice([0, K - 1, int(rng.integers(0, K + 40))]))
+    pr = int(rng.choice([0, 0, int(rng.integers(0, 50))]))
+    if T + pl + pr < K:
+        pl = K - T
+    x = rnd((C, T), seed)
+    kf = (rng.standard_normal(K) / np.sqrt(K)).astype(np.float32)
+    y = ext().fft_conv_forward(dev(x), kf, (pl, pr))
+    xp = np.pad(x.astype(np.float64), ((0, 0), (pl, pr)))
+    exp = fftconvolve(xp, kf[::-1].astype(np.float64)[None], mode="valid", axes=-1)
+    assert y.shape == exp.shape == (C, T + pl + pr - K + 1)
+    close(y, exp.astype(np.float32), TOL_CONV_F32, f"C={C} T={T} K={K} pad=({pl},{pr})")
+
+
+def test_fft_conv_kernel_longer_than_the_native_limit():
+    """600 001 taps is beyond the hand-written path (K <= 2^19): the rocFFT path takes over."""
+    from scipy.signal import fftconvolve
+    K, T = 600_001, 1_500_000
+    assert not ext().ols_plan_info(K, T, (K - 1, 0))["native"]
+    rng = np.random.default_rng(8)
+    kf = (rng.standard_normal(K) * np.exp(-np.arange(K) / 90000.0) / 300).astype(np.float32)
+    x = rnd((2, T), 4)
+    y = ext().fft_conv_forward(dev(x), kf, (K - 1, 0))
+    exp = fftconvolve(np.pad(x.astype(np.float64), ((0, 0), (K - 1, 0))), kf[::-1].astype(np.float64)[None], mode="valid", axes=-1)
+    close(y, exp.astype(np.float32), TOL_CONV_F32, "600k taps")

@@ -4,7 +4,7 @@ cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
 {
 for v in "TFX_OLS_ROW_XCH=2" "TFX_OLS_ROW_XCH=1,TFX_OLS_ROW_PERSIST=4" "TFX_OLS_ROW_XCH=2,TFX_OLS_ROW_PERSIST=4"; do
-  echo "== parity $v"; env $(echo $v | tr ',' ' ') timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "65536 or fftconv" 2>&1 | tail -2; done
+  echo "== parity $v"; env $(echo $v | tr ',' ' ') timeout 600 python -m pytest tests/test_gpu_ols.py -m gpu -x -q -k "65536 or fftconv" 2>&1 | tail -2; done
 timeout 900 python tools/ols_knobs.py "TFX_OLS_ROW_XCH=0" "TFX_OLS_ROW_XCH=1" "TFX_OLS_ROW_XCH=2" \
    "TFX_OLS_ROW_XCH=1,TFX_OLS_ROW_PERSIST=4" "TFX_OLS_ROW_XCH=1,TFX_OLS_ROW_PERSIST=8" "TFX_OLS_ROW_XCH=1,TFX_OLS_ROW_PERSIST=2" \
    "TFX_OLS_ROW_XCH=1,TFX_OLS_ROW_PERSIST=16" "TFX_OLS_ROW_XCH=2,TFX_OLS_ROW_PERSIST=4" "TFX_OLS_ROW_XCH=0,TFX_OLS_ROW_PERSIST=4" "TFX_OLS_ROW_XCH=1" 2>&1 | tail -12
