@@ -219,6 +219,29 @@ int tfx_fir_stream_forward(const void *x, void *y, int dtype, int64_t C, int64_t
                            const void *kernel_host, int64_t K, int direct,
                            const void *hist_in, void *hist_out, tfx_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * tfx_chunk_forward -- ONE launch for one small streaming chunk: SOS cascade -> stateful direct FIR -> gain / clip.
+ * Replaces, for the reference's small-block caller (RealtimeProcessor._audio_callback,
+ * src/torchfx/realtime/processor.py:253-292, and StreamProcessor's chunk loop, realtime/stream.py:234-273), the
+ * per-effect launches of   IIR ... | FIR | Gain   on a [C, T] float32 block:
+ *   u = cascade(x) with carried DF1 state (layout and rounding of tfx_sos_forward, float32 output),
+ *   y[c,n] = clip(gain * sum_{j<Kf} taps[j] * [hist_in[c] | u[c]][n+j]),  hist_out[c] = last Kf-1 samples of [hist_in[c] | u[c]].
+ * Same arithmetic as tfx_sos_forward -> tfx_fir_stream_forward(direct) -> tfx_gain_forward (the cascade walks 16-sample lane
+ * chunks instead of 64: results agree to float64 round-off of the recursion, i.e. to the last float32 bit in all but rare samples).
+ *   K = 0: no cascade (u = x);  Kf = 1 with taps {1}: no FIR;  scale / clamp = 0: no gain stage.
+ *   Limits (tfx_chunk_supported): T <= 4096, K <= 64, Kf <= 4096, T * Kf <= 2^22 -- a latency path, not a throughput one.
+ *   x_pitch: elements between consecutive rows of x (a chunk is usually a column window of a longer [C, T_total] buffer:
+ *   no contiguous copy needed); 0 = T.  y is contiguous [C, T].
+ *   state pointers: DEVICE float64 [K, C, 2] (in: NULL = zeros);  hist: DEVICE float32 [C, Kf-1], in and out distinct;
+ *   sos_host [K, 6] HOST float64;  taps_host HOST float32 (flipped, like the module's kernel buffer).
+ * ------------------------------------------------------------------------- */
+int tfx_chunk_supported(int64_t C, int64_t T, int64_t K, int64_t Kf);
+int tfx_chunk_forward(const float *x, int64_t x_pitch, float *y, int64_t C, int64_t T,
+                      const double *sos_host, int64_t K,
+                      const double *state_x_in, const double *state_y_in, double *state_x_out, double *state_y_out,
+                      const float *taps_host, int64_t Kf, const float *hist_in, float *hist_out,
+                      double gain, int scale, int clamp, int precision, tfx_stream_t stream);
+
 /* Block geometry the overlap-save op would use for a [*, T] signal and a K-tap kernel with
  * padding (l, r): *N = FFT block length, *S = hop (valid outputs per block), *F = blocks per row,
  * *native = 1 when the hand-written LDS-FFT path runs (0 = rocFFT path).  For bench/DESIGN

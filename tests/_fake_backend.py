@@ -110,6 +110,31 @@ def fir_stream_forward(x, kernel, hist, direct=False):
     return torch.from_numpy(np.ascontiguousarray(y)), torch.from_numpy(np.ascontiguousarray(xv[:, xv.shape[1] - (k.size - 1):]))
 
 
+def chunk_supported(C, T, K, taps):
+    return C >= 1 and 1 <= T <= 4096 and 0 <= K <= 64 and 1 <= taps <= 4096 and T * taps <= (1 << 22)
+
+
+def chunk_forward(x, sos, state_x, state_y, kernel, hist, gain=None, clamp=False, *, precision=None):
+    """The fused per-chunk launch, staged on the oracle: cascade -> stateful direct FIR -> gain / clip."""
+    calls.append(("chunk_forward", tuple(x.shape), int(np.asarray(_np(sos)).shape[0]), int(kernel.numel())))
+    K = int(_np(sos).shape[0])
+    if K:
+        u, nsx, nsy = sos_forward(x, None, sos, state_x, state_y)[:3]
+    else:
+        u, nsx, nsy = x, torch.zeros(0, x.shape[0], 2, dtype=torch.float64), torch.zeros(0, x.shape[0], 2, dtype=torch.float64)
+    calls.pop() if K else None
+    if kernel.numel() > 1:
+        y, nh = fir_stream_forward(u, kernel, hist, True)
+        calls.pop()
+    else:
+        y, nh = u * float(_np(kernel).reshape(-1)[0]), torch.zeros(x.shape[0], 0)
+    if gain is not None:
+        y = y * np.float32(gain)
+    if clamp:
+        y = y.clamp(-1.0, 1.0)
+    return y, nsx, nsy, nh
+
+
 def sum_forward(tensors):
     calls.append(("sum_forward", len(tensors)))
     out = torch.zeros_like(tensors[0])

@@ -134,8 +134,8 @@ def test_realtime_processor_callback_on_device(use_graph):
         outs = [be.fire(xt[:, i:i + B]) for i in range(0, B * 12, B)]
         p.set_parameter("2.gain", 2.0)                        # lands at the next buffer boundary
         outs += [be.fire(xt[:, i:i + B]) for i in range(B * 12, x.shape[-1], B)]
-        if use_graph:
-            assert p._runner._graph is not None
+        if use_graph:                                             # a chain that is ONE fused launch has no use for a graph
+            assert p._runner._graph is not None or p._runner._fused(torch.zeros(xt.shape[0], B, device=DEV))
     y = torch.cat(outs, dim=-1).numpy()
     sos = lpf._sos.cpu().numpy()
     e, _, _ = O.iir_module_forward(x, sos)                    # float32 in, float32 out
@@ -183,3 +183,91 @@ def test_stream_processor_process_file(tmp_path, monkeypatch):
     chunks = list(StreamProcessor(effects(), chunk_size=8192, device=DEV).process_file_chunks(src))
     assert [c.shape[1] for c in chunks] == [8192] * 6 + [50_000 - 6 * 8192] and not chunks[0].is_cuda
     assert np.abs(torch.cat(chunks, dim=1).numpy() - ref).max() <= 2e-6
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("C,T,K,taps,gain,clamp", [
+    (2, 512, 4, 301, 1.7, True), (1, 1, 1, 1, None, False), (3, 4096, 2, 256, 0.5, False), (2, 511, 3, 64, None, True),
+    (5, 1000, 0, 129, 2.0, False), (2, 128, 6, 1, 0.25, True), (64, 4096, 4, 255, None, False), (2, 2048, 8, 512, -1.5, True), (2, 4096, 4, 1024, 1.0, False), (3, 1000, 2, 4096, None, False)])
+def test_chunk_forward_equals_the_staged_ops(C, T, K, taps, gain, clamp, prec):
+    """tfx_chunk_forward (one launch: cascade -> stateful direct FIR -> gain / clip) against the three staged ops on
+    three consecutive chunks with carried state and history (same cascade code with shorter lane chunks, same float32
+    FMA order as the plain direct kernel: equal to float64 round-off of the recursion), and against the oracle on the
+    whole signal."""
+    from scipy.signal import butter
+    E = ext()
+    g = np.random.default_rng(C * 1000 + T)
+    sos = np.vstack([butter(2, (0.05 + 0.1 * i), output="sos") for i in range(K)]) if K else np.zeros((0, 6))
+    kf = (g.standard_normal(taps) / max(1, taps) ** 0.5).astype(np.float32)
+    x = rnd((C, 3 * T), C + T)
+    xd = dev(x)
+    sx = sy = hist = None
+    ssx = ssy = shist = None
+    outs = []
+    for i in range(3):
+        xv = xd[:, i * T:(i + 1) * T]                   # a column window of the longer buffer: taken by row pitch, no copy
+        xc = xv.contiguous()
+        y, sx, sy, hist = E.chunk_forward(xv if i else xc, torch.from_numpy(sos), sx, sy, torch.from_numpy(kf), hist, gain, clamp, precision=prec)
+        u = xc
+        if K:
+            u, ssx, ssy = E.sos_forward(xc, None, torch.from_numpy(sos), ssx, ssy, precision=prec)
+        if taps > 1:
+            u, shist = E.fir_stream_forward(u, torch.from_numpy(kf), shist, True)
+        else:
+            u = u * float(kf[0])
+        if gain is not None or clamp:
+            u = E.gain_forward(u, 1.0 if gain is None else gain, clamp)
+        # the staged cascade walks 64-sample lane chunks (LC 64 / 32), the chunk kernel 16-sample ones: the float64
+        # recursions agree to round-off, so the float32 samples are equal except where 1e-16 crosses a rounding boundary
+        ytol = 1.5e-7 if prec == "f64" else 2e-5         # float32 recursions with different lane chunks differ like any two float32 orders
+        close(y, u.cpu().numpy(), ytol, f"chunk {i}: fused vs staged")
+        if K:
+            close(sx, ssx.cpu().numpy(), 1e-12 if prec == "f64" else 2e-5)
+            close(sy, ssy.cpu().numpy(), 1e-12 if prec == "f64" else 2e-5)
+        if taps > 1:
+            close(hist, shist.cpu().numpy(), ytol)
+        outs.append(y)
+    if prec == "f64":
+        ref = O.sos_forward(x, sos)[0].astype(np.float32) if K else x
+        ref = O.fir_direct(ref, kf)
+        if gain is not None:
+            ref = ref * np.float32(gain)
+        if clamp:
+            ref = np.clip(ref, -1.0, 1.0)
+        close(torch.cat(outs, dim=1), ref, 1e-5, "fused chunks vs oracle")
+
+
+def test_stream_processor_takes_the_fused_chunk_path_on_device(monkeypatch):
+    """LoButterworth-4 | ParametricEQ | StatefulFIR-301 | Gain(clamp) in 512-sample chunks: one chunk_iir_fir_kernel launch
+    per chunk (counted by the library's profiler), equal to the one-shot oracle; TORCHFX_AMD_FUSE_CHUNK=0 gives the staged
+    launches and the same samples to a float32 ulp."""
+    import json
+    from torchfx_amd import _lib
+    from torchfx_amd import filter as F
+    from torchfx_amd.effect import Gain
+    from torchfx_amd.realtime import StatefulFIR, StreamProcessor
+    lib = _lib.load()
+    fs = 48000
+    b = (np.hanning(301) / np.hanning(301).sum())
+    x = rnd((2, 512 * 20), 5)
+
+    def chain():
+        return [F.LoButterworth(3000, order=4, fs=fs), F.ParametricEQ(frequency=800, q=2.0, gain=4.0, fs=fs),
+                StatefulFIR(b, conv_mode="fft"), Gain(1.9, clamp=True)]
+    sp = StreamProcessor(chain(), chunk_size=512, device=DEV)
+    lib.tfx_prof_enable(1)
+    lib.tfx_prof_collect()
+    y = sp.process_tensor(torch.from_numpy(x), fs)
+    torch.cuda.synchronize()
+    prof = json.loads(lib.tfx_prof_collect().decode())
+    lib.tfx_prof_enable(0)
+    assert set(prof) == {"chunk_iir_fir_kernel"} and prof["chunk_iir_fir_kernel"]["calls"] == 20, prof
+    mods = chain()
+    for m in mods[:2]:
+        m.compute_coefficients()
+    sos = np.vstack([m._sos.numpy() for m in mods[:2]])
+    ref = np.clip(O.fir_direct(O.sos_forward(x, sos)[0].astype(np.float32), b[::-1].astype(np.float32).copy()) * np.float32(1.9), -1, 1)
+    close(y, ref, 1e-5, "fused chunks vs one-shot oracle")
+    monkeypatch.setenv("TORCHFX_AMD_FUSE_CHUNK", "0")
+    ys = StreamProcessor(chain(), chunk_size=512, device=DEV).process_tensor(torch.from_numpy(x), fs)
+    close(y, ys.cpu().numpy(), 3e-7, "fused vs staged chunk loop")

@@ -675,3 +675,45 @@ def test_user_held_cascade_and_stateful_fir_stay_staged(oracle_backend):
     yb = (fx.Wave(x[:, 10_000:], 48000) | s1 | Gain(0.5)).ys
     s1.reset_state()
     close(torch.cat([ya, yb], dim=1), (fx.Wave(x, 48000) | s1 | Gain(0.5)).ys.numpy(), 1e-6)
+
+
+# ------------------------------------------------------------------ fused per-chunk run of the stream processors
+def test_stream_processor_fuses_small_chunks_and_keeps_member_state(oracle_backend):
+    from torchfx_amd.effect import Gain
+    from torchfx_amd.realtime import StatefulFIR, StreamProcessor, _ChunkRun
+    fs = 48000
+    f1, f2 = F.LoButterworth(3000, order=4, fs=fs), F.ParametricEQ(frequency=800, q=2.0, gain=4.0, fs=fs)
+    fir, g = StatefulFIR(np.hanning(65) / np.hanning(65).sum(), conv_mode="fft"), Gain(1.7, clamp=True)
+    x = torch.from_numpy(np.random.default_rng(3).standard_normal((2, 6000))).float()
+    ref = Gain(1.7, clamp=True)(F.FIR(fir.kernel.flip(-1).reshape(-1).numpy())(
+        F.ParametricEQ(frequency=800, q=2.0, gain=4.0, fs=fs)(F.LoButterworth(3000, order=4, fs=fs)(x))))
+    sp = StreamProcessor([f1, f2, fir, g], chunk_size=512, device="cpu")
+    assert len(sp._segments) == 1 and isinstance(sp._segments[0], _ChunkRun)
+    oracle_backend.calls.clear()
+    y = sp.process_tensor(x, fs)
+    assert {c[0] for c in oracle_backend.calls} == {"chunk_forward"} and len(oracle_backend.calls) == 12   # one launch per chunk
+    close(y, ref.numpy(), 2e-6)
+    # the members still own their state: [K, C, 2] views of the combined tensors, the FIR's history
+    run = sp._segments[0]
+    assert f1._state_y.shape == (2, 2, 2) and f2._state_y.shape == (1, 2, 2) and fir._hist.shape == (2, 64)
+    assert f1._state_y.data_ptr() == run._sy.data_ptr() and f2._state_y.data_ptr() == run._sy[2:].data_ptr()
+    # a member reset in between is honoured: the next chunk starts that member from silence, the others continue
+    sp2 = StreamProcessor([F.LoButterworth(3000, order=4, fs=fs), F.ParametricEQ(frequency=800, q=2.0, gain=4.0, fs=fs)],
+                          chunk_size=1000, device="cpu")
+    a = sp2._run(x[:, :1000])
+    sp2.effects[1].reset_state()
+    b = sp2._run(x[:, 1000:2000])
+    m1, m2 = F.LoButterworth(3000, order=4, fs=fs), F.ParametricEQ(frequency=800, q=2.0, gain=4.0, fs=fs)
+    a_ref = m2(m1(x[:, :1000]))
+    m2.reset_state()
+    b_ref = m2(m1(x[:, 1000:2000]))
+    # several IIR members run as ONE float64 cascade (rounded once, like the Wave planner's fusion); the staged modules
+    # round to float32 between members: equal to a float32 ulp, not bit for bit
+    close(a, a_ref.numpy(), 3e-7)
+    close(b, b_ref.numpy(), 3e-7)
+    # chunks the fused kernel does not take run member by member; lone effects are not wrapped
+    big = StreamProcessor([F.LoButterworth(3000, order=4, fs=fs), Gain(0.5)], chunk_size=8192, device="cpu")
+    oracle_backend.calls.clear()
+    big.process_tensor(torch.zeros(2, 8192), fs)
+    assert [c[0] for c in oracle_backend.calls] == ["sos_forward", "gain_forward"]
+    assert not any(isinstance(s, _ChunkRun) for s in StreamProcessor([F.LoButterworth(3000, order=4, fs=fs)], 512, device="cpu")._segments)

@@ -22,16 +22,18 @@ print("StreamProcessor: LoButterworth-4 | ParametricEQ | StatefulFIR-301 (fft) |
 for C, chunk in ((2, 512), (2, 1024), (2, 2048), (2, 4096), (2, 8192), (2, 16384), (2, 32768), (2, 65536), (16, 4096), (64, 4096)):
     x = torch.randn(C, chunk * 400, device="cuda:0")
     res = {}
-    for g in (False, True):
+    for fuse, g in (("0", False), ("0", True), ("1", False), ("1", True)):
+        os.environ["TORCHFX_AMD_FUSE_CHUNK"] = fuse
         sp = StreamProcessor(make(), chunk_size=chunk, device="cuda:0", use_graph=g)
         sp.process_tensor(x[:, : chunk * 20], 48000)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         y = sp.process_tensor(x, 48000)
         torch.cuda.synchronize()
-        res[g] = (time.perf_counter() - t0) / 400 * 1e6
-    print(f"[{C} x {chunk}] eager {res[False]:7.1f} us/chunk   graph {res[True]:7.1f} us/chunk   x{res[False] / res[True]:.2f}"
-          f"   real-time factor at 48 kHz: {chunk / 48000 * 1e6 / res[True]:.0f}x", flush=True)
+        res[fuse, g] = (time.perf_counter() - t0) / 400 * 1e6
+    print(f"[{C} x {chunk}] staged: eager {res['0', False]:6.1f} graph {res['0', True]:6.1f} | one fused launch: eager "
+          f"{res['1', False]:6.1f} graph {res['1', True]:6.1f} us/chunk   real-time factor at 48 kHz: "
+          f"{chunk / 48000 * 1e6 / min(res.values()):.0f}x", flush=True)
 
 
 # ---- RealtimeProcessor: round trip of one backend callback (host block in -> host block out) ----------------
@@ -52,7 +54,8 @@ class _Backend:
 print("RealtimeProcessor callback (pinned staging in, chain, pinned staging out, one host wait), same chain, 2 channels")
 for B in (128, 256, 512, 1024, 2048, 4096):
     res = {}
-    for g in (False, True):
+    for fuse, g in (("0", False), ("1", False), ("1", True)):
+        os.environ["TORCHFX_AMD_FUSE_CHUNK"] = fuse
         be = _Backend()
         cfg = StreamConfig(sample_rate=48000, buffer_size=B, channels_in=2, channels_out=2)
         with RealtimeProcessor(make(), be, cfg, device="cuda:0", use_graph=g):
@@ -65,6 +68,7 @@ for B in (128, 256, 512, 1024, 2048, 4096):
                 be.callback(xin, out, B)
                 ts.append(time.perf_counter() - t0)
         ts = np.array(ts) * 1e6
-        res[g] = (np.median(ts), np.percentile(ts, 99))
-    print(f"[2 x {B}] eager median {res[False][0]:6.1f} us  p99 {res[False][1]:6.1f}   graph median {res[True][0]:6.1f} us  p99 {res[True][1]:6.1f}"
+        res[fuse, g] = (np.median(ts), np.percentile(ts, 99))
+    print(f"[2 x {B}] staged eager median {res['0', False][0]:6.1f} us p99 {res['0', False][1]:6.1f} | fused eager {res['1', False][0]:6.1f} "
+          f"p99 {res['1', False][1]:6.1f} | fused graph {res['1', True][0]:6.1f} p99 {res['1', True][1]:6.1f}"
           f"   buffer period at 48 kHz {B / 48000 * 1e6:7.0f} us", flush=True)

@@ -21,6 +21,11 @@ void sos_plan_info(const double *sos_host, int64_t K, int *precision, int64_t *w
 void sos_clear_plans();
 void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
                         const void *kernel_host, int64_t K, hipStream_t stream, const void *hist = nullptr, int64_t H = 0);
+bool chunk_supported(int64_t C, int64_t T, int64_t K, int64_t Kf);
+void chunk_forward(const float *x, int64_t x_pitch, float *y, int64_t C, int64_t T, const double *sos_host, int64_t K,
+                   const double *sx_in, const double *sy_in, double *sx_out, double *sy_out,
+                   const float *taps_host, int64_t Kf, const float *hist_in, float *hist_out,
+                   double gain, int scale, int clamp, int precision, hipStream_t stream);
 void fir_hist_update(const void *x, const void *hist_in, void *hist_out, int dtype, int64_t C, int64_t T, int64_t H,
                      hipStream_t stream);
 void fir_clear();
@@ -295,6 +300,19 @@ int tfx_fir_stream_forward(const void *x, void *y, int dtype, int64_t C, int64_t
         TFX_CHECK(T == 0 || x, "fir_stream_forward: null signal");
         fir_hist_update(x, hist_in, hist_out, dtype, C, T, H, (hipStream_t)stream);
     }
+    TFX_API_END
+}
+
+int tfx_chunk_supported(int64_t C, int64_t T, int64_t K, int64_t Kf) { return chunk_supported(C, T, K, Kf) ? 1 : 0; }
+
+int tfx_chunk_forward(const float *x, int64_t x_pitch, float *y, int64_t C, int64_t T, const double *sos_host, int64_t K,
+                      const double *state_x_in, const double *state_y_in, double *state_x_out, double *state_y_out,
+                      const float *taps_host, int64_t Kf, const float *hist_in, float *hist_out,
+                      double gain, int scale, int clamp, int precision, tfx_stream_t stream)
+{
+    TFX_API_BEGIN
+    chunk_forward(x, x_pitch, y, C, T, sos_host, K, state_x_in, state_y_in, state_x_out, state_y_out, taps_host, Kf, hist_in, hist_out,
+                  gain, scale, clamp, precision, (hipStream_t)stream);
     TFX_API_END
 }
 

@@ -64,6 +64,9 @@ void scratch_clear();
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// fir.hip: device copy of a host tap vector, cached by content and device (uploaded, blocking, the first time a filter is seen)
+const void *cached_taps(const void *host, size_t bytes, size_t padded);
+
 // Every device-side cache (plans, taps, spectra, scratch, internal streams, occupancy answers) is
 // keyed by the ordinal of the device that is current at the call: one process may drive several GPUs
 // (the Python layer wraps each op in torch.cuda.device(x.device)).

@@ -340,6 +340,44 @@ std::tuple<Tensor, Tensor> fir_stream_op(const Tensor &x_in, const Tensor &kerne
     return {y, hout};
 }
 
+// one small streaming chunk through cascade -> stateful direct FIR -> gain / clip in ONE launch (tfx_chunk_forward).
+// Returns (y, new_state_x, new_state_y, new_hist); sos_cpu [K, 6] may have K = 0, kernel one tap.
+std::tuple<Tensor, Tensor, Tensor, Tensor> chunk_op(const Tensor &x_in, const Tensor &sos_cpu, const OptTensor &state_x,
+                                                    const OptTensor &state_y, const Tensor &kernel, const OptTensor &hist,
+                                                    double gain, bool scale, bool clamp, int64_t precision)
+{
+    TORCH_CHECK(x_in.dim() == 2 && x_in.scalar_type() == at::kFloat, "chunk_forward: x must be float32 [C, T], got ", x_in.sizes());
+    need_device(x_in, "x");
+    // a chunk is usually a column window of a longer buffer: rows with unit stride are taken as they are (row pitch)
+    const Tensor x = (x_in.stride(1) == 1 && x_in.stride(0) >= x_in.size(1)) ? x_in : x_in.contiguous();
+    const Tensor sos = host_f64(sos_cpu, 6, "chunk_forward");
+    TORCH_CHECK(sos.dim() == 2, "chunk_forward: sos must be [K, 6]");
+    const Tensor k = taps_host(kernel, x);
+    const int64_t C = x.size(0), T = x.size(1), K = sos.size(0), Kf = k.numel();
+    TORCH_CHECK(tfx_chunk_supported(C, T, K, Kf), "chunk_forward: unsupported geometry C=", C, " T=", T, " K=", K, " taps=", Kf);
+    Tensor kx, ky, hin;
+    const double *sx = K ? state_ptr(state_x, {K, C, 2}, x, "state_x", kx) : nullptr;
+    const double *sy = K ? state_ptr(state_y, {K, C, 2}, x, "state_y", ky) : nullptr;
+    const float *hp = nullptr;
+    if (hist.has_value() && hist->defined() && Kf > 1) {
+        TORCH_CHECK(hist->dim() == 2 && hist->size(0) == C && hist->size(1) == Kf - 1, "chunk_forward: history must be [C, K-1] = [",
+                    C, ", ", Kf - 1, "], got ", hist->sizes());
+        hin = hist->to(x.device(), at::kFloat).contiguous();
+        hp = hin.data_ptr<float>();
+    }
+    Tensor y = at::empty({C, T}, x.options());
+    Tensor nsx = at::empty({K, C, 2}, x.options().dtype(at::kDouble));
+    Tensor nsy = at::empty({K, C, 2}, x.options().dtype(at::kDouble));
+    Tensor hout = at::empty({C, Kf - 1}, x.options());
+    c10::hip::HIPGuard guard(x.get_device());
+    check_rc(tfx_chunk_forward(x.data_ptr<float>(), C > 1 ? x.stride(0) : T, y.data_ptr<float>(), C, T, K ? sos.data_ptr<double>() : nullptr, K, sx, sy,
+                               K ? nsx.data_ptr<double>() : nullptr, K ? nsy.data_ptr<double>() : nullptr, k.data_ptr<float>(), Kf,
+                               hp, Kf > 1 ? hout.data_ptr<float>() : nullptr, gain, scale ? 1 : 0, clamp ? 1 : 0,
+                               precision_or_default(precision), stream_of(x)),
+             "chunk_forward");
+    return {y, nsx, nsy, hout};
+}
+
 // ---------------------------------------------------------------------------------------------------
 // `+` of branch outputs, Gain / Normalize passes, layout kernels
 // ---------------------------------------------------------------------------------------------------
@@ -504,6 +542,8 @@ TORCH_LIBRARY(torchfx_hip, m)
     m.def("fir_direct_forward(Tensor x, Tensor kernel) -> Tensor");
     m.def("fft_conv_forward(Tensor x, Tensor kernel, int pad_left, int pad_right) -> Tensor");
     m.def("fir_stream_forward(Tensor x, Tensor kernel, Tensor? hist, bool direct) -> (Tensor, Tensor)");
+    m.def("chunk_forward(Tensor x, Tensor sos_cpu, Tensor? state_x, Tensor? state_y, Tensor kernel, Tensor? hist, float gain, "
+          "bool scale, bool clamp, int precision=-1) -> (Tensor, Tensor, Tensor, Tensor)");
     m.def("sos_forward_ep(Tensor x, Tensor sos_cpu, Tensor? state_x, Tensor? state_y, float gain, bool clamp, int stat_mode, "
           "bool per_row, *, ScalarType? out_dtype=None, int precision=-1) -> (Tensor, Tensor, Tensor, Tensor)");
     m.def("fft_conv_forward_ep(Tensor x, Tensor kernel, int pad_left, int pad_right, float gain, bool clamp, int stat_mode, "
@@ -529,6 +569,7 @@ TORCH_LIBRARY_IMPL(torchfx_hip, CUDA, m)          // "CUDA" is the dispatch key 
     m.impl("fir_direct_forward", fir_direct_op);
     m.impl("fft_conv_forward", fft_conv_op);
     m.impl("fir_stream_forward", fir_stream_op);
+    m.impl("chunk_forward", chunk_op);
     m.impl("sos_forward_ep", sos_ep_op);
     m.impl("fft_conv_forward_ep", fft_conv_ep_op);
     m.impl("normalize_apply", normalize_apply_op);
@@ -567,7 +608,7 @@ static void no_cpu_boxed(const c10::OperatorHandle &op, c10::DispatchKeySet, tor
 TORCH_LIBRARY_IMPL(torchfx_hip, CPU, m)
 {
     for (const char *name : {"sos_forward", "sos_forward_sections", "sos_bank_forward", "sos_bank_sum_forward", "biquad_forward",
-                             "delay_line_forward", "fir_direct_forward", "fft_conv_forward", "fir_stream_forward", "sos_forward_ep",
+                             "delay_line_forward", "fir_direct_forward", "fft_conv_forward", "fir_stream_forward", "chunk_forward", "sos_forward_ep",
                              "fft_conv_forward_ep", "normalize_apply", "sum_forward", "gain_forward", "stat_forward",
                              "normalize_forward", "deinterleave_forward", "deinterleave_into", "interleave_forward"})
         m.impl(name, torch::CppFunction::makeFromBoxedFunction<&no_cpu_boxed>());

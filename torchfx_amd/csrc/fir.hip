@@ -35,7 +35,7 @@ static std::mutex g_taps_mu;
 static std::map<std::vector<char>, void *> g_taps;
 static const std::vector<char> *g_taps_last_key[TFX_MAX_DEVICES] = {};   // per device: the entry used last
 static const void *g_taps_last[TFX_MAX_DEVICES] = {};
-static const void *cached_taps(const void *host, size_t bytes, size_t padded)
+const void *cached_taps(const void *host, size_t bytes, size_t padded)
 {
     const int dev = current_device();
     std::lock_guard<std::mutex> lk(g_taps_mu);

@@ -55,6 +55,7 @@ struct SosParams {
     const double *sx_in, *sy_in;
     double *sx_out, *sy_out;
     int64_t C, T;        // C = output rows (= bands x input rows in filter-bank mode)
+    int64_t x_pitch;     // elements between consecutive input rows (= T for a contiguous [C_in, T] signal)
     int64_t C_in;        // input rows: output row c reads input row c % C_in with the tables of band c / C_in
     int64_t seg_len;     // distance between the starts of consecutive streams of a row = seg_tiles * TILE - warm
     int64_t warm;        // halo of the streams g > 0; multiple of 32 samples (streams start on 128-byte lines)
@@ -113,11 +114,13 @@ template <typename T> struct U16 {               // 16 bytes of T
 //      zeros_like + in-place adds -- so N branches cost 8 B/sample instead of N x 8 + (N + 1) x 4
 // EPI  epilogue on the stored samples (epilogue.h); a separate instantiation so that the plain kernel keeps
 //      its register budget (the statistic accumulator and the extra selects cost ~30 VGPRs = one wave per SIMD)
-template <typename TIn, typename TOut, typename TC, int LC, bool VEC, bool TAPS, bool PF, int MINW, bool SUMB = false, bool EPI = false>
-__global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p)
+// The stream body: one wavefront walks stream `sid` = (row, segment) with `stage` as its private LDS (transposition
+// stage + carry).  Shared by the cascade kernel below and by the fused per-chunk kernel (chunk_iir_fir_kernel), whose
+// output pointer is an LDS buffer.
+template <typename TIn, typename TOut, typename TC, int LC, bool VEC, bool TAPS, bool PF, bool SUMB, bool EPI>
+__device__ __forceinline__ void sos_stream_body(const SosParams &p, const int64_t sid, char *const stage, const int lane)
 {
     static_assert(!(TAPS && SUMB), "section taps are not available in sum mode");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int IOB = sizeof(TIn) > sizeof(TOut) ? sizeof(TIn) : sizeof(TOut);
     constexpr int CHUNK_B = LC * IOB + 16;   // per-lane chunk, padded: conflict-free b128 access
     constexpr int STAGE_B = 64 * CHUNK_B;
@@ -130,23 +133,18 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
     constexpr int EI = 16 / sizeof(TIn), NUI = LC / EI;   // elems per 16 B, units per lane (in)
     constexpr int EO = 16 / sizeof(TOut), NUO = LC / EO;  // (out)
 
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform -> SGPR addressing
     const int K = p.K;
-    const int64_t sid = (int64_t)blockIdx.x * 4 + wave;
     if (sid >= p.C * p.nseg) return;                       // wave-uniform
     const int64_t c = sid / p.nseg;
     const int g = (int)(sid - c * p.nseg);
     const int nbl = SUMB ? p.nsum : 1;                     // bands handled inside this stream
-    const int carry_b = (((nbl * K * 4 + 2 * LC) * (int)sizeof(TC)) + 15) & ~15;
-    char *stage = smem + wave * (STAGE_B + carry_b);
     TC *carry = (TC *)(stage + STAGE_B);                   // [nbl][K][4] = vin1 vin2 y1 y2
     TC *cap = carry + nbl * K * 4;                         // [2][LC] final-state capture scratch
 
     const int64_t T = p.T;
     const int64_t band = SUMB ? 0 : c / p.C_in;
     const int64_t st_rows = SUMB ? p.C_in * nbl : p.C;     // rows of the [K, rows, 2] state tensors
-    const TIn *__restrict__ xrow = (const TIn *)p.x + (c - band * p.C_in) * T;
+    const TIn *__restrict__ xrow = (const TIn *)p.x + (c - band * p.C_in) * p.x_pitch;
     TOut *__restrict__ yrow = (TOut *)p.y + c * T;
     // Coefficient tables live in the CONSTANT address space: wave-uniform indices then lower to
     // s_load (scalar cache, SGPR operands) instead of per-lane vector loads.
@@ -471,6 +469,27 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
         for (int off = 32; off >= 1; off >>= 1) ep_acc = red_comb_rt(p.ep_stat, ep_acc, __shfl_xor(ep_acc, off));
         if (lane == 0) p.ep_partial[sid] = ep_acc;
     }
+}
+
+// bytes of LDS one stream needs: the transposition stage plus the carry (4 values per band and section, 2 x LC capture scratch)
+template <typename TIn, typename TOut, typename TC, int LC>
+__host__ __device__ constexpr int sos_stage_bytes()
+{
+    return 64 * (LC * (int)(sizeof(TIn) > sizeof(TOut) ? sizeof(TIn) : sizeof(TOut)) + 16);
+}
+template <typename TC, int LC> __host__ __device__ inline int sos_carry_bytes(int nbl, int K)
+{
+    return (((nbl * K * 4 + 2 * LC) * (int)sizeof(TC)) + 15) & ~15;
+}
+
+template <typename TIn, typename TOut, typename TC, int LC, bool VEC, bool TAPS, bool PF, int MINW, bool SUMB = false, bool EPI = false>
+__global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform -> SGPR addressing
+    const int per_wave = sos_stage_bytes<TIn, TOut, TC, LC>() + sos_carry_bytes<TC, LC>(SUMB ? p.nsum : 1, p.K);
+    sos_stream_body<TIn, TOut, TC, LC, VEC, TAPS, PF, SUMB, EPI>(p, (int64_t)blockIdx.x * 4 + wave, smem + wave * per_wave, lane);
 }
 
 // Non-finite samples and time segmentation.  In the sequential recursion a NaN / Inf never leaves: once the
@@ -1082,7 +1101,7 @@ void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C_in,
     SosParams p{};
     p.x = x; p.y = y; p.taps = y_sections;
     p.sx_in = sx_in; p.sy_in = sy_in; p.sx_out = sx_out; p.sy_out = sy_out;
-    p.C = C; p.C_in = C_in; p.T = T; p.K = (int)K;
+    p.C = C; p.C_in = C_in; p.T = T; p.K = (int)K; p.x_pitch = T;
     p.nsum = sum_bands ? (int)NB : 0;
     p.ep_gain = ep->gain; p.ep_scale = ep->scale; p.ep_clamp = ep->clamp; p.ep_stat = ep->stat_mode;
     p.ep_partial = nullptr; p.ep_host = ep;
@@ -1115,6 +1134,159 @@ void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C_in,
         else launch_rare<double, double, double>(p, vec, nstreams, stream);
     }
     if (ep->any() && !ep_fused) epilogue_as_passes(y, y_dtype, C, T, *ep, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// One launch per small streaming chunk:  SOS cascade -> direct FIR with carried history -> gain / clip
+// (the reference's small-block caller is RealtimeProcessor._audio_callback, realtime/processor.py:253-292, over
+// StreamProcessor's chunk loop, realtime/stream.py:234-273: a 2 x 512 block is launch-bound -- four to five kernels
+// for a few microseconds of arithmetic).  One workgroup per channel: wave 0 runs the cascade stream body on the chunk
+// (carried DF1 state in / out, float64 or float32 arithmetic, output rounded to float32 exactly like the IIR module's)
+// straight into an LDS buffer that sits behind the channel's FIR history, then all four waves convolve [history |
+// cascade output] with the taps from LDS, apply the gain / clip to what they store and write the next history.
+// Same arithmetic as the staged passes (same cascade code with LC = 16, same float32 FMA order as fir_direct_simple_kernel).
+// ------------------------------------------------------------------------------------------
+struct ChunkParams {
+    SosParams sos;           // x = the chunk [C, T] with row pitch sos.x_pitch; y is replaced by the LDS buffer inside the kernel
+    const float *taps;       // device: [Hpad - H zeros | flipped taps (Kf) | zeros up to Hpad + 4]   (cached_taps)
+    const float *hist_in;    // [C, Kf - 1] or null (= silence)
+    float *hist_out;         // [C, Kf - 1] or null
+    float *y;                // [C, T]
+    int Kf;
+    int Tpad;                // T rounded up to a multiple of 4
+    float gain;
+    int scale, clamp;
+};
+
+template <typename TC, bool VEC>
+__global__ void __launch_bounds__(1024) chunk_iir_fir_kernel(const ChunkParams q)
+{
+    constexpr int LC = 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t c = blockIdx.x;
+    const int T = (int)q.sos.T, H = q.Kf - 1;
+    const int Hpad = (H + 3) & ~3;                         // the cascade output starts on a 16-byte boundary
+    const int Kp = Hpad + 4;                               // padded tap count: leading zeros align the history, trailing ones fill the float4
+    // ubuf = [Hpad - H zeros | history (H) | cascade output (T) | zeros]: every float4 the FIR phase touches is aligned
+    float *ubuf = (float *)smem;                           // [Hpad + Tpad + 8]
+    float *kp = ubuf + Hpad + q.Tpad + 8;                  // [Kp]
+    char *stage = (char *)(kp + Kp);                       // cascade stage + carry (wave 0)
+    float *u = ubuf + Hpad;
+    for (int i = tid; i < Hpad; i += nthr) {
+        const int j = i - (Hpad - H);
+        ubuf[i] = (j >= 0 && q.hist_in) ? q.hist_in[c * H + j] : 0.0f;
+    }
+    for (int i = T + tid; i < q.Tpad + 8; i += nthr) u[i] = 0.0f;
+    for (int i = tid; i < Kp; i += nthr) kp[i] = q.taps[i];
+    if (q.sos.K == 0) {
+        const float *xr = (const float *)q.sos.x + c * q.sos.x_pitch;
+        for (int i = tid; i < T; i += nthr) u[i] = xr[i];
+    } else if (wave == 0) {
+        SosParams p = q.sos;
+        p.y = (void *)(u - c * (int64_t)T);                // the body stores row c at y + c * T
+        p.C_in = p.C;
+        sos_stream_body<float, float, TC, LC, VEC, false, false, false, false>(p, c, stage, lane);
+    }
+    __syncthreads();
+    // direct form, float32 FMA in tap order (as fir_direct_simple_kernel): y[n] = sum_k kp[k] * ubuf[n + k].  A thread owns
+    // four consecutive outputs and slides an 8-sample register window over the taps: one ds_read_b128 of samples and one
+    // (broadcast) of taps per 16 FMAs.
+    const float4 *ub4 = (const float4 *)ubuf, *kp4 = (const float4 *)kp;
+    for (int n0 = 4 * tid; n0 < T; n0 += 4 * nthr) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        float4 a = ub4[n0 >> 2];
+        for (int k = 0; k < Kp; k += 4) {
+            const float4 b = ub4[((n0 + k) >> 2) + 1];
+            const float4 h = kp4[k >> 2];
+            const float win[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[r] = fmaf(h.x, win[r], acc[r]);
+                acc[r] = fmaf(h.y, win[r + 1], acc[r]);
+                acc[r] = fmaf(h.z, win[r + 2], acc[r]);
+                acc[r] = fmaf(h.w, win[r + 3], acc[r]);
+            }
+            a = b;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + r;
+            if (n < T) {
+                float o = acc[r];
+                if (q.scale) o *= q.gain;
+                if (q.clamp) o = clamp_unit(o);
+                q.y[c * T + n] = o;
+            }
+        }
+    }
+    if (q.hist_out)
+        for (int i = tid; i < H; i += nthr) q.hist_out[c * H + i] = ubuf[(Hpad - H) + T + i];      // the last H samples of [hist | u]
+}
+
+bool chunk_supported(int64_t C, int64_t T, int64_t K, int64_t Kf)
+{
+    // one workgroup per channel, everything in LDS; the FIR phase costs T * Kf / 1024 FMAs per thread
+    return C >= 1 && T >= 1 && T <= 4096 && K >= 0 && K <= 64 && Kf >= 1 && Kf <= 4096 && T * Kf <= ((int64_t)1 << 22);
+}
+
+void chunk_forward(const float *x, int64_t x_pitch, float *y, int64_t C, int64_t T, const double *sos_host, int64_t K,
+                   const double *sx_in, const double *sy_in, double *sx_out, double *sy_out,
+                   const float *taps_host, int64_t Kf, const float *hist_in, float *hist_out,
+                   double gain, int scale, int clamp, int precision, hipStream_t stream)
+{
+    TFX_CHECK(chunk_supported(C, T, K, Kf), "chunk_forward: unsupported geometry C=%lld T=%lld K=%lld taps=%lld "
+              "(T <= 4096, K <= 64, T * taps <= 2^22)", (long long)C, (long long)T, (long long)K, (long long)Kf);
+    TFX_CHECK(x && y && taps_host && (K == 0 || sos_host), "chunk_forward: null pointer");
+    TFX_CHECK(hist_out != hist_in || Kf == 1, "chunk_forward: the new history needs its own buffer");
+    ChunkParams q{};
+    SosParams &p = q.sos;
+    p.x = x; p.y = nullptr; p.taps = nullptr;
+    p.sx_in = sx_in; p.sy_in = sy_in; p.sx_out = sx_out; p.sy_out = sy_out;
+    if (x_pitch <= 0) x_pitch = T;
+    TFX_CHECK(x_pitch >= T, "chunk_forward: row pitch %lld smaller than the row length %lld", (long long)x_pitch, (long long)T);
+    p.C = C; p.C_in = C; p.T = T; p.K = (int)K; p.x_pitch = x_pitch;
+    p.nseg = 1; p.warm = 0; p.seg_len = ceil_div(T, 1024) * 1024; p.nsum = 0;
+    p.ep_stat = -1; p.nf_flag = nullptr;
+    int prec = precision;
+    if (K > 0) {
+        for (int64_t i = 0; i < K * 6; ++i) TFX_CHECK(std::isfinite(sos_host[i]), "chunk_forward: non-finite SOS coefficient");
+        SosPlan *pl = get_plan(sos_host, K, stream, 1);
+        if (prec == TFX_PREC_AUTO) prec = (plan_err_bound(pl) <= auto_bound()) ? TFX_PREC_F32 : TFX_PREC_F64;
+        if (prec == TFX_PREC_F32) {
+            p.tab = ensure_table<float>(pl, &pl->tab_f32_lc16, 16, &pl->nsteps16, stream);
+        } else {
+            p.tab = ensure_table<double>(pl, &pl->tab_f64_lc16, 16, &pl->nsteps16, stream);
+        }
+        p.nsteps = pl->nsteps16;
+    }
+    const int H = (int)Kf - 1, Hpad = (H + 3) & ~3, Kp = Hpad + 4;
+    {   // device taps in the kernel's layout: Hpad - H leading zeros (they meet the zero-filled front of the LDS buffer),
+        // the flipped taps, zeros up to Kp; cached by content like every other tap vector
+        std::vector<float> lay((size_t)Kp, 0.0f);
+        memcpy(lay.data() + (Hpad - H), taps_host, (size_t)Kf * 4);
+        q.taps = (const float *)cached_taps(lay.data(), (size_t)Kp * 4, (size_t)Kp * 4);
+    }
+    q.hist_in = Kf > 1 ? hist_in : nullptr; q.hist_out = Kf > 1 ? hist_out : nullptr; q.y = y; q.Kf = (int)Kf;
+    q.Tpad = (int)((T + 3) & ~3);
+    q.gain = (float)gain; q.scale = scale; q.clamp = clamp;
+    const bool vec = (((uintptr_t)x & 15) == 0) && (T % 4 == 0) && (x_pitch % 4 == 0);
+    const bool f32 = prec == TFX_PREC_F32;
+    const size_t stage_b = K > 0 ? (size_t)(sos_stage_bytes<float, float, double, 16>() + (f32 ? sos_carry_bytes<float, 16>(1, (int)K) : sos_carry_bytes<double, 16>(1, (int)K))) : 0;
+    const size_t shmem = (size_t)(Hpad + q.Tpad + 8 + Kp) * 4 + stage_b;
+    TFX_CHECK(shmem <= 64 * 1024, "chunk_forward: needs %zu B of LDS", shmem);
+    // the cascade is one wavefront's work; the FIR phase scales with the threads: 4 outputs each
+    const int threads = T * Kf <= (1 << 14) ? 256 : 1024;
+    ProfScope ps("chunk_iir_fir_kernel", stream);
+    if (f32) {
+        if (vec) hipLaunchKernelGGL((chunk_iir_fir_kernel<float, true>), dim3((unsigned)C), dim3(threads), shmem, stream, q);
+        else hipLaunchKernelGGL((chunk_iir_fir_kernel<float, false>), dim3((unsigned)C), dim3(threads), shmem, stream, q);
+    } else {
+        if (vec) hipLaunchKernelGGL((chunk_iir_fir_kernel<double, true>), dim3((unsigned)C), dim3(threads), shmem, stream, q);
+        else hipLaunchKernelGGL((chunk_iir_fir_kernel<double, false>), dim3((unsigned)C), dim3(threads), shmem, stream, q);
+    }
+    TFX_HIP(hipGetLastError());
 }
 
 void sos_plan_info(const double *sos_host, int64_t K, int *precision, int64_t *warmup, double *err_bound)

@@ -22,6 +22,7 @@ from __future__ import annotations
 import abc
 import dataclasses
 import enum
+import os
 import threading
 from collections.abc import Generator, Sequence
 
@@ -69,6 +70,127 @@ class StatefulFIR(FIR):
         return y.reshape(shape)
 
 
+class _ChunkRun:
+    """``IIR ... | StatefulFIR | Gain`` (any non-empty sub-pattern of at least two effects) as ONE launch per small chunk
+    (``torchfx_ext.chunk_forward``): the chain of a 2 x 512 block is launch-bound, not arithmetic-bound.  Consecutive
+    IIR members run as one float64 cascade rounded to float32 once -- what the ``Wave`` planner does with them
+    (``wave.py:207-239``); member by member they would round to float32 in between, so the two agree to a float32 ulp.
+
+    The members stay the owners of their state as far as a caller can see: after every chunk each IIR member's
+    ``_state_x`` / ``_state_y`` are row-block views of the combined ``[sum K, C, 2]`` tensors the kernel wrote and the FIR's
+    ``_hist`` is the kernel's new history, so a member that is reset, redesigned or run on its own in between is
+    picked up on the next chunk (the combined state is then rebuilt from what the members hold).  Chunks the fused
+    kernel does not take (too long, float64) run member by member, exactly as before."""
+
+    def __init__(self, iirs: list, fir, gain) -> None:
+        self.iirs, self.fir, self.gain = iirs, fir, gain
+        self.members = [*iirs, *([fir] if fir is not None else []), *([gain] if gain is not None else [])]
+        self._sos_key = None
+        self._sos = None
+        self._sx = self._sy = None
+        self._views: list = []
+        self._one = torch.ones(1)                     # "no FIR": one unit tap
+        self._geom: dict = {}
+
+    def _table(self) -> Tensor:
+        for m in self.iirs:
+            if m._sos is None:
+                m.compute_coefficients()
+        key = tuple((id(m._sos), m._sos._version) for m in self.iirs)
+        if key != self._sos_key:
+            self._sos = (torch.cat([m._sos for m in self.iirs]).contiguous() if self.iirs else torch.zeros(0, 6, dtype=torch.float64))
+            self._sos_key = key
+            self._keep = [m._sos for m in self.iirs]             # the ids in the key stay unique
+        return self._sos
+
+    def _states(self, rows: int, device) -> tuple[Tensor | None, Tensor | None]:
+        if not self.iirs:
+            return None, None
+        if self._sx is not None and len(self._views) == len(self.iirs) and all(
+                m._state_x is vx and m._state_y is vy for m, (vx, vy) in zip(self.iirs, self._views)):
+            return self._sx, self._sy                           # untouched since the last chunk
+        if all(m._state_x is None for m in self.iirs):
+            return None, None                                   # fresh: the kernel treats None as zeros
+        xs, ys = [], []
+        for m in self.iirs:
+            k = int(m._sos.shape[0])
+            ok = m._state_x is not None and m._state_y is not None and tuple(m._state_x.shape) == (k, rows, 2)
+            xs.append(m._state_x.to(device) if ok else torch.zeros(k, rows, 2, dtype=torch.float64, device=device))
+            ys.append(m._state_y.to(device) if ok else torch.zeros(k, rows, 2, dtype=torch.float64, device=device))
+        return torch.cat(xs), torch.cat(ys)
+
+    def fuses(self, w: Tensor) -> bool:
+        """Whether this chunk goes through the one-launch kernel (geometry answers are cached: one ctypes call each)."""
+        if w.dtype != torch.float32 or w.dim() != 2 or w.shape[-1] == 0:
+            return False
+        from torchfx_amd import torchfx_ext
+
+        taps = self.fir.kernel.numel() if self.fir is not None else 1
+        key = (w.shape[0], w.shape[1], int(self._table().shape[0]), taps)
+        ok = self._geom.get(key)
+        if ok is None:
+            ok = self._geom[key] = torchfx_ext.chunk_supported(*key)
+        return ok
+
+    def __call__(self, w: Tensor) -> Tensor:
+        from torchfx_amd import torchfx_ext
+
+        taps = self.fir.kernel.reshape(-1) if self.fir is not None else self._one
+        sos = self._table()
+        if not self.fuses(w):
+            for m in self.members:
+                w = m(w)
+            return w
+        rows = w.shape[0]
+        sx, sy = self._states(rows, w.device)
+        hist = self.fir._hist if self.fir is not None else None
+        if hist is not None and (hist.shape[0] != rows or hist.dtype != w.dtype or hist.device != w.device):
+            hist = None
+        g = self.gain.linear_gain() if self.gain is not None else None
+        y, nsx, nsy, nh = torchfx_ext.chunk_forward(w, sos, sx, sy, taps, hist, g,
+                                                    bool(self.gain is not None and self.gain.clamp))
+        self._sx, self._sy, self._views = nsx, nsy, []
+        k0 = 0
+        for m in self.iirs:
+            k1 = k0 + int(m._sos.shape[0])
+            m._state_x, m._state_y = nsx[k0:k1], nsy[k0:k1]
+            self._views.append((m._state_x, m._state_y))
+            k0 = k1
+        if self.fir is not None and taps.numel() > 1:
+            self.fir._hist = nh
+        return y
+
+
+def _chunk_segments(effects: list) -> list:
+    """Group the effect list into fused per-chunk runs (``_ChunkRun``) and single effects."""
+    from torchfx_amd.effect import Gain
+    from torchfx_amd.filter.biquad import Biquad
+    from torchfx_amd.filter.iir import IIR
+
+    out, i, n = [], 0, len(effects)
+    while i < n:
+        j = i
+        iirs = []
+        while j < n and isinstance(effects[j], (IIR, Biquad)):
+            iirs.append(effects[j])
+            j += 1
+        fir = None
+        if j < n and isinstance(effects[j], StatefulFIR) and type(effects[j]).forward is StatefulFIR.forward:
+            fir = effects[j]
+            j += 1
+        gain = None
+        if (iirs or fir is not None) and j < n and type(effects[j]) is Gain:
+            gain = effects[j]
+            j += 1
+        if len(iirs) + (fir is not None) + (gain is not None) >= 2:
+            out.append(_ChunkRun(iirs, fir, gain))
+            i = j
+        else:
+            out.append(effects[i])
+            i += 1
+    return out
+
+
 class StreamProcessor:
     """Run a list of effects over a long ``[C, T]`` tensor chunk by chunk."""
 
@@ -87,6 +209,8 @@ class StreamProcessor:
         self._chunk_size, self._overlap, self._device = chunk_size, overlap, device
         self._use_graph = use_graph
         self._graph = None            # (CUDAGraph, static in, static out, stream, signature, state slots, homes)
+        # small chunks: runs of IIR ... | StatefulFIR | Gain go through one fused launch (TORCHFX_AMD_FUSE_CHUNK=0: never)
+        self._segments = _chunk_segments(self._effects) if os.environ.get("TORCHFX_AMD_FUSE_CHUNK", "1") != "0" else list(self._effects)
 
     chunk_size = property(lambda self: self._chunk_size)
     overlap = property(lambda self: self._overlap)
@@ -133,8 +257,13 @@ class StreamProcessor:
                             slots.append((f, a))
         return slots
 
+    def _fused(self, w: Tensor) -> bool:
+        """The whole chain is one fused launch for this chunk: nothing for a HIP graph to save (one kernel node against
+        the copy-in / replay / copy-out of a graph step)."""
+        return len(self._segments) == 1 and isinstance(self._segments[0], _ChunkRun) and self._segments[0].fuses(w)
+
     def _run(self, w: Tensor) -> Tensor:
-        for e in self._effects:
+        for e in self._segments:
             w = e(w)
         return w
 
@@ -194,7 +323,7 @@ class StreamProcessor:
         while offset < n:
             w = x[..., offset:offset + self._chunk_size].to(self._device)
             full = w.shape[-1] == self._chunk_size
-            if self._use_graph and full and primed and w.is_cuda:
+            if self._use_graph and full and primed and w.is_cuda and not self._fused(w):
                 w = self._graph_step(w)
             else:
                 w = self._run(w)            # first chunk creates the states; ragged tail runs eagerly
@@ -225,7 +354,7 @@ class StreamProcessor:
             frames, _ = sf.read(str(input_path), start=offset, stop=offset + n, dtype="float32", always_2d=True)
             # interleaved [n, C] -> planar [C, n] on the device (reference: data_np.T.copy() on the host)
             w = _io.upload_interleaved(frames, self._device) if on_gpu else torch.from_numpy(frames.T.copy())
-            if self._use_graph and on_gpu and primed and w.shape[-1] == self._chunk_size:
+            if self._use_graph and on_gpu and primed and w.shape[-1] == self._chunk_size and not self._fused(w):
                 w = self._graph_step(w)
             else:
                 w = self._run(w)
@@ -428,7 +557,7 @@ class RealtimeProcessor:
 
     def _chain(self, w: Tensor) -> Tensor:
         full = w.shape[-1] == self._config.buffer_size
-        if self._runner._use_graph and w.is_cuda and full and self._primed:
+        if self._runner._use_graph and w.is_cuda and full and self._primed and not self._runner._fused(w):
             return self._runner._graph_step(w)
         y = self._runner._run(w)             # the first block creates the carried states; ragged blocks run eagerly
         self._primed = self._primed or full

@@ -33,7 +33,7 @@ from torchfx_amd import native
 
 __all__ = [
     "biquad_forward", "sos_forward", "sos_bank_forward", "sos_bank_sum_forward", "delay_line_forward",
-    "fir_direct_forward", "fft_conv_forward", "fir_stream_forward", "normalize_apply", "Epilogue", "sum_forward", "gain_forward", "stat_forward", "normalize_forward",
+    "fir_direct_forward", "fft_conv_forward", "fir_stream_forward", "chunk_forward", "chunk_supported", "normalize_apply", "Epilogue", "sum_forward", "gain_forward", "stat_forward", "normalize_forward",
     "deinterleave_forward", "interleave_forward", "sos_plan_info", "ols_plan_info",
 ]
 
@@ -179,6 +179,21 @@ def fir_stream_forward(x: Tensor, kernel, hist: Tensor | None, direct: bool = Fa
     [C,K-1]`` (``None`` = silence).  Returns ``(y [C,T], new_hist [C,K-1])``.  The kernels read history and
     chunk from their two buffers -- no concatenated copy of the chunk."""
     return native.ops().fir_stream_forward(x, _kernel_host(kernel, x.dtype), hist, bool(direct))
+
+
+def chunk_supported(C: int, T: int, K: int, taps: int) -> bool:
+    """Whether :func:`chunk_forward` takes a ``[C, T]`` chunk with ``K`` sections and ``taps`` FIR taps (host-only query)."""
+    return bool(L.load().tfx_chunk_supported(int(C), int(T), int(K), int(taps)))
+
+
+def chunk_forward(x: Tensor, sos, state_x: Tensor | None, state_y: Tensor | None, kernel, hist: Tensor | None,
+                  gain: float | None = None, clamp: bool = False, *, precision=None):
+    """ONE launch for one small streaming chunk ``x [C, T]`` (float32): SOS cascade with carried state -> stateful
+    direct FIR (``kernel`` = flipped taps, ``hist [C, K-1]`` or None) -> ``* gain`` (None = no gain stage) and clip.
+    Returns ``(y, new_state_x, new_state_y, new_hist)``; same arithmetic as ``sos_forward`` -> ``fir_stream_forward(direct)`` ->
+    ``gain_forward`` (equal to float64 round-off of the recursion).  ``sos [K, 6]`` host float64 (``K`` may be 0), limits: :func:`chunk_supported`."""
+    return native.ops().chunk_forward(x, _coeff(sos), state_x, state_y, _kernel_host(kernel, torch.float32), hist,
+                                      1.0 if gain is None else float(gain), gain is not None, bool(clamp), _prec(precision))
 
 
 def sum_forward(tensors: list[Tensor]) -> Tensor:
