@@ -466,6 +466,8 @@ def main() -> None:
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.randn(C, T, device=dev, generator=gen, dtype=torch.float32)
     x.mul_(1.0 / float(x.abs().max()))     # max|x| <= 1 (benchmarks/conftest.py:70-82 of the reference)
+    if os.environ.get("TFX_BENCH_ZERO_INPUT", "0") == "1":
+        x.zero_()                          # development only: a compute-bound kernel without data toggling (clock / power study)
 
     step, desc, ols_taps = make_step(args.workload, x)
 

@@ -91,28 +91,34 @@ __device__ __forceinline__ int xpad33(int m) { return m + (m >> 5); }
 // kf_dev: [Kpad] flipped taps on device, zero-padded to a multiple of FIR_KC_MAX
 // FIR_KC: taps per chunk (128 / 512 / 1024 -- short filters do not pay for 1024-tap chunks).
 // DBG (tools/ubench/fir_probe.hip only): bit 0 drops the output stores, bit 1 the global loads.
-template <int FIR_KC, int DBG = 0>
-__global__ void __launch_bounds__(256, 2)
+// NJ = 32x32 output tiles per wave (TFX_FIR_NJ): 4 = 16384 outputs and a 76 KB window per workgroup, two workgroups per
+// CU (rounds 1-2); 2 = 8192 outputs, 43 KB, three per CU; 1 = 4096 outputs, 26 KB, five per CU (default).  With two
+// workgroups per CU, both fill their window, multiply and store in lockstep, so the matrix pipe idles during every fill
+// and store; more, smaller workgroups interleave those phases: cfg 3 2.86 / 2.77 / 2.73 ms for NJ = 4 / 2 / 1 on one box
+// (profiles/r03_fir.txt; NJ = 1 at six waves per SIMD spills 36 B and is back to 2.78).
+template <int FIR_KC, int DBG = 0, int NJ = FIR_NJ>
+__global__ void __launch_bounds__(256, NJ == 4 ? 2 : (NJ == 2 ? 3 : 5))
 fir_direct_mfma_kernel(const float *__restrict__ x, float *__restrict__ y,
                        const float *__restrict__ kf_dev, int64_t C, int64_t T, int K, int nchunks,
                        int64_t tiles_per_row, const float *__restrict__ hist, int H)
 {
     // hist (streaming, StatefulFIR): [C, H] samples that precede the row, x[-H .. -1]; null = zeros
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int XW = FIR_NOUT + FIR_KC + 32;              // window length (floats)
+    constexpr int WOUT = NJ * 1024, NOUT = 4 * WOUT;
+    constexpr int XW = NOUT + FIR_KC + 32;              // window length (floats)
     constexpr int XW_PAD = XW + (XW >> 5) + 1;
     float *xw = (float *)smem;                              // [XW_PAD]
     float *kp = xw + ((XW_PAD + 3) & ~3);                   // [31 + FIR_KC + 33]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t c = blockIdx.x / tiles_per_row;
-    const int64_t n0 = (blockIdx.x % tiles_per_row) * (int64_t)FIR_NOUT;
+    const int64_t n0 = (blockIdx.x % tiles_per_row) * (int64_t)NOUT;
     const float *xrow = x + c * T;
     float *yrow = y + c * T;
 
-    floatx16 acc[FIR_NJ];
+    floatx16 acc[NJ];
 #pragma unroll
-    for (int t = 0; t < FIR_NJ; ++t)
+    for (int t = 0; t < NJ; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
@@ -121,7 +127,7 @@ fir_direct_mfma_kernel(const float *__restrict__ x, float *__restrict__ y,
     // Per-lane LDS bases.  With s = 32*blk + 2*q + kk the padded window index of A[i=li][s] for
     // tile t is  (xb + xb/32 + 33*li + kk) + 1056*t + 33*blk + 2*q  and the Toeplitz tap index is
     // (31 - li + kk) + 32*blk + 2*q : everything but `blk` is an immediate ds_read offset.
-    const int xb = wave * FIR_WOUT;
+    const int xb = wave * WOUT;
     const float *pa0 = xw + xb + (xb >> 5) + 33 * li + kk;
     const float *pb0 = kp + 31 - li + kk;
     constexpr int XV = (XW + 255) / 256;                    // window loads per thread
@@ -201,7 +207,7 @@ fir_direct_mfma_kernel(const float *__restrict__ x, float *__restrict__ y,
             for (int q = 0; q < 16; ++q) {
                 const float b = pb[2 * q];
 #pragma unroll
-                for (int t = 0; t < FIR_NJ; ++t) {
+                for (int t = 0; t < NJ; ++t) {
                     const float a = pa[1056 * t + 2 * q];
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
                 }
@@ -211,8 +217,8 @@ fir_direct_mfma_kernel(const float *__restrict__ x, float *__restrict__ y,
 
     // D layout: lane holds column j = lane&31, rows i = 8*(r/4) + 4*(lane>>5) + (r&3)
 #pragma unroll
-    for (int t = 0; t < FIR_NJ; ++t) {
-        const int64_t nb = n0 + wave * FIR_WOUT + t * 1024;
+    for (int t = 0; t < NJ; ++t) {
+        const int64_t nb = n0 + wave * WOUT + t * 1024;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = 8 * (r >> 2) + 4 * kk + (r & 3);
@@ -314,7 +320,10 @@ void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
     const bool few_tiles = C * ceil_div(T, (int64_t)1024) <= envi_fir("TFX_FIR_ONE_ROUND_TILES", 2048);   // 0: MFMA whenever T allows (tests)
     const bool short_rows = dtype == TFX_F32 && (T < envi_fir("TFX_FIR_MFMA_MIN_T", FIR_NOUT / 4) || few_tiles);
     if (dtype == TFX_F32 && !short_rows) {
-        const int64_t tiles = ceil_div(T, FIR_NOUT);
+        const int njv = (int)envi_fir("TFX_FIR_NJ", 1);
+        const int nj = (njv == 2 || njv == 4) ? njv : 1;
+        const int nout = 4 * nj * 1024;
+        const int64_t tiles = ceil_div(T, nout);
         TFX_CHECK(C * tiles < (1ll << 31), "fir_direct_forward: grid too large");
         // chunk size: cost per chunk ~ (KC+32)/32 contraction blocks + ~4 blocks' worth of refill
         int kc = 1024;
@@ -329,11 +338,11 @@ void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
         }
         const int nchunks = (int)ceil_div(K, kc);
         auto launch = [&](auto kern, int KC) {
-            const int XW = FIR_NOUT + KC + 32;
+            const int XW = nout + KC + 32;
             const int XW_PAD = XW + (XW >> 5) + 1;
             const size_t shmem = (((XW_PAD + 3) & ~3) + 31 + KC + 33) * sizeof(float);
-            static bool attr_done[TFX_MAX_DEVICES][3] = {};
-            bool &done = attr_done[current_device()][KC == 128 ? 0 : (KC == 512 ? 1 : 2)];
+            static bool attr_done[TFX_MAX_DEVICES][9] = {};
+            bool &done = attr_done[current_device()][(KC == 128 ? 0 : (KC == 512 ? 1 : 2)) + (nj == 2 ? 3 : (nj == 1 ? 6 : 0))];
             if (!done) {
                 TFX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
                 done = true;
@@ -343,7 +352,15 @@ void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
                                (float *)y, (const float *)kdev, C, T, (int)K, nchunks, tiles, (const float *)hist, (int)H);
             TFX_HIP(hipGetLastError());
         };
-        if (kc == 128) launch(fir_direct_mfma_kernel<128, 0>, 128);
+        if (nj == 1) {
+            if (kc == 128) launch(fir_direct_mfma_kernel<128, 0, 1>, 128);
+            else if (kc == 512) launch(fir_direct_mfma_kernel<512, 0, 1>, 512);
+            else launch(fir_direct_mfma_kernel<1024, 0, 1>, 1024);
+        } else if (nj == 2) {
+            if (kc == 128) launch(fir_direct_mfma_kernel<128, 0, 2>, 128);
+            else if (kc == 512) launch(fir_direct_mfma_kernel<512, 0, 2>, 512);
+            else launch(fir_direct_mfma_kernel<1024, 0, 2>, 1024);
+        } else if (kc == 128) launch(fir_direct_mfma_kernel<128, 0>, 128);
         else if (kc == 512) launch(fir_direct_mfma_kernel<512, 0>, 512);
         else launch(fir_direct_mfma_kernel<1024, 0>, 1024);
     } else {
