@@ -16,7 +16,7 @@
 namespace tfx {
 
 constexpr int EFX_THREADS = 256;
-constexpr int EFX_U = 4;                                   // 16-byte vectors per thread
+constexpr int EFX_U = 1;                                   // 16-byte vectors per thread (1: short-lived waves stream best, stream_copy2.hip)
 
 template <typename T> struct Vec16;
 template <> struct Vec16<float> { typedef float4 type; static constexpr int N = 4; };
@@ -33,7 +33,7 @@ gain_kernel(const T *__restrict__ x, T *__restrict__ y, int64_t n, T g)
     if (base + (int64_t)(EFX_U - 1) * EFX_THREADS * N + N <= n && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
         V v[EFX_U];
 #pragma unroll
-        for (int u = 0; u < EFX_U; ++u) v[u] = *(const V *)(x + base + (int64_t)u * EFX_THREADS * N);
+        for (int u = 0; u < EFX_U; ++u) v[u] = ldg16_stream<V>(x + base + (int64_t)u * EFX_THREADS * N);
 #pragma unroll
         for (int u = 0; u < EFX_U; ++u) {
             T *e = (T *)&v[u];
@@ -42,7 +42,7 @@ gain_kernel(const T *__restrict__ x, T *__restrict__ y, int64_t n, T g)
                 e[i] = e[i] * g;
                 if (CLAMP) e[i] = clamp_unit(e[i]);
             }
-            *(V *)(y + base + (int64_t)u * EFX_THREADS * N) = v[u];
+            stg16_stream<V>(y + base + (int64_t)u * EFX_THREADS * N, v[u]);
         }
     } else {
 #pragma unroll
@@ -150,7 +150,7 @@ normalize_apply_kernel(const T *__restrict__ x, T *__restrict__ y, int64_t T_, i
     if (base + (int64_t)(EFX_U - 1) * EFX_THREADS * N + N <= T_ && (((uintptr_t)xr | (uintptr_t)yr) & 15) == 0) {
         V v[EFX_U];
 #pragma unroll
-        for (int u = 0; u < EFX_U; ++u) v[u] = *(const V *)(xr + base + (int64_t)u * EFX_THREADS * N);
+        for (int u = 0; u < EFX_U; ++u) v[u] = ldg16_stream<V>(xr + base + (int64_t)u * EFX_THREADS * N);
 #pragma unroll
         for (int u = 0; u < EFX_U; ++u) {
             T *e = (T *)&v[u];
@@ -158,7 +158,7 @@ normalize_apply_kernel(const T *__restrict__ x, T *__restrict__ y, int64_t T_, i
 #pragma unroll
                 for (int i = 0; i < N; ++i) e[i] = (e[i] / s) * peak;
             }
-            *(V *)(yr + base + (int64_t)u * EFX_THREADS * N) = v[u];
+            stg16_stream<V>(yr + base + (int64_t)u * EFX_THREADS * N, v[u]);
         }
     } else {
 #pragma unroll
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(EFX_THREADS) sum_kernel(SumArgs a, T *__restri
         V v[SUM_MAX];
 #pragma unroll
         for (int i = 0; i < SUM_MAX; ++i)
-            if (i < a.n) v[i] = *(const V *)((const T *)a.p[i] + base);
+            if (i < a.n) v[i] = ldg16_stream<V>((const T *)a.p[i] + base);
         V acc;
         T *ac = (T *)&acc;
 #pragma unroll
@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(EFX_THREADS) sum_kernel(SumArgs a, T *__restri
 #pragma unroll
                 for (int k = 0; k < N; ++k) ac[k] += e[k];
             }
-        *(V *)(y + base) = acc;
+        stg16_stream<V>(y + base, acc);
     } else {
         for (int k = 0; k < N && base + k < total; ++k) {
             T acc = (T)0;
