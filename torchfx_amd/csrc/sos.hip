@@ -66,7 +66,7 @@ struct SosParams {
     double ep_gain;
     int ep_scale, ep_clamp, ep_stat;
     double *ep_partial;  // [C * nseg], one per stream (row-major over (row, segment)), pre-zeroed
-    int *nf_flag;        // [C * nseg]: stream ended with a non-finite carried state (nseg > 1 only, pre-zeroed)
+    int *nf_flag;        // [C * nseg]: stream ended with a non-finite carried state (nseg > 1 only; every stream writes its slot)
     const void *ep_host; // host side only: the Epilogue this launch serves
     int ep_fused;        // host side only: the kernel applies it (else separate passes follow the launch)
 };
@@ -170,7 +170,10 @@ __device__ __forceinline__ void sos_stream_body(const SosParams &p, const int64_
     // first `warm` samples of a stream g > 0 being its halo (plan_segments)
     const int64_t start = (int64_t)g * p.seg_len;
     const int64_t out_begin = g ? start + p.warm : 0;
-    if (out_begin >= T) return;
+    if (out_begin >= T) {
+        if (p.nf_flag && lane == 0) p.nf_flag[sid] = 0;
+        return;
+    }
     int64_t out_end = start + p.seg_len + p.warm;
     if (out_end > T || g == p.nseg - 1) out_end = T;
     const bool last_seg = (out_end == T);
@@ -477,7 +480,8 @@ __device__ __forceinline__ void sos_stream_body(const SosParams &p, const int64_
         // whatever an epilogue (clamp) made of the stored samples
         int badc = 0;
         for (int i = lane; i < nbl * K * 4; i += 64) badc |= !(fabs((double)carry[i]) <= 1.79e308);
-        if (__any(badc) && lane == 0) p.nf_flag[sid] = 1;
+        const int anyb = __any(badc) ? 1 : 0;
+        if (lane == 0) p.nf_flag[sid] = anyb;
     }
     if (EPI && p.ep_stat >= 0) {           // one partial per stream, lanes combined in a fixed order
 #pragma unroll
@@ -510,44 +514,43 @@ __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p
 // Non-finite samples and time segmentation.  In the sequential recursion a NaN / Inf never leaves: once the
 // state is non-finite every later output of the row is (iir_cpu.cpp:132-147).  A segment that starts from its
 // warm-up halo does not see what happened before the halo, so every stream leaves a flag "my carried state ended
-// non-finite" and, after the main launch, every segment g > 0 checks the flags of the earlier segments of its row
-// and, if one is set, overwrites itself with NaN -- its samples (and section taps), its statistic partial (so a
-// following Normalize sees NaN like the standalone reduction would) and, for the last segment, the returned
-// states: "non-finite from the first bad sample to the end of the row", independent of how many segments the
-// launch used and of what an epilogue (clamp) did to the stored samples.  Finite signals: one tiny launch that
-// reads nseg flags per workgroup and exits.
+// non-finite" (every slot is written: no memset in front of the launch) and a second, tiny launch -- one workgroup
+// per row; the kernel boundary is what makes the flags and samples of the eight XCDs' L2s visible -- finds the first
+// flagged segment g0 of its row and overwrites the segments after it with NaN: their samples (and section taps),
+// their statistic partials (so a following Normalize sees NaN like the standalone reduction would) and the returned
+// states: "non-finite from the first bad sample to the end of the row", independent of how many segments the launch
+// used and of what an epilogue (clamp) did to the stored samples.  Finite signals: C workgroups read nseg flags each
+// and exit.  (Folding this into the main launch -- last workgroup to finish, device-scope fences -- was measured:
+// the per-workgroup release fence writes back the XCD's L2 and the cfg-2 kernel went from 0.29-0.33 to 0.46-0.52 ms.)
 //   y rows = C (output rows); state rows = st_rows with row c owning {b * C_in + c} for b < nbl in sum mode.
 template <typename TOut>
-__global__ void __launch_bounds__(256) sos_nonfinite_fix_kernel(TOut *__restrict__ y, TOut *__restrict__ taps, int64_t C, int64_t T,
-                                                                int64_t seg_len, int64_t warm, int nseg, const int *__restrict__ nf_flag,
-                                                                double *ep_partial, double *sx_out, double *sy_out, int K,
-                                                                int64_t st_rows, int64_t C_in, int nbl)
+__global__ void __launch_bounds__(256) sos_nonfinite_fix_kernel(const SosParams p, int nbl, int64_t st_rows)
 {
-    __shared__ int bad;
-    const int64_t row = blockIdx.x / (nseg - 1);
-    const int g = (int)(blockIdx.x % (nseg - 1)) + 1;
-    const int64_t begin = (int64_t)g * seg_len + warm;          // first sample segment g stores
+    __shared__ int sh_first;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int64_t T = p.T, row = blockIdx.x;
+    if (tid == 0) sh_first = p.nseg;
+    __syncthreads();
+    for (int q = tid; q < p.nseg; q += nthr)
+        if (p.nf_flag[row * p.nseg + q]) atomicMin(&sh_first, q);
+    __syncthreads();
+    const int g0 = sh_first;
+    if (g0 >= p.nseg - 1) return;                                // clean row, or only the last segment is bad (it poisons itself)
+    const int64_t begin = (int64_t)(g0 + 1) * p.seg_len + p.warm;   // first sample segment g0 + 1 stores
     if (begin >= T) return;
-    if (threadIdx.x == 0) bad = 0;
-    __syncthreads();
-    for (int q = threadIdx.x; q < g; q += 256)
-        if (nf_flag[row * nseg + q]) bad = 1;
-    __syncthreads();
-    if (!bad) return;
-    const int64_t end = (g == nseg - 1 || begin + seg_len > T) ? T : begin + seg_len;
+    TOut *y = (TOut *)p.y, *taps = (TOut *)p.taps;
     const TOut nanv = (TOut)__builtin_nan("");
-    for (int64_t n = begin + threadIdx.x; n < end; n += 256) y[row * T + n] = nanv;
+    for (int64_t n = begin + tid; n < T; n += nthr) y[row * T + n] = nanv;
     if (taps)
-        for (int s = 0; s < K; ++s)
-            for (int64_t n = begin + threadIdx.x; n < end; n += 256) taps[((int64_t)s * C + row) * T + n] = nanv;
-    if (ep_partial && threadIdx.x == 0) ep_partial[row * nseg + g] = __builtin_nan("");
-    if (end == T) {
-        for (int i = threadIdx.x; i < nbl * K * 2; i += 256) {
-            const int b = i / (K * 2), sct = (i >> 1) % K, f = i & 1;
-            const int64_t o = ((int64_t)sct * st_rows + (nbl > 1 ? b * C_in + row : row)) * 2 + f;
-            if (sx_out && sct > 0) sx_out[o] = __builtin_nan("");   // section 0's input history is the signal itself: already exact
-            if (sy_out) sy_out[o] = __builtin_nan("");
-        }
+        for (int sct = 0; sct < p.K; ++sct)
+            for (int64_t n = begin + tid; n < T; n += nthr) taps[((int64_t)sct * p.C + row) * T + n] = nanv;
+    if (p.ep_stat >= 0 && p.ep_partial)
+        for (int g = g0 + 1 + tid; g < p.nseg; g += nthr) p.ep_partial[row * p.nseg + g] = __builtin_nan("");
+    for (int i = tid; i < nbl * p.K * 2; i += nthr) {
+        const int b = i / (p.K * 2), sct = (i >> 1) % p.K, f = i & 1;
+        const int64_t o = ((int64_t)sct * st_rows + (nbl > 1 ? b * p.C_in + row : row)) * 2 + f;
+        if (p.sx_out && sct > 0) p.sx_out[o] = __builtin_nan("");   // section 0's input history is the signal itself: already exact
+        if (p.sy_out) p.sy_out[o] = __builtin_nan("");
     }
 }
 
@@ -976,19 +979,15 @@ static void launch_one(SosParams p, int64_t plan_warm, hipStream_t stream)
         TFX_HIP(hipMemsetAsync(p.ep_partial, 0, (size_t)nstreams * sizeof(double), stream));
     }
     p.nf_flag = nullptr;
-    if (p.nseg > 1) {                      // see sos_nonfinite_fix_kernel
+    if (p.nseg > 1)                        // see sos_nonfinite_fix_kernel: every stream writes its slot, no memset needed
         p.nf_flag = (int *)scratch("sos_nf_flag", (size_t)nstreams * sizeof(int), stream);
-        TFX_HIP(hipMemsetAsync(p.nf_flag, 0, (size_t)nstreams * sizeof(int), stream));
-    }
     {
         ProfScope ps(sizeof(TC) == 8 ? "sos_stream_kernel<f64>" : "sos_stream_kernel<f32>", stream);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, stream, p);
         TFX_HIP(hipGetLastError());
     }
-    if (p.nseg > 1) {
-        hipLaunchKernelGGL(sos_nonfinite_fix_kernel<TOut>, dim3((unsigned)(p.C * (p.nseg - 1))), dim3(256), 0, stream, (TOut *)p.y,
-                           (TOut *)p.taps, p.C, p.T, p.seg_len, p.warm, p.nseg, p.nf_flag, p.ep_stat >= 0 ? p.ep_partial : nullptr,
-                           p.sx_out, p.sy_out, p.K, SUMB ? p.C_in * nbl : p.C, p.C_in, nbl);
+    if (p.nseg > 1) {                      // ~2 us on cfg 2 (measured by leaving it out)
+        hipLaunchKernelGGL(sos_nonfinite_fix_kernel<TOut>, dim3((unsigned)p.C), dim3(256), 0, stream, p, nbl, SUMB ? p.C_in * nbl : p.C);
         TFX_HIP(hipGetLastError());
     }
     if (p.ep_stat >= 0) {
