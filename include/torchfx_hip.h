@@ -219,6 +219,13 @@ int tfx_fir_stream_forward(const void *x, void *y, int dtype, int64_t C, int64_t
                            const void *kernel_host, int64_t K, int direct,
                            const void *hist_in, void *hist_out, tfx_stream_t stream);
 
+/* tfx_quantile_abs -- out_dev[0] (DEVICE float64) = the q-quantile (0 <= q <= 1, linear interpolation) of |x| over all n float32
+ * elements: the threshold of PercentileNormalizationStrategy (src/torchfx/effect.py:723-755,
+ * `torch.quantile(torch.abs(waveform), p / 100, interpolation="linear")`) as a three-pass radix SELECT instead of a sort -- same
+ * value as torch.quantile wherever that runs (float32 rank arithmetic and lerp of ATen), no 16 M element limit, no host sync.
+ * Feed out_dev to tfx_normalize_apply (mode 0) for the scaling.  NaN anywhere in x -> NaN. */
+int tfx_quantile_abs(const float *x, int64_t n, double q, double *out_dev, tfx_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * tfx_chunk_forward -- ONE launch for one small streaming chunk: SOS cascade -> stateful direct FIR -> gain / clip.
  * Replaces, for the reference's small-block caller (RealtimeProcessor._audio_callback,

@@ -110,6 +110,11 @@ def fir_stream_forward(x, kernel, hist, direct=False):
     return torch.from_numpy(np.ascontiguousarray(y)), torch.from_numpy(np.ascontiguousarray(xv[:, xv.shape[1] - (k.size - 1):]))
 
 
+def quantile_abs(x, q):
+    calls.append(("quantile_abs", tuple(x.shape)))
+    return torch.quantile(torch.abs(x.reshape(-1)), float(q), interpolation="linear").to(torch.float64).reshape(1)
+
+
 def chunk_supported(C, T, K, taps):
     return C >= 1 and 1 <= T <= 4096 and 0 <= K <= 64 and 1 <= taps <= 4096 and T * taps <= (1 << 22)
 

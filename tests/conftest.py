@@ -65,7 +65,7 @@ def oracle_backend(monkeypatch):
     from torchfx_amd import torchfx_ext
 
     for name in ("sos_forward", "sos_bank_forward", "sos_bank_sum_forward", "biquad_forward", "fir_direct_forward", "fft_conv_forward",
-                 "fir_stream_forward", "chunk_forward", "chunk_supported", "normalize_apply", "sum_forward", "delay_line_forward", "gain_forward", "stat_forward", "normalize_forward"):
+                 "fir_stream_forward", "chunk_forward", "chunk_supported", "quantile_abs", "normalize_apply", "sum_forward", "delay_line_forward", "gain_forward", "stat_forward", "normalize_forward"):
         monkeypatch.setattr(torchfx_ext, name, getattr(_fake_backend, name))
     return _fake_backend
 

@@ -171,3 +171,62 @@ def test_epilogue_statistics_and_golden_mix(golden):
         w = w | m
     assert [type(m).__name__ for m in w.plan()] == ["Epilogued", "FusedSOSCascade"]
     close(w.ys, g["mix_y"], TOL_IIR_F32OUT * 2, "reference mixed pipeline, gain as an epilogue")
+
+
+@pytest.mark.parametrize("n,q", [(1, 0.5), (2, 0.3), (7, 0.99), (1000, 0.97), (4097, 0.5), (100_003, 0.999), (1 << 20, 0.97),
+                                 (3_000_001, 0.25), (16_000_000, 0.99), (5, 1.0), (5, 0.0)])
+def test_quantile_abs_equals_torch_quantile(n, q):
+    """The percentile threshold as a three-pass radix select on the device == torch.quantile(|x|, q, "linear") on the same
+    float32 data (torch's own CPU implementation; same float32 rank arithmetic and lerp), including heavy ties, denormals,
+    zeros and +-inf."""
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g)
+    if n > 100:
+        x[::7] = x[3]                      # ties
+        x[5] = 0.0
+        x[11] = -0.0
+        x[13] = 1e-42                      # denormal
+        x[17] = float("inf")
+        x[19] = -float("inf")
+    ref = torch.quantile(x.abs(), q, interpolation="linear")
+    got = ext().quantile_abs(x.to(DEV), q).cpu()
+    assert got.dtype == torch.float64 and got.shape == (1,)
+    assert float(got) == float(ref), (n, q, float(got), float(ref))
+    # unaligned base pointer and a 2-D view
+    if n > 9:
+        xo = torch.zeros(n + 1, device=DEV)
+        xo[1:] = x.to(DEV)
+        assert float(ext().quantile_abs(xo[1:], q).cpu()) == float(ref)
+
+
+def test_quantile_abs_nan_and_beyond_torch_limit():
+    x = torch.randn(1000)
+    x[123] = float("nan")
+    assert torch.isnan(ext().quantile_abs(x.to(DEV), 0.5).cpu()).all()
+    # 40 M elements: torch.quantile refuses (> 16 M); the select agrees with a sort-based float32 computation done ATen's way
+    n = 40_000_000
+    g = torch.Generator(device=DEV).manual_seed(3)
+    xd = torch.randn(n, device=DEV, generator=g)
+    q = 0.97
+    s = torch.sort(xd.abs()).values
+    ranks = np.float32(q) * np.float32(n - 1)
+    lo, hi = int(np.floor(ranks)), int(np.ceil(ranks))
+    w = np.float32(ranks - np.float32(np.floor(ranks)))
+    a, b = np.float32(s[lo].item()), np.float32(s[hi].item())
+    exp = a + w * (b - a) if w < 0.5 else b - (b - a) * (np.float32(1) - w)
+    assert float(ext().quantile_abs(xd, q).cpu()) == float(np.float32(exp))
+
+
+def test_percentile_strategy_runs_on_the_device_without_torch_quantile(monkeypatch):
+    """PercentileNormalizationStrategy (effect.py:723-755) on a float32 device signal: select + apply pass, equal to the
+    reference formula; an all-zero signal (threshold 0) is returned unchanged; a 3-D batch works."""
+    from torchfx_amd import effect as E
+    x = torch.from_numpy(rnd((3, 50_001), 91))
+    exp = x / torch.quantile(x.abs(), 0.97, interpolation="linear") * 0.8
+    monkeypatch.setattr(torch, "quantile", None)                   # the device path must not need it
+    y = E.Normalize(0.8, E.PercentileNormalizationStrategy(97.0))(x.to(DEV))
+    close(y, exp.numpy(), 1e-6, "percentile normalisation")
+    z = torch.zeros(2, 1000, device=DEV)
+    assert torch.equal(E.PercentileNormalizationStrategy(99.0)(z, 1.0), z)
+    xb = x.reshape(3, 1, -1).to(DEV)
+    close(E.PercentileNormalizationStrategy(97.0)(xb, 0.8), exp.reshape(3, 1, -1).numpy(), 1e-6)

@@ -43,6 +43,7 @@ SIGNATURES = {
     "tfx_fft_conv_forward_ep": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp]),
     "tfx_normalize_apply": (_int, [_vp, _vp, _int, _i64, _i64, _int, _int, _dbl, _vp, _vp]),
     "tfx_fir_stream_forward": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _i64, _int, _vp, _vp, _vp]),
+    "tfx_quantile_abs": (_int, [_vp, _i64, _dbl, _vp, _vp]),
     "tfx_chunk_supported": (_int, [_i64, _i64, _i64, _i64]),
     "tfx_chunk_forward": (_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _dbl, _int, _int, _int, _vp]),
     "tfx_ols_plan_info": (_int, [_i64, _i64, _i64, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64),

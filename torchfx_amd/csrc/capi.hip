@@ -21,6 +21,7 @@ void sos_plan_info(const double *sos_host, int64_t K, int *precision, int64_t *w
 void sos_clear_plans();
 void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
                         const void *kernel_host, int64_t K, hipStream_t stream, const void *hist = nullptr, int64_t H = 0);
+void quantile_abs_forward(const float *x, int64_t n, double q, double *out_dev, hipStream_t stream);
 bool chunk_supported(int64_t C, int64_t T, int64_t K, int64_t Kf);
 void chunk_forward(const float *x, int64_t x_pitch, float *y, int64_t C, int64_t T, const double *sos_host, int64_t K,
                    const double *sx_in, const double *sy_in, double *sx_out, double *sy_out,
@@ -300,6 +301,13 @@ int tfx_fir_stream_forward(const void *x, void *y, int dtype, int64_t C, int64_t
         TFX_CHECK(T == 0 || x, "fir_stream_forward: null signal");
         fir_hist_update(x, hist_in, hist_out, dtype, C, T, H, (hipStream_t)stream);
     }
+    TFX_API_END
+}
+
+int tfx_quantile_abs(const float *x, int64_t n, double q, double *out_dev, tfx_stream_t stream)
+{
+    TFX_API_BEGIN
+    quantile_abs_forward(x, n, q, out_dev, (hipStream_t)stream);
     TFX_API_END
 }
 

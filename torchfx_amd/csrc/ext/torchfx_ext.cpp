@@ -404,6 +404,19 @@ Tensor sum_op(at::TensorList tensors)
     return out;
 }
 
+// q-quantile (linear interpolation) of |x| over all elements, float64 [1] on the device: the percentile threshold as a radix select
+Tensor quantile_abs_op(const Tensor &x, double q)
+{
+    need_device(x, "x");
+    TORCH_CHECK(x.scalar_type() == at::kFloat, "quantile_abs: float32 signals only (got ", x.scalar_type(), ")");
+    TORCH_CHECK(x.numel() >= 1, "quantile_abs: empty input");
+    const Tensor xc = x.contiguous();
+    Tensor out = at::empty({1}, xc.options().dtype(at::kDouble));
+    c10::hip::HIPGuard guard(x.get_device());
+    check_rc(tfx_quantile_abs(xc.data_ptr<float>(), xc.numel(), q, out.data_ptr<double>(), stream_of(x)), "quantile_abs");
+    return out;
+}
+
 Tensor gain_op(const Tensor &x, double gain, bool clamp)
 {
     need_device(x, "x");
@@ -551,6 +564,7 @@ TORCH_LIBRARY(torchfx_hip, m)
     m.def("normalize_apply(Tensor x, Tensor stat, float peak, int mode, bool per_row) -> Tensor");
     m.def("sum_forward(Tensor[] tensors) -> Tensor");
     m.def("gain_forward(Tensor x, float gain, bool clamp) -> Tensor");
+    m.def("quantile_abs(Tensor x, float q) -> Tensor");
     m.def("stat_forward(Tensor x, int mode, bool per_row) -> Tensor");
     m.def("normalize_forward(Tensor x, float peak, int mode, bool per_row) -> Tensor");
     m.def("deinterleave_forward(Tensor frames, float scale=3.0517578125e-05) -> Tensor");
@@ -575,6 +589,7 @@ TORCH_LIBRARY_IMPL(torchfx_hip, CUDA, m)          // "CUDA" is the dispatch key 
     m.impl("normalize_apply", normalize_apply_op);
     m.impl("sum_forward", sum_op);
     m.impl("gain_forward", gain_op);
+    m.impl("quantile_abs", quantile_abs_op);
     m.impl("stat_forward", stat_op);
     m.impl("normalize_forward", normalize_op);
     m.impl("deinterleave_forward", deinterleave_op);
@@ -609,7 +624,7 @@ TORCH_LIBRARY_IMPL(torchfx_hip, CPU, m)
 {
     for (const char *name : {"sos_forward", "sos_forward_sections", "sos_bank_forward", "sos_bank_sum_forward", "biquad_forward",
                              "delay_line_forward", "fir_direct_forward", "fft_conv_forward", "fir_stream_forward", "chunk_forward", "sos_forward_ep",
-                             "fft_conv_forward_ep", "normalize_apply", "sum_forward", "gain_forward", "stat_forward",
+                             "fft_conv_forward_ep", "normalize_apply", "sum_forward", "gain_forward", "quantile_abs", "stat_forward",
                              "normalize_forward", "deinterleave_forward", "deinterleave_into", "interleave_forward"})
         m.impl(name, torch::CppFunction::makeFromBoxedFunction<&no_cpu_boxed>());
 }

@@ -107,15 +107,21 @@ class RMSNormalizationStrategy(NormalizationStrategy):
 
 
 class PercentileNormalizationStrategy(NormalizationStrategy):
-    """``x / P_p(|x|) * peak`` (``effect.py:723-755``).  The percentile is a selection problem, not a
-    streaming pass: it runs as ``torch.quantile`` on the device (with torch's input-size limit, like
-    the reference); only the scaling uses the HIP kernel."""
+    """``x / P_p(|x|) * peak`` (``effect.py:723-755``).  The percentile is a selection problem, not a sort: on float32 device
+    signals it is a three-pass radix select (``torchfx_ext.quantile_abs`` -- the value ``torch.quantile(|x|, p / 100,
+    interpolation="linear")`` returns, without its 16 M element limit), the threshold stays on the device and the scaling is the
+    ``normalize_apply`` pass (unchanged signal when the threshold is not positive, as in the reference).  Other dtypes take
+    ``torch.quantile`` like the reference."""
 
     def __init__(self, percentile: float = 99.0) -> None:
         assert 0 < percentile <= 100, "Percentile must be between 0 and 100."
         self.percentile = percentile
 
     def __call__(self, waveform: Tensor, peak: float) -> Tensor:
+        if waveform.dtype == torch.float32 and waveform.numel() > 0:
+            E = _ext()
+            threshold = E.quantile_abs(waveform, self.percentile / 100)
+            return E.normalize_apply(waveform, threshold, peak, E.STAT_ABSMAX, False)
         threshold = torch.quantile(torch.abs(waveform), self.percentile / 100, interpolation="linear")
         return waveform / threshold * peak if threshold > 0 else waveform
 

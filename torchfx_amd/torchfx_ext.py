@@ -33,7 +33,7 @@ from torchfx_amd import native
 
 __all__ = [
     "biquad_forward", "sos_forward", "sos_bank_forward", "sos_bank_sum_forward", "delay_line_forward",
-    "fir_direct_forward", "fft_conv_forward", "fir_stream_forward", "chunk_forward", "chunk_supported", "normalize_apply", "Epilogue", "sum_forward", "gain_forward", "stat_forward", "normalize_forward",
+    "fir_direct_forward", "fft_conv_forward", "fir_stream_forward", "chunk_forward", "chunk_supported", "normalize_apply", "Epilogue", "sum_forward", "gain_forward", "quantile_abs", "stat_forward", "normalize_forward",
     "deinterleave_forward", "interleave_forward", "sos_plan_info", "ols_plan_info",
 ]
 
@@ -210,6 +210,13 @@ def gain_forward(x: Tensor, gain: float, clamp: bool = False) -> Tensor:
     """``y = x * gain`` (+ clip to [-1, 1]) -- ``Gain.forward``, ``effect.py:361-383``; ``gain`` is the linear
     factor."""
     return native.ops().gain_forward(x, float(gain), bool(clamp))
+
+
+def quantile_abs(x: Tensor, q: float) -> Tensor:
+    """``torch.quantile(torch.abs(x), q, interpolation="linear")`` over all elements of a float32 signal as a three-pass radix
+    select on the device (no sort, no 16 M element limit, no host sync): float64 ``[1]`` on the device, the same value
+    torch.quantile returns wherever it runs; NaN anywhere in ``x`` -> NaN.  Feed it to :func:`normalize_apply`."""
+    return native.ops().quantile_abs(x, float(q))
 
 
 def stat_forward(x: Tensor, mode: int = STAT_ABSMAX, per_row: bool = False) -> Tensor:
