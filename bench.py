@@ -244,10 +244,13 @@ def source_digest() -> str:
     return h.hexdigest()[:16]
 
 
-def timed_region(step, steps: int, warmup: int, sync, lib):
+def timed_region(step, steps: int, warmup: int, sync, lib, profile: bool = True):
     """W untimed steps, then exactly K timed ones.  The previous step's result is dropped BEFORE the next step runs
     (a caller that is done with it): the caching allocator then hands the same 7.4 GB block to every step, so no
-    step of the timed region -- not even the first one after a single warm-up -- contains a fresh hipMalloc."""
+    step of the timed region -- not even the first one after a single warm-up -- contains a fresh hipMalloc.
+    `profile`: record the library's per-kernel HIP events during the timed steps.  The headline region runs WITHOUT them
+    (two event records per launch cost ~1.5 us each, and a cache-sized-slab overlap-save step is ~270 launches: 8.4 ms
+    becomes 9.3 with events); the per-kernel table comes from an identical region with events right after it."""
     out = None
     first_ms = None
     for i in range(warmup):
@@ -260,8 +263,9 @@ def timed_region(step, steps: int, warmup: int, sync, lib):
             sync()
             first_ms = (time.perf_counter() - f0) * 1e3     # the very first call: planning, tables, workspaces
     sync()
-    lib.tfx_prof_enable(1)
-    lib.tfx_prof_collect()
+    if profile:
+        lib.tfx_prof_enable(1)
+        lib.tfx_prof_collect()
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -269,24 +273,25 @@ def timed_region(step, steps: int, warmup: int, sync, lib):
         out = step()
     sync()
     elapsed = time.perf_counter() - t0
-    prof = json.loads(lib.tfx_prof_collect().decode())
-    lib.tfx_prof_enable(0)
+    prof = {}
+    if profile:
+        prof = json.loads(lib.tfx_prof_collect().decode())
+        lib.tfx_prof_enable(0)
     timed_region.first_ms = first_ms
     return elapsed, prof, out
 
 
 def batch_timed(step, sync, lib, batches: int, per_batch: int, warmup: int = 2):
     """Secondary figures (stages, variants): `batches` groups of `per_batch` back-to-back steps, device
-    synchronised around every group; returns (median group time / per_batch in ms, all group values,
-    per-kernel ms per step from the library's HIP events, last output).  The median keeps a one-off
-    allocator stall (a fresh multi-GB hipMalloc inside torch.empty) out of a 5-step figure."""
+    synchronised around every group, no event profiling; returns (median group time / per_batch in ms, all group values,
+    per-kernel ms per step from the library's HIP events -- one extra group, recorded with events after the timed ones --,
+    last output).  The median keeps a one-off allocator stall (a fresh multi-GB hipMalloc inside torch.empty) out of a
+    5-step figure."""
     out = None
     for _ in range(warmup):
         out = None
         out = step()
     sync()
-    lib.tfx_prof_enable(1)
-    lib.tfx_prof_collect()
     groups = []
     for _ in range(batches):
         sync()
@@ -296,9 +301,15 @@ def batch_timed(step, sync, lib, batches: int, per_batch: int, warmup: int = 2):
             out = step()
         sync()
         groups.append((time.perf_counter() - t0) / per_batch * 1e3)
+    lib.tfx_prof_enable(1)
+    lib.tfx_prof_collect()
+    for _ in range(per_batch):
+        out = None
+        out = step()
+    sync()
     prof = json.loads(lib.tfx_prof_collect().decode())
     lib.tfx_prof_enable(0)
-    kern = {k: round(v["total_ms"] / (batches * per_batch), 4) for k, v in prof.items()}
+    kern = {k: round(v["total_ms"] / per_batch, 4) for k, v in prof.items()}
     return float(np.median(groups)), [round(g, 4) for g in groups], kern, out
 
 
@@ -403,7 +414,7 @@ def cfg5_on_one_gpu(dev, sync, lib, total_channels: int = 512, seconds: float = 
         blk.normal_(generator=g)
         blk.mul_(1.0 / float(blk.abs().max()))
     step, desc, _ = make_step("chain", x)
-    elapsed, _, out = timed_region(step, 3, 1, sync, lib)
+    elapsed, _, out = timed_region(step, 3, 1, sync, lib, profile=False)
     ms = elapsed / 3 * 1e3
     del out, x
     torch.cuda.empty_cache()
@@ -477,8 +488,10 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    elapsed, prof, out = timed_region(step, args.steps, args.warmup, sync, lib)
+    elapsed, _, out = timed_region(step, args.steps, args.warmup, sync, lib, profile=False)      # THE timed region: wall clock only
     first_call_ms = timed_region.first_ms
+    out = None
+    elapsed_prof, prof, out = timed_region(step, args.steps, 0, sync, lib, profile=True)       # same steps again, with per-kernel events
     # what the process group itself says about its size (an all-reduce of ones over RCCL / gloo), and which device
     # every rank drives -- WORLD_SIZE is only what the launcher claimed
     from torchfx_amd.distributed import ranks_seen as _ranks_seen
@@ -543,7 +556,8 @@ def main() -> None:
                 sms, sgroups, skern, sout = batch_timed(sstep, sync, lib, 5, 5)
                 n = xs.numel()
                 ent = {"workload": sdesc, "channels": C, "seconds": sec, "ms_per_step": round(sms, 4),
-                       "timing": "median of 5 groups of 5 back-to-back steps, wall clock, device synchronised around each group",
+                       "timing": "median of 5 groups of 5 back-to-back steps, wall clock, device synchronised around each group, no "
+                                 "event profiling; kernel_ms_per_step from one more group with the library's HIP events",
                        "ms_per_step_groups": sgroups,
                        "Msamples_per_s": round(n / sms / 1e3, 1), "bound": bound, "kernel_ms_per_step": skern}
                 if bound == "hbm":
@@ -737,6 +751,9 @@ def main() -> None:
                        "source_digest": source_digest()},
             "roofline": roof,
             "kernels": kernels, "gpu_ms_per_step_sum_of_kernels": round(gpu_ms, 4),
+            "kernels_from": "an identical region of the same steps run right after the timed one WITH the library's per-kernel HIP "
+                            "events (the timed region itself runs without them: two event records per launch)",
+            "ms_per_step_with_event_profiling": round(elapsed_prof / args.steps * 1e3, 4),
             "kernels_note": "timed region: overlap-save passes of different slabs overlap on internal streams, so "
                             "per-kernel times there include contention; kernels_single_stream = same kernels, one stream, untimed pass",
             "kernels_single_stream": kernels_serial,

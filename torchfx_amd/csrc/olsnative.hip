@@ -862,21 +862,22 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     const int64_t npairs = ceil_div(g.nframes, 2);
     if (g.ep_stat >= 0)                   // every (frame, column block) slot is written by exactly one workgroup
         g.ep_partial = (double *)scratch("olsn_ep_partial", (size_t)(g.nframes * (g.N2 / OLS_CB)) * sizeof(double), stream);
-    // Slab = the frame pairs one A / B / C launch triple covers.  Launches of a few thousand workgroups are
-    // dominated by their ramp and tail (64 MB slabs: 12.2 ms for the three passes of cfg 4 on one stream,
-    // 1 GB slabs: 9.8 ms), so slabs are as large as the workspace budget allows (1 GB per lane), but
-    // there are at least two per internal stream so that the passes of different slabs overlap.
-    constexpr int MAXL = 4;
-    int nlanes = (int)envi("TFX_OLS_STREAMS", 3);
+    // Slab = the frame pairs one A / B / C launch triple covers; slabs rotate over `nlanes` internal streams, each with its own
+    // workspace.  Rounds 1-2 sized slabs for launch efficiency (1 GB: few, large launches).  Round 3 measured the other
+    // regime: when the LIVE workspace (slab x lanes) fits the 256 MB Infinity Cache with room for the streaming signal, passes
+    // B and C find the slab pass A / B just wrote in the cache instead of in HBM and the whole step gains 8-11 % despite
+    // the smaller launches -- cfg 4: 9.4-9.5 ms at 3 x 1 GB, 8.4-8.5 ms at 2 x 64 MB; 48 MB x 3 is as good, 4 lanes or
+    // >= 128 MB slabs are not (profiles/r03_experiments.txt).  Default: 64 MB slabs on two lanes.
+    constexpr int MAXL = 8;
+    int nlanes = (int)envi("TFX_OLS_STREAMS", 2);
     if (nlanes < 1) nlanes = 1;
     if (nlanes > MAXL) nlanes = MAXL;
     const int64_t pair_bytes = (int64_t)OLS_N1 * g.P2 * (int64_t)sizeof(cpx);
     int64_t slab = envi("TFX_OLS_PAIRS_PER_SLAB", 0);
     if (slab <= 0) {
         // The workspace lives outside PyTorch's caching allocator and is kept between calls (scratch(), released by
-        // tfx_clear_caches): 1 GB per internal stream by default, but never more than 1/8 of the memory that is free
-        // right now over all lanes, so a process that shares the device with large torch tensors is not pushed into OOM.
-        int64_t slab_mb = envi("TFX_OLS_SLAB_MB", 1024);
+        // tfx_clear_caches); TFX_OLS_SLAB_MB bounds a lane's share, never more than 1/8 of the free memory over all lanes.
+        int64_t slab_mb = envi("TFX_OLS_SLAB_MB", 64);
         {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -884,11 +885,9 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
                 if (slab_mb > cap_mb) slab_mb = std::max<int64_t>(cap_mb, 8);
             }
         }
-        const int64_t hi = std::max<int64_t>(1, (slab_mb << 20) / pair_bytes);
-        const int64_t lo = std::max<int64_t>(1, (envi("TFX_OLS_SLAB_MIN_MB", 64) << 20) / pair_bytes);
-        slab = ceil_div(npairs, 2 * nlanes);
-        if (slab < lo) slab = lo;
-        if (slab > hi) slab = hi;
+        slab = std::max<int64_t>(1, (slab_mb << 20) / pair_bytes);
+        const int64_t per_lane = ceil_div(npairs, nlanes);             // short signals: still one slab per lane
+        if (slab > per_lane) slab = std::max<int64_t>(per_lane, 1);
     }
     if (slab > npairs) slab = npairs;
     cpx *T = (cpx *)scratch("olsn_T", (size_t)slab * (size_t)OLS_N1 * (size_t)g.P2 * sizeof(cpx), stream);
@@ -896,7 +895,8 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     const size_t shm_row = (size_t)(g.N2 * 5) * sizeof(cpx);
     const int probe = (int)envi("TFX_OLS_PROBE", 0);           // development only (tools/ols_knobs.py)
     const int nbf = envi("TFX_OLS_COL_THREADS", 512) == 512 ? 1 : 2;
-    const int rowmap = (int)envi("TFX_OLS_ROWMAP", 1);
+    // XCD-aware row map (1) pays when a slab holds many pairs per spectrum row; with cache-sized slabs the plain map is faster
+    const int rowmap = (int)envi("TFX_OLS_ROWMAP", slab >= 32 ? 1 : 0);
     typedef void (*colf_t)(const float *, cpx *, const cpx *, OlsGeom, int64_t);
     typedef void (*coli_t)(const cpx *, float *, const cpx *, OlsGeom, int64_t);
     typedef void (*row_t)(cpx *, const cpx *, const cpx *, const cpx *, const cpx *, const cpx *, const cpx *, const cpx *,
@@ -932,15 +932,15 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     // Fork/join with events on the caller's stream; each lane has its own workspace.
     if (npairs <= slab) nlanes = 1;
     struct Lanes {                      // internal streams and fork/join events of one device
-        hipStream_t stream[MAXL] = {nullptr, nullptr, nullptr, nullptr};
-        hipEvent_t fork = nullptr, join[MAXL] = {nullptr, nullptr, nullptr, nullptr};
+        hipStream_t stream[MAXL] = {};
+        hipEvent_t fork = nullptr, join[MAXL] = {};
     };
     static Lanes lanes_tab[TFX_MAX_DEVICES];
     Lanes &ln_ = lanes_tab[dev];
     hipStream_t *lane_stream = ln_.stream;
     hipEvent_t &ev_fork = ln_.fork;
     hipEvent_t *ev_join = ln_.join;
-    cpx *Tlane[MAXL] = {T, T, T, T};
+    cpx *Tlane[MAXL] = {T, T, T, T, T, T, T, T};
     hipStream_t user_stream = stream;
     if (nlanes > 1) {
         if (!lane_stream[0]) {
@@ -950,7 +950,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
             }
             TFX_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         }
-        static const char *tags[MAXL] = {"olsn_T", "olsn_T2", "olsn_T3", "olsn_T4"};
+        static const char *tags[MAXL] = {"olsn_T", "olsn_T2", "olsn_T3", "olsn_T4", "olsn_T5", "olsn_T6", "olsn_T7", "olsn_T8"};
         for (int i = 1; i < nlanes; ++i)
             Tlane[i] = (cpx *)scratch(tags[i], (size_t)slab * (size_t)OLS_N1 * (size_t)g.P2 * sizeof(cpx), user_stream);
         TFX_HIP(hipEventRecord(ev_fork, user_stream));
