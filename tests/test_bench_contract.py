@@ -33,4 +33,6 @@ def test_traffic_file_is_consistent():
     # the row pass reads and writes its workspace slab exactly once: the counter corrections reproduce known bytes
     mc = tr["chain"]["model_check"]
     assert abs(mc["measured_write"] / mc["row_pass_slab_GB_per_launch"] - 1) < 0.02
-    assert 1.0 <= mc["measured_read"] / mc["row_pass_slab_GB_per_launch"] < 1.05
+    # ... plus the spectrum rows: once per slab with the XCD-aware row map (1 GB slabs, round 2: < 1.05), once per frame pair with
+    # the plain map that wins for cache-sized slabs (8 MB of spectrum per 8-pair slab and what L2 loses in between: ~1.23)
+    assert 1.0 <= mc["measured_read"] / mc["row_pass_slab_GB_per_launch"] < 1.30

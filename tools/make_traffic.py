@@ -8,7 +8,8 @@ Bytes: FETCH_SIZE and WRITE_SIZE are reported in KiB by rocprofv3.  On gfx950 FE
 128-B request for wide coalesced streams (MI355X_MICROARCH.md, HBM section), so read bytes = 2 x FETCH_SIZE;
 WRITE_SIZE is taken at face value.  Both factors are validated here against bytes that are known by
 construction: the row pass reads and writes its workspace slab exactly once (model_check below).
-The profiled command runs 1 warm-up + 3 timed steps, all of them profiled: per-step = totals / 4."""
+The profiled command runs W warm-up steps, K timed steps and (since round 3) the same K steps once more with the library's
+per-kernel events -- all of them seen by rocprofv3: per-step = totals / (W + 2 K), read from the bench line of the run."""
 import json
 import os
 import re
@@ -16,7 +17,6 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-STEPS = 4
 
 
 def short(name: str) -> str | None:
@@ -43,6 +43,8 @@ def main() -> None:
         if not os.path.exists(p):
             continue
         d = json.load(open(p))
+        under = json.loads(open(os.path.join(src, f"{tag}_{wl}_bench_under_rocprof.json")).read().strip().splitlines()[-1])
+        STEPS = under["warmup"] + (2 if "ms_per_step_with_event_profiling" in under else 1) * under["steps"]
         per = {}
         for tagc, key in (("fetch", "read"), ("write", "write")):
             for r in d.get(tagc, []):
@@ -62,7 +64,6 @@ def main() -> None:
                    "traffic_over_algorithmic": round(total / alg, 3), "per_kernel_GB_per_launch": per}
         row = per.get("ols_row4096_kernel")
         if row:       # the row pass touches its slab exactly once each way: known bytes
-            under = json.loads(open(os.path.join(src, f"{tag}_{wl}_bench_under_rocprof.json")).read().strip().splitlines()[-1])
             ols = under["config"]["overlap_save"]
             frames = 64 * ols["blocks_per_row"]
             slab_gb = ((frames + 1) // 2) * ols["fft_block"] * 8 / row["launches_per_step"] / 1e9
