@@ -718,7 +718,8 @@ def main() -> None:
                     lps = pk.get("launches_per_step")
                     scale = (lps / kernels[dom]["launches_per_step"]) if lps else 1.0   # same bytes, other slab count
                     roof["traffic"] = round((pk["read"] + pk["write"]) * 1e9 * scale)
-                roof["traffic_source"] = f"{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this command)"
+                roof["traffic_source"] = (f"{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of this command): L2-miss "
+                                          "traffic; the overlap-save workspace share of it is served by the Infinity Cache (64 MB slabs), not HBM")
                 roof["traffic_from_this_build"] = tr.get("source_digest") == source_digest()
         except Exception:
             pass
