@@ -26,6 +26,7 @@ the reference (``tests/test_chain_fusion.py:102-121``).
 from __future__ import annotations
 
 import os
+import threading
 import typing as tp
 from collections import OrderedDict
 
@@ -84,12 +85,22 @@ _MERGED: "OrderedDict[tuple, tuple[list, nn.Module]]" = OrderedDict()
 # impulse responses of fresh cascades by SOS content
 _IIR_FIR: "OrderedDict[bytes, nn.Module | None]" = OrderedDict()
 _CACHE_MAX = 32
+_CACHE_LOCK = threading.RLock()          # waves may be materialised from several host threads
+
+
+def _lru_get(cache: OrderedDict, key):
+    with _CACHE_LOCK:
+        hit = cache.get(key)
+        if hit is not None:
+            cache.move_to_end(key)
+        return hit
 
 
 def _lru_put(cache: OrderedDict, key, value) -> None:
-    cache[key] = value
-    while len(cache) > _CACHE_MAX:
-        cache.popitem(last=False)
+    with _CACHE_LOCK:
+        cache[key] = value
+        while len(cache) > _CACHE_MAX:
+            cache.popitem(last=False)
 
 
 def _merge_fir_run(run: list) -> nn.Module:
@@ -98,9 +109,8 @@ def _merge_fir_run(run: list) -> nn.Module:
     another length -- does not convolve again."""
     kernels = [f.kernel for f in run]
     key = tuple((id(k), k._version) for k in kernels)
-    hit = _MERGED.get(key)
+    hit = _lru_get(_MERGED, key)
     if hit is not None:
-        _MERGED.move_to_end(key)
         return hit[1]
     taps = None
     for k in kernels:
@@ -121,9 +131,10 @@ def _iir_as_fir(sos_t: Tensor, max_taps: int = 1 << 17) -> nn.Module | None:
 
     sos = np.ascontiguousarray(sos_t.detach().cpu().numpy(), dtype=np.float64)
     key = sos.tobytes()
-    if key in _IIR_FIR:
-        _IIR_FIR.move_to_end(key)
-        return _IIR_FIR[key]
+    with _CACHE_LOCK:
+        if key in _IIR_FIR:
+            _IIR_FIR.move_to_end(key)
+            return _IIR_FIR[key]
     w = torchfx_ext.sos_plan_info(sos)["warmup"]
     fir = None
     if 0 <= w <= max_taps:
@@ -150,9 +161,10 @@ _PLANS: "OrderedDict[tuple, tuple[list, list]]" = OrderedDict()
 
 
 def plan_cache_clear() -> None:
-    _PLANS.clear()
-    _MERGED.clear()
-    _IIR_FIR.clear()
+    with _CACHE_LOCK:
+        _PLANS.clear()
+        _MERGED.clear()
+        _IIR_FIR.clear()
 
 
 def _member_key(m: nn.Module, guard: list) -> tuple:
@@ -234,9 +246,8 @@ class Wave:
         length = int(self._ys.shape[-1]) if self._ys.dim() else 0
         guard: list = []
         key = (tuple(_member_key(m, guard) for m in self._pipeline), flags, length)
-        hit = _PLANS.get(key)
+        hit = _lru_get(_PLANS, key)
         if hit is not None:
-            _PLANS.move_to_end(key)
             return _instantiate(hit[1])
         built = self._build_plan(length)
         _lru_put(_PLANS, key, (guard, built))
