@@ -5,6 +5,7 @@
 //   pipe      software pipeline: the loads of tile i+1 are issued BEFORE the stores of tile i (two register sets)
 //   interleave  stream s walks tiles s, s + S, s + 2 S, ... (the address order of a linear sweep, persistent waves): what a
 //             look-back formulation of the recurrence would produce
+//   shared    G = 4 / 16 waves share one segment (wave w takes tiles w, w + G, ...): what a workgroup-level scan would read
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -28,6 +29,23 @@ __global__ void __launch_bounds__(256) streams_k(const float4 *__restrict__ x, f
             for (int u = 0; u < NU; ++u) v[u] = (o + u * 64 < n4) ? x[o + u * 64] : make_float4(0, 0, 0, 0);
 #pragma unroll
             for (int u = 0; u < NU; ++u) if (o + u * 64 < n4) y[o + u * 64] = scale(v[u]);
+        }
+        return;
+    }
+    if (MODE == 4 || MODE == 5) {
+        // a GROUP of G waves (4 = one workgroup, 5: 16 = four workgroups in a row) shares one segment: wave w takes tiles w, w + G, ...
+        // of it -- what a workgroup-level scan (lanes x waves) would read: G x fewer address streams, G x longer bursts
+        const size_t G = MODE == 4 ? 4 : 16;
+        const size_t grp = sid / G, w = sid % G;
+        const size_t gseg4 = seg4 * G;
+        const size_t gb = grp * gseg4, ge = (gb + gseg4 < n4) ? gb + gseg4 : n4;
+        for (size_t t = gb + w * TILE4; t < ge; t += G * TILE4) {
+            const size_t o = t + lane;
+            float4 v[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) { floatx4 q = (o + u * 64 < ge) ? __builtin_nontemporal_load((const floatx4 *)(x + o + u * 64)) : (floatx4){0, 0, 0, 0}; v[u] = make_float4(q.x, q.y, q.z, q.w); }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) if (o + u * 64 < ge) { const float4 r = scale(v[u]); __builtin_nontemporal_store((floatx4){r.x, r.y, r.z, r.w}, (floatx4 *)(y + o + u * 64)); }
         }
         return;
     }
@@ -99,7 +117,7 @@ int main()
             char nm[96];
 #define RUN(NU, MODE, label) snprintf(nm, sizeof nm, "%d streams, %d KB tiles, %s", nstreams, NU, label); \
             run([&] { hipLaunchKernelGGL((streams_k<NU, MODE>), dim3((nstreams + 3) / 4), dim3(256), 0, 0, x, y, seg4, n4, nstreams); }, nm);
-            RUN(8, 0, "burst") RUN(8, 1, "nontemporal") RUN(8, 2, "pipelined") RUN(8, 3, "tile-interleaved")
+            RUN(8, 0, "burst") RUN(8, 1, "nontemporal") RUN(8, 2, "pipelined") RUN(8, 3, "tile-interleaved") RUN(8, 4, "nt, 4 waves share a segment") RUN(8, 5, "nt, 16 waves share a segment") RUN(4, 4, "nt, 4 waves share a segment") RUN(4, 5, "nt, 16 waves share a segment")
             RUN(2, 0, "burst") RUN(2, 1, "nontemporal") RUN(2, 3, "tile-interleaved")
             RUN(16, 1, "nontemporal") RUN(16, 3, "tile-interleaved")
         }
