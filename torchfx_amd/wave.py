@@ -114,7 +114,8 @@ def _merge_fir_run(run: list) -> nn.Module:
         return hit[1]
     taps = None
     for k in kernels:
-        b = k.detach().cpu().reshape(-1).flip(0).to(torch.float64).numpy()
+        # numpy, not torch: a flip + cast of 65 536 values through torch's CPU kernels costs 10-30 ms a piece (intra-op thread pool)
+        b = np.ascontiguousarray(k.detach().cpu().reshape(-1).numpy()[::-1], dtype=np.float64)
         taps = b if taps is None else _convolve64(taps, b)
     merged = _planner_fir(taps[::-1])
     _lru_put(_MERGED, key, (kernels, merged))
