@@ -230,3 +230,29 @@ def test_percentile_strategy_runs_on_the_device_without_torch_quantile(monkeypat
     assert torch.equal(E.PercentileNormalizationStrategy(99.0)(z, 1.0), z)
     xb = x.reshape(3, 1, -1).to(DEV)
     close(E.PercentileNormalizationStrategy(97.0)(xb, 0.8), exp.reshape(3, 1, -1).numpy(), 1e-6)
+
+
+def test_percentile_normalisation_is_hip_graph_capturable():
+    """The selection is stream-ordered device work only (an init launch, three histogram + pick pairs, the apply pass): it can be
+    captured into a HIP graph and replayed on new samples; no host-to-device copy, no host synchronisation."""
+    from torchfx_amd import effect as E
+    strat = E.PercentileNormalizationStrategy(97.0)
+    static_x = dev(rnd((4, 200_000), 5))
+    for _ in range(2):
+        strat(static_x, 0.8)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        strat(static_x, 0.8)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        out = strat(static_x, 0.8)
+    for seed in (6, 7):
+        x2 = torch.from_numpy(rnd((4, 200_000), seed))
+        static_x.copy_(x2.to(DEV))
+        graph.replay()
+        torch.cuda.synchronize()
+        exp = x2 / torch.quantile(x2.abs(), 0.97, interpolation="linear") * 0.8
+        close(out, exp.numpy(), 1e-6, f"replay {seed}")

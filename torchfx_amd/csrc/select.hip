@@ -9,6 +9,7 @@
 // selected in the same passes (two histograms per level).  Rank arithmetic and the interpolation are done in float32 exactly
 // as ATen does them (quantile_compute: ranks = q * (n - 1) in the input dtype, lerp(below, above, ranks - floor(ranks))), so
 // the result equals torch.quantile's wherever torch.quantile runs.  NaN anywhere -> NaN, like torch.
+#include <cstddef>
 #include "common.h"
 #include "../../include/torchfx_hip.h"
 
@@ -86,6 +87,20 @@ __global__ void __launch_bounds__(256) select_hist_kernel(const float *__restric
     if (LEVEL == 1 && tid == 0 && lnan) atomicAdd(&st->nan_count, (unsigned long long)lnan);
 }
 
+// Clears the histograms and sets the two wanted ranks: a launch instead of memset + a host-to-device copy of a stack variable,
+// so that the whole selection is stream-ordered, never blocks the host and can be captured into a HIP graph
+__global__ void __launch_bounds__(256) select_init_kernel(SelState *st, unsigned long long rank0, unsigned long long rank1)
+{
+    unsigned long long *w = (unsigned long long *)st;
+    constexpr int NW = (int)(offsetof(SelState, nan_count) / sizeof(unsigned long long));
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < NW; i += gridDim.x * 256) w[i] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        st->nan_count = 0;
+        st->rank[0] = rank0; st->rank[1] = rank1;
+        st->prefix[0] = st->prefix[1] = 0;
+    }
+}
+
 // One workgroup: for each of the two order statistics find the bin of this level that holds its remaining rank, append the
 // bin to its prefix and reduce the rank.  After level 3 the prefixes are the full 31-bit keys: interpolate and write the result.
 template <int LEVEL>
@@ -146,9 +161,7 @@ void quantile_abs_forward(const float *x, int64_t n, double q, double *out_dev, 
     float below = floorf(ranks), above = ceilf(ranks);
     const float weight = ranks - below;
     auto clampi = [&](float v) { int64_t r = (int64_t)v; return r < 0 ? (int64_t)0 : (r > n - 1 ? n - 1 : r); };
-    struct Init { unsigned long long nan_count, rank[2]; unsigned prefix[2]; } init = {0, {(unsigned long long)clampi(below), (unsigned long long)clampi(above)}, {0, 0}};
-    TFX_HIP(hipMemsetAsync(st, 0, offsetof(SelState, nan_count), stream));
-    TFX_HIP(hipMemcpyAsync((char *)st + offsetof(SelState, nan_count), &init, sizeof(init), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(select_init_kernel, dim3(16), dim3(256), 0, stream, st, (unsigned long long)clampi(below), (unsigned long long)clampi(above));
     const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(n, 256 * 16), 256 * 8);
     ProfScope ps("select_hist_kernel", stream);
     hipLaunchKernelGGL(select_hist_kernel<1>, dim3(grid), dim3(256), 0, stream, x, n, st);
