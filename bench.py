@@ -281,7 +281,7 @@ def timed_region(step, steps: int, warmup: int, sync, lib, profile: bool = True)
     return elapsed, prof, out
 
 
-def batch_timed(step, sync, lib, batches: int, per_batch: int, warmup: int = 2):
+def batch_timed(step, sync, lib, batches: int, per_batch: int, warmup: int = 2, min_group_ms: float = 20.0):
     """Secondary figures (stages, variants): `batches` groups of `per_batch` back-to-back steps, device
     synchronised around every group, no event profiling; returns (median group time / per_batch in ms, all group values,
     per-kernel ms per step from the library's HIP events -- one extra group, recorded with events after the timed ones --,
@@ -292,6 +292,14 @@ def batch_timed(step, sync, lib, batches: int, per_batch: int, warmup: int = 2):
         out = None
         out = step()
     sync()
+    # sub-millisecond steps: a 5-step group is mostly the synchronisation around it and the clock ramp after the idle gap;
+    # make every group last >= min_group_ms of back-to-back steps (the per-step figure is still group time / steps)
+    t0 = time.perf_counter()
+    out = None
+    out = step()
+    sync()
+    est_ms = (time.perf_counter() - t0) * 1e3
+    per_batch = max(per_batch, min(200, int(np.ceil(min_group_ms / max(est_ms, 1e-3)))))
     groups = []
     for _ in range(batches):
         sync()
@@ -310,6 +318,7 @@ def batch_timed(step, sync, lib, batches: int, per_batch: int, warmup: int = 2):
     prof = json.loads(lib.tfx_prof_collect().decode())
     lib.tfx_prof_enable(0)
     kern = {k: round(v["total_ms"] / per_batch, 4) for k, v in prof.items()}
+    batch_timed.per_batch = per_batch
     return float(np.median(groups)), [round(g, 4) for g in groups], kern, out
 
 
@@ -556,8 +565,9 @@ def main() -> None:
                 sms, sgroups, skern, sout = batch_timed(sstep, sync, lib, 5, 5)
                 n = xs.numel()
                 ent = {"workload": sdesc, "channels": C, "seconds": sec, "ms_per_step": round(sms, 4),
-                       "timing": "median of 5 groups of 5 back-to-back steps, wall clock, device synchronised around each group, no "
-                                 "event profiling; kernel_ms_per_step from one more group with the library's HIP events",
+                       "timing": f"median of 5 groups of {batch_timed.per_batch} back-to-back steps (>= 20 ms per group), wall clock, device "
+                                 "synchronised around each group, no event profiling; kernel_ms_per_step from one more group with "
+                                 "the library's HIP events",
                        "ms_per_step_groups": sgroups,
                        "Msamples_per_s": round(n / sms / 1e3, 1), "bound": bound, "kernel_ms_per_step": skern}
                 if bound == "hbm":
