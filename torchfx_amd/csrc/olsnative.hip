@@ -23,7 +23,7 @@
 //     radix 4 for N2 = 256; layouts are chosen so all LDS accesses of the column passes are
 //     conflict-free ([row][col] with the column on the lane index).
 //   * frames start on 128-byte lines (zero taps prepended to the flipped kernel, hop rounded to 32),
-//     slabs of frame pairs (up to 1 GB of workspace each) rotate over three internal streams.
+//     slabs of frame pairs (64 MB of workspace each: the live workspace stays in the Infinity Cache) rotate over two internal streams.
 //
 // Semantics = fft_conv1d (src/torchfx/filter/_fftconv.py:70-141): causal correlation with the
 // stored flipped kernel, output length T + l + r - K + 1.
@@ -949,7 +949,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
         attr = true;
     }
     const int ncb = g.N2 / OLS_CB;
-    // Internal streams (TFX_OLS_STREAMS, default 3), slabs rotate over them: while one slab drains the tail of a pass
+    // Internal streams (TFX_OLS_STREAMS, default 2), slabs rotate over them: while one slab drains the tail of a pass
     // (the last, partially filled round of workgroups) the other slab's pass fills the idle CUs.
     // Fork/join with events on the caller's stream; each lane has its own workspace.
     if (npairs <= slab) nlanes = 1;
