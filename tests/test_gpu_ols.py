@@ -120,3 +120,78 @@ def test_fft_conv_kernel_longer_than_the_native_limit():
     y = ext().fft_conv_forward(dev(x), kf, (K - 1, 0))
     exp = fftconvolve(np.pad(x.astype(np.float64), ((0, 0), (K - 1, 0))), kf[::-1].astype(np.float64)[None], mode="valid", axes=-1)
     close(y, exp.astype(np.float32), TOL_CONV_F32, "600k taps")
+
+
+# ---- one launch, transform in LDS (olslds.hip): K <= 2048, float32 and float64, rows of any length ----------
+def _f64_corr(x, kf, pl, pr):
+    from scipy.signal import fftconvolve
+    xp = np.pad(x.astype(np.float64), ((0, 0), (pl, pr)))
+    return fftconvolve(xp, kf[::-1].astype(np.float64)[None], mode="valid", axes=-1)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("C,T,K", [(2, 44100, 5), (2, 44100, 32), (2, 44100, 256), (2, 44100, 1024), (1, 3073, 1024),
+                                   (3, 1000, 64), (1, 1, 1), (2, 7, 3), (5, 100_003, 2048), (4, 65_536, 1024),
+                                   (64, 30_000, 1000), (1, 6146, 1024), (3, 12_288, 1025), (7, 9_217, 2047)])
+def test_lds_ols_reference_shapes_vs_float64(C, T, K, dtype):
+    """The reference's own test shapes for FFT-mode FIR and fft_conv1d (tests/test_fir.py:79-90,
+    tests/test_fftconv.py:64-122: [2, 44100], K = 5 ... 1024) run on the single-launch LDS kernel -- not rocFFT --
+    in float32 and float64, odd frame counts (an unpaired last frame), rows shorter than one block, T < K."""
+    info = ext().ols_plan_info(K, T, (K - 1, 0), torch.float32 if dtype == np.float32 else torch.float64)
+    assert info["path"] == "lds" and info["N"] == 4096
+    rng = np.random.default_rng(K * 7 + T)
+    kf = (rng.standard_normal(K) / np.sqrt(K)).astype(np.float32).astype(dtype)      # taps are float32 values (fir.py:516)
+    x = rnd((C, T), T + K, dtype)
+    y = ext().fft_conv_forward(dev(x), kf, (K - 1, 0))
+    assert y.dtype == (torch.float32 if dtype == np.float32 else torch.float64)
+    close(y, _f64_corr(x, kf, K - 1, 0).astype(dtype), 4e-6 if dtype == np.float32 else TOL_CONV_F64, f"C={C} T={T} K={K}")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_lds_ols_padding_alignment_and_env_switch(dtype, monkeypatch):
+    """Every padding flavour (aligned rows take `lead` zero taps and a hop of whole cache lines, unaligned ones do not),
+    and the LDS kernel against the other two paths on the same input."""
+    K = 1000
+    kf = rnd((K,), 3, dtype)
+    for T in (150_016, 150_001):
+        x = rnd((3, T), T, dtype)
+        for pad in ((0, 0), (K - 1, 0), (100, 77), (0, K), (999 + 33, 0)):
+            y = ext().fft_conv_forward(dev(x), kf, pad)
+            close(y, _f64_corr(x, kf, *pad).astype(dtype), 1e-5 if dtype == np.float32 else TOL_CONV_F64, f"T={T} pad={pad}")
+    x = rnd((3, 150_016), 9, dtype)
+    y = ext().fft_conv_forward(dev(x), kf, (K - 1, 0))
+    monkeypatch.setenv("TFX_OLS_LDS", "0")
+    assert ext().ols_plan_info(K, 150_016, (K - 1, 0))["path"] == "passes"
+    y2 = ext().fft_conv_forward(dev(x), kf, (K - 1, 0))
+    monkeypatch.setenv("TFX_OLS_NATIVE", "0")
+    assert ext().ols_plan_info(K, 150_016, (K - 1, 0))["path"] == "rocfft"
+    y3 = ext().fft_conv_forward(dev(x), kf, (K - 1, 0))
+    tol = 4e-6 if dtype == np.float32 else 1e-12
+    close(y, y2.cpu().numpy(), tol, "lds vs three passes / rocFFT (f64)")
+    close(y, y3.cpu().numpy(), tol, "lds vs rocFFT")
+    if dtype == np.float32:
+        assert not torch.equal(y, y3)            # a different kernel really ran
+
+
+def test_lds_ols_plan_info_paths():
+    e = ext()
+    assert e.ols_plan_info(1024, 2_880_000, (1023, 0))["path"] == "lds"
+    assert e.ols_plan_info(2048, 2_880_000, (2047, 0), torch.float64)["path"] == "lds"
+    assert e.ols_plan_info(2049, 2_880_000, (2048, 0))["path"] == "passes"
+    assert e.ols_plan_info(2049, 2_880_000, (2048, 0), torch.float64)["path"] == "rocfft"
+    i = e.ols_plan_info(1024, 2_880_000, (1023, 0))
+    assert i["S"] == 3072 and i["F"] == 938 and abs(i["bytes_per_sample"] - (4 * 4096 / 3072 + 4)) < 1e-9
+    i = e.ols_plan_info(1024, 2_880_001, (1023, 0))                      # unaligned rows: no lead, odd hop
+    assert i["S"] == 4096 - 1024 + 1
+
+
+def test_lds_ols_many_rows_full_config():
+    """cfg-3's shape through the FFT mode (64 x 2.88 M, 1024 taps): channels {0, 31, 63} against float64."""
+    from scipy.signal import firwin
+    k = firwin(1024, 5000, fs=48000).astype(np.float32)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.rand(64, 2_880_000, generator=g, device=DEV) * 2 - 1
+    y = ext().fft_conv_forward(x, k[::-1].copy(), (1023, 0))
+    for c in (0, 31, 63):
+        xc = x[c].cpu().numpy()
+        close(y[c:c + 1], _f64_corr(xc[None], k[::-1].copy(), 1023, 0).astype(np.float32), 2e-6, f"row {c}")

@@ -64,6 +64,24 @@ def main():
         wall, prof = timed(lambda: E.fft_conv_forward(x, k, (1023, 0)), reps=3, warm=1)
         print(f"fir fft 1024: wall {wall:.3f} ms  {C * T / wall / 1e3:.1f} Msamp/s", prof, flush=True)
         del x
+    if "lds" in which:
+        from scipy.signal import firwin as fw
+        C, T = 64, 2_880_000
+        x = torch.randn(C, T, device=dev)
+        for K in (64, 256, 1024, 2048):
+            k = fw(K, 5000, fs=48000).astype(np.float32)[::-1].copy()
+            for lds in ("1", "0"):
+                os.environ["TFX_OLS_LDS"] = lds
+                wall, prof = timed(lambda: E.fft_conv_forward(x, k, (K - 1, 0)), reps=20, warm=3)
+                tot = sum(prof.values())
+                print(f"fir fft K={K:5d} lds={lds}: wall {wall:7.3f} ms kernels {tot:7.3f} ms {8 * C * T / wall / 1e9:5.2f} TB/s "
+                      f"({8 * C * T / wall / 1e9 / 8 * 100:5.1f}% of 8 TB/s) " + " ".join(f"{n.replace('_kernel', '')}={v:.3f}" for n, v in prof.items()), flush=True)
+        os.environ["TFX_OLS_LDS"] = "1"
+        xd = x.double()[:32]
+        k = fw(1024, 5000, fs=48000).astype(np.float32).astype(np.float64)[::-1].copy()
+        wall, prof = timed(lambda: E.fft_conv_forward(xd, k, (1023, 0)), reps=10, warm=2)
+        print(f"fir fft K=1024 float64 32 rows: wall {wall:7.3f} ms {16 * 32 * T / wall / 1e9:5.2f} TB/s of 16 B/sample", prof, flush=True)
+        del x, xd
     if "efx" in which:
         C, T = 64, 28_800_000
         x = torch.randn(C, T, device=dev)

@@ -38,6 +38,9 @@ void normalize_apply_forward(const void *x, void *y, int dtype, int64_t C, int64
 void fftconv_clear();
 void olsnative_clear();
 bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out);
+void olslds_clear();
+bool olslds_supported(int64_t K, int64_t *N_out);
+void olslds_geometry(int64_t K, int64_t Tn, int64_t pl, int64_t pr, int elem_bytes, int64_t *lead_out, int64_t *S_out);
 // effects.hip
 void gain_forward(const void *x, void *y, int dtype, int64_t n, double gain, int clamp, hipStream_t stream);
 void stat_forward(const void *x, int dtype, int64_t C, int64_t T, int mode, int per_row, double *out_dev, hipStream_t stream);
@@ -324,21 +327,25 @@ int tfx_chunk_forward(const float *x, int64_t x_pitch, float *y, int64_t C, int6
     TFX_API_END
 }
 
-int tfx_ols_plan_info(int64_t K, int64_t T, int64_t pad_left, int64_t pad_right, int64_t *N, int64_t *S,
-                      int64_t *F, int *native)
+static void ols_plan(int64_t K, int64_t T, int64_t pad_left, int64_t pad_right, int dtype, int64_t *N, int64_t *S,
+                     int64_t *F, int *path)
 {
-    TFX_API_BEGIN
     const int64_t L = T + pad_left + pad_right;
     TFX_CHECK(K >= 1 && L >= K, "ols_plan_info: kernel size %lld larger than the padded signal %lld", (long long)K, (long long)L);
-    int64_t n = 0;
-    const bool nat = olsnative_supported(K, L, &n);
-    int64_t hop;
-    if (nat) {
+    TFX_CHECK(dtype == TFX_F32 || dtype == TFX_F64, "ols_plan_info: bad dtype %d", dtype);
+    int64_t n = 0, hop = 0;
+    int p = 0;
+    if (olslds_supported(K, &n)) {
+        int64_t lead = 0;
+        olslds_geometry(K, T, pad_left, pad_right, dtype == TFX_F32 ? 4 : 8, &lead, &hop);
+        p = 2;
+    } else if (dtype == TFX_F32 && olsnative_supported(K, L, &n)) {
         const int64_t tout = L - K + 1;
         const bool align = (T % 32 == 0) && (tout % 32 == 0);
         const int64_t lead = align ? (32 - (pad_left % 32)) % 32 : 0;
         hop = n - (K + lead) + 1;
         if (align && hop > 64) hop -= hop % 32;
+        p = 1;
     } else {
         n = fftconv_block_size(K, L);
         hop = n - K + 1;
@@ -346,7 +353,24 @@ int tfx_ols_plan_info(int64_t K, int64_t T, int64_t pad_left, int64_t pad_right,
     if (N) *N = n;
     if (S) *S = hop;
     if (F) *F = ceil_div(L - K + 1, hop);
-    if (native) *native = nat ? 1 : 0;
+    if (path) *path = p;
+}
+
+int tfx_ols_plan_info(int64_t K, int64_t T, int64_t pad_left, int64_t pad_right, int64_t *N, int64_t *S,
+                      int64_t *F, int *native)
+{
+    TFX_API_BEGIN
+    int path = 0;
+    ols_plan(K, T, pad_left, pad_right, TFX_F32, N, S, F, &path);
+    if (native) *native = path != 0;
+    TFX_API_END
+}
+
+int tfx_ols_plan_info2(int64_t K, int64_t T, int64_t pad_left, int64_t pad_right, int dtype, int64_t *N, int64_t *S,
+                       int64_t *F, int *path)
+{
+    TFX_API_BEGIN
+    ols_plan(K, T, pad_left, pad_right, dtype, N, S, F, path);
     TFX_API_END
 }
 
@@ -453,6 +477,7 @@ int tfx_clear_caches(void)
     fir_clear();
     fftconv_clear();
     olsnative_clear();
+    olslds_clear();
     scratch_clear();
     TFX_API_END
 }

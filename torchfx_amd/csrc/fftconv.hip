@@ -30,6 +30,11 @@ bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out);
 void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const float *kf_host, int64_t K,
                        int64_t pl, int64_t pr, int64_t N, hipStream_t stream, const float *hist, int64_t H, const Epilogue *ep);
 
+// olslds.hip: one launch, the whole 4096-point transform in LDS (K <= 2048 taps, float32 and float64, rows of any length)
+bool olslds_supported(int64_t K, int64_t *N_out);
+void olslds_forward(const void *x, void *y, int dtype, int64_t C, int64_t Tn, const void *kf_host, int64_t K,
+                    int64_t pl, int64_t pr, hipStream_t stream, const void *hist, int64_t H, const Epilogue *ep);
+
 #define TFX_ROCFFT(expr)                                                                     \
     do {                                                                                     \
         rocfft_status _s = (expr);                                                           \
@@ -327,6 +332,11 @@ void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, c
     TFX_CHECK(C > 0 && T >= 0, "fft_conv_forward: negative size");
     TFX_CHECK(y && kernel_host && (x || T == 0), "fft_conv_forward: null pointer");
     int64_t Nn = 0;
+    if (olslds_supported(K, &Nn)) {
+        // kernels that fit on chip: no workspace, epilogue in the store of the inverse transform
+        olslds_forward(x, y, dtype, C, T, kernel_host, K, pad_left, pad_right, stream, hist, H, (ep && ep->any()) ? ep : nullptr);
+        return;
+    }
     if (dtype == TFX_F32 && olsnative_supported(K, L, &Nn)) {
         // the LDS-resident path applies the epilogue in its last pass (the store of the inverse column FFT)
         olsnative_forward((const float *)x, (float *)y, C, T, (const float *)kernel_host, K, pad_left, pad_right, Nn, stream,

@@ -729,6 +729,8 @@ static void host_fft(std::vector<double> &re, std::vector<double> &im)
     }
 }
 
+void host_fft_f64(std::vector<double> &re, std::vector<double> &im) { host_fft(re, im); }     // olslds.hip's spectra
+
 static cpx *upload_cpx(const std::vector<cpx> &h)
 {
     cpx *d = nullptr;

@@ -263,10 +263,16 @@ def sos_plan_info(sos) -> dict:
             "warmup": warm.value, "f32_error_bound": eb.value}
 
 
-def ols_plan_info(K: int, T: int, padding: tuple[int, int] = (0, 0)) -> dict:
-    """Block geometry of the overlap-save op (FFT length N, hop S, blocks per row F, native path?)."""
+def ols_plan_info(K: int, T: int, padding: tuple[int, int] = (0, 0), dtype: torch.dtype = torch.float32) -> dict:
+    """Block geometry of the overlap-save op for a signal of `dtype` (FFT length N, hop S, blocks per row F) and the
+    path that runs: "lds" (one launch, 4096-point transform in LDS), "passes" (three-pass four-step pipeline) or
+    "rocfft"; `native` = a hand-written path; `bytes_per_sample` = modelled HBM traffic per output sample."""
     lib = L.load()
-    n, s_, f, nat = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int(0)
-    L.check(lib.tfx_ols_plan_info(int(K), int(T), int(padding[0]), int(padding[1]), ctypes.byref(n),
-                                  ctypes.byref(s_), ctypes.byref(f), ctypes.byref(nat)))
-    return {"N": n.value, "S": s_.value, "F": f.value, "native": bool(nat.value)}
+    n, s_, f, path = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int(0)
+    code = L.TFX_F64 if dtype == torch.float64 else L.TFX_F32
+    L.check(lib.tfx_ols_plan_info2(int(K), int(T), int(padding[0]), int(padding[1]), code, ctypes.byref(n),
+                                   ctypes.byref(s_), ctypes.byref(f), ctypes.byref(path)))
+    esz = 8 if dtype == torch.float64 else 4
+    bps = {2: esz * n.value / s_.value + esz, 1: 20.0 * n.value / s_.value + 4.0, 0: 95.0 * esz / 4}[path.value]
+    return {"N": n.value, "S": s_.value, "F": f.value, "native": path.value != 0,
+            "path": ("rocfft", "passes", "lds")[path.value], "bytes_per_sample": bps}
