@@ -155,6 +155,160 @@ __device__ __forceinline__ void fft4096(cx<R> (&v)[16], cx<R> *lds, const cx<R> 
     for (int k = 0; k < 16; ++k) v[k] = o[k];
 }
 
+// ---- float32: the same transform in packed arithmetic -------------------------------------------------------------
+// A complex number is one aligned VGPR pair, and gfx950's v_pk_{add,mul,fma}_f32 take per-source half selectors
+// (op_sel / op_sel_hi) and per-half negation: a +- i b is ONE instruction, a complex product two -- the compiler never
+// emits those forms (it builds swapped pairs with v_mov / v_xor first: PMC round 4, 1206 vector instructions per wave
+// and pair, the kernel 69 % VALU-bound), so the butterflies are written with single-instruction asm statements the
+// scheduler is free to place.  A 16-point DFT is 80 instructions instead of ~160.
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v2f pk_add_ib(v2f a, v2f b)            // a + i b
+{
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ v2f pk_sub_ib(v2f a, v2f b)            // a - i b
+{
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// a * w (CONJ = false) or a * conj(w)
+template <bool CONJ> __device__ __forceinline__ v2f pk_cmul(v2f a, v2f w)
+{
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));          // (a.x w.x, a.y w.x)
+    if (CONJ) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    else      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// x * (c - i s) forward, x * (c + i s) inverse, with c = (-1)^NEGC W[SELC], s = (-1)^NEGS W[SELS] picked from one constant pair
+template <int SELC, int NEGC, int SELS, int NEGS, bool INV>
+__device__ __forceinline__ v2f pk_twc(v2f x, v2f W)
+{
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,%3] op_sel_hi:[1,%3] neg_lo:[0,%4] neg_hi:[0,%4]" : "=v"(t) : "v"(x), "v"(W), "n"(SELC), "n"(NEGC));
+    if (!INV) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,%4,0] op_sel_hi:[0,%4,1] neg_lo:[0,%5,0] neg_hi:[1,%5,0]"
+                  : "=v"(r) : "v"(x), "v"(W), "v"(t), "n"(SELS), "n"(NEGS));
+    else      asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,%4,0] op_sel_hi:[0,%4,1] neg_lo:[1,%5,0] neg_hi:[0,%5,0]"
+                  : "=v"(r) : "v"(x), "v"(W), "v"(t), "n"(SELS), "n"(NEGS));
+    return r;
+}
+// 4-point DFT; ROT2: a2 stands for (-i) a2 forward / (+i) a2 inverse (a twiddle of the 16-point DFT folded in)
+template <bool INV, bool ROT2>
+__device__ __forceinline__ void pk_dft4(v2f &a0, v2f &a1, v2f &a2, v2f &a3)
+{
+    v2f s02, d02;
+    if (!ROT2) { s02 = a0 + a2; d02 = a0 - a2; }
+    else if (!INV) { s02 = pk_sub_ib(a0, a2); d02 = pk_add_ib(a0, a2); }
+    else { s02 = pk_add_ib(a0, a2); d02 = pk_sub_ib(a0, a2); }
+    const v2f s13 = a1 + a3, d13 = a1 - a3;
+    a0 = s02 + s13;
+    a2 = s02 - s13;
+    a1 = INV ? pk_add_ib(d02, d13) : pk_sub_ib(d02, d13);
+    a3 = INV ? pk_sub_ib(d02, d13) : pk_add_ib(d02, d13);
+}
+// 16-point DFT, same index conventions as dft16<>: Wc = (cos pi/8, sin pi/8), Wr = (sqrt 1/2, sqrt 1/2)
+template <bool INV>
+__device__ __forceinline__ void pk_dft16(v2f (&v)[16], v2f Wc, v2f Wr)
+{
+#pragma unroll
+    for (int t1 = 0; t1 < 4; ++t1) pk_dft4<INV, false>(v[t1], v[t1 + 4], v[t1 + 8], v[t1 + 12]);
+    v[1 + 4] = pk_twc<0, 0, 1, 0, INV>(v[1 + 4], Wc);      // (C1, S1)
+    v[1 + 8] = pk_twc<0, 0, 0, 0, INV>(v[1 + 8], Wr);      // (R2, R2)
+    v[1 + 12] = pk_twc<1, 0, 0, 0, INV>(v[1 + 12], Wc);    // (S1, C1)
+    v[2 + 4] = pk_twc<0, 0, 0, 0, INV>(v[2 + 4], Wr);      // (R2, R2)
+    /* v[2 + 8]: (0, 1) = -i / +i, folded into the second pass (ROT2) */
+    v[2 + 12] = pk_twc<0, 1, 0, 0, INV>(v[2 + 12], Wr);    // (-R2, R2)
+    v[3 + 4] = pk_twc<1, 0, 0, 0, INV>(v[3 + 4], Wc);      // (S1, C1)
+    v[3 + 8] = pk_twc<0, 1, 0, 0, INV>(v[3 + 8], Wr);      // (-R2, R2)
+    v[3 + 12] = pk_twc<0, 1, 1, 1, INV>(v[3 + 12], Wc);    // (-C1, -S1)
+    pk_dft4<INV, false>(v[0], v[1], v[2], v[3]);
+    pk_dft4<INV, false>(v[4], v[5], v[6], v[7]);
+    pk_dft4<INV, true>(v[8], v[9], v[10], v[11]);
+    pk_dft4<INV, false>(v[12], v[13], v[14], v[15]);
+}
+
+// N ds_read_b64 at base + t * STRIDE_B (t = T0 ... T0 + N - 1), issued from one asm statement WITHOUT waiting; the caller
+// passes the results through lds_wait(), which ties them to the s_waitcnt
+template <int STRIDE_B, int T0>
+__device__ __forceinline__ void lds_issue8_b64(v2f (&v)[8], unsigned a)
+{
+    asm volatile(
+        "ds_read_b64 %0, %8 offset:%9\n\tds_read_b64 %1, %8 offset:%10\n\tds_read_b64 %2, %8 offset:%11\n\t"
+        "ds_read_b64 %3, %8 offset:%12\n\tds_read_b64 %4, %8 offset:%13\n\tds_read_b64 %5, %8 offset:%14\n\t"
+        "ds_read_b64 %6, %8 offset:%15\n\tds_read_b64 %7, %8 offset:%16"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+        : "v"(a), "n"((T0 + 0) * STRIDE_B), "n"((T0 + 1) * STRIDE_B), "n"((T0 + 2) * STRIDE_B), "n"((T0 + 3) * STRIDE_B),
+          "n"((T0 + 4) * STRIDE_B), "n"((T0 + 5) * STRIDE_B), "n"((T0 + 6) * STRIDE_B), "n"((T0 + 7) * STRIDE_B)
+        : "memory");
+}
+__device__ __forceinline__ void lds_wait8(v2f (&a)[8])
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    typedef const char __attribute__((address_space(3))) *lds_ptr;
+    return (unsigned)(uintptr_t)(lds_ptr)(const char *)p;
+}
+
+template <bool INV>
+__device__ __forceinline__ void fft4096_pk(v2f (&v)[16], cx<float> *lds, const cx<float> *twB, const cx<float> *twA, int j, v2f Wc, v2f Wr)
+{
+    v2f *l2 = (v2f *)lds;
+    const int kb = j & 15, jh = j >> 4;
+    pk_dft16<INV>(v, Wc, Wr);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) l2[j + jh + 272 * k] = v[LDS_DFT16_AT(k)];
+    __syncthreads();
+    {   // stage 2: data (n0 + 256 k0) + 16 n1 and twiddles W256^(n1 k0) = twB[16 n1 + k0]
+        v2f a[8], b[8], wa[8], wb[8];
+        const unsigned da = lds_addr(l2 + kb + 272 * jh), ta = lds_addr(twB + jh);
+        lds_issue8_b64<17 * 8, 0>(a, da);
+        lds_issue8_b64<17 * 8, 8>(b, da);
+        lds_issue8_b64<16 * 8, 0>(wa, ta);
+        lds_issue8_b64<16 * 8, 8>(wb, ta);
+        lds_wait8(a); lds_wait8(b); lds_wait8(wa); lds_wait8(wb);
+        v[0] = a[0];
+#pragma unroll
+        for (int t = 1; t < 8; ++t) v[t] = pk_cmul<INV>(a[t], wa[t]);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[8 + t] = pk_cmul<INV>(b[t], wb[t]);
+    }
+    __syncthreads();
+    pk_dft16<INV>(v, Wc, Wr);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) l2[j + jh + 272 * k] = v[LDS_DFT16_AT(k)];
+    __syncthreads();
+    {   // stage 3: data 16 j + n0, twiddles W4096^(n0 j) = twA[16 n0 + (j & 15)] * twB[16 n0 + (j >> 4)]
+        v2f a[8], wa[8], wb[8];
+        const unsigned da = lds_addr(l2 + 17 * j), t1 = lds_addr(twA + kb), t2 = lds_addr(twB + jh);
+        lds_issue8_b64<8, 0>(a, da);
+        lds_issue8_b64<16 * 8, 0>(wa, t1);
+        lds_issue8_b64<16 * 8, 0>(wb, t2);
+        lds_wait8(a); lds_wait8(wa); lds_wait8(wb);
+        v[0] = a[0];
+#pragma unroll
+        for (int t = 1; t < 8; ++t) v[t] = pk_cmul<INV>(a[t], pk_cmul<false>(wa[t], wb[t]));
+        lds_issue8_b64<8, 8>(a, da);
+        lds_issue8_b64<16 * 8, 8>(wa, t1);
+        lds_issue8_b64<16 * 8, 8>(wb, t2);
+        lds_wait8(a); lds_wait8(wa); lds_wait8(wb);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[8 + t] = pk_cmul<INV>(a[t], pk_cmul<false>(wa[t], wb[t]));
+    }
+    __syncthreads();
+    pk_dft16<INV>(v, Wc, Wr);
+    v2f o[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) o[k] = v[LDS_DFT16_AT(k)];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = o[k];
+}
+
 template <typename R> struct Geom {
     int64_t Tn, Tout;     // row lengths in / out
     int64_t F, S;         // frames per row, hop
@@ -170,33 +324,26 @@ template <typename R> struct Geom {
 constexpr int LDS_N = 4096;
 template <typename R> constexpr size_t lds_bytes() { return (size_t)(LDS_N + LDS_N / 16 + 512) * sizeof(cx<R>); }
 
-// Workgroup b handles pair  (b % 8) * ceil(npairs / 8) + b / 8: workgroups are dealt to the eight XCDs round robin
-// (observed, MI355X_MICROARCH.md; only speed depends on it), so the pairs one XCD works on at a time are neighbours in
-// memory and the K - 1 samples two consecutive pairs share are found in that XCD's L2.
-template <typename R>
-__global__ void __launch_bounds__(256, sizeof(R) == 4 ? 4 : 2)
-ols_lds4096_kernel(const R *__restrict__ x, R *__restrict__ y, const cx<R> *__restrict__ Hs,
-                   const cx<R> *__restrict__ tw256g, const cx<R> *__restrict__ t4log, Geom<R> g, int64_t npairs, int64_t per_xcd)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    cx<R> *lds = (cx<R> *)smem;                       // [4096 + 256]
-    cx<R> *twB = lds + LDS_N + LDS_N / 16;            // [16][16]  W256^(t k)
-    cx<R> *twA = twB + 256;                           // [16][16]  W4096^(t a)
-    const int j = threadIdx.x;
-    twB[j] = tw256g[((j >> 4) * (j & 15)) & 255];
-    twA[j] = t4log[j];
-    const int64_t pair = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if ((int64_t)(blockIdx.x >> 3) >= per_xcd || pair >= npairs) return;
-    __syncthreads();
+// Where a pair of frames lives: rows and offsets of frame a (real part) and frame b (imaginary part)
+template <typename R> struct PairAt {
+    int64_t fa, ca, cb, ra, rb;
+    bool has_b;
+    __device__ __forceinline__ PairAt(int64_t pair, const Geom<R> &g)
+    {
+        fa = 2 * pair;
+        has_b = fa + 1 < g.nframes;
+        ca = fa / g.F; ra = fa - ca * g.F;
+        cb = has_b ? (fa + 1) / g.F : ca; rb = has_b ? (fa + 1) - cb * g.F : ra;
+    }
+};
 
-    const int64_t fa = 2 * pair, fb = fa + 1;
-    const bool has_b = fb < g.nframes;
-    const int64_t ca = fa / g.F, ra = fa - ca * g.F;
-    const int64_t cb = has_b ? fb / g.F : ca, rb = has_b ? fb - cb * g.F : ra;
-    const int64_t ia0 = ra * g.S - g.pad_left, ib0 = rb * g.S - g.pad_left;
-    const R *xa = x + ca * g.Tn, *xb = x + cb * g.Tn;
-    cx<R> v[16];
-    if (ia0 >= 0 && ia0 + LDS_N <= g.Tn && has_b && ib0 >= 0 && ib0 + LDS_N <= g.Tn) {     // interior pair: no checks
+// thread j's sixteen elements j + 256 t of z = frame_a + i frame_b, gathered from the signal (zero fill / history outside the row)
+template <typename R>
+__device__ __forceinline__ void fetch_pair(cx<R> (&v)[16], const R *__restrict__ x, const Geom<R> &g, const PairAt<R> &p, int j)
+{
+    const int64_t ia0 = p.ra * g.S - g.pad_left, ib0 = p.rb * g.S - g.pad_left;
+    const R *xa = x + p.ca * g.Tn, *xb = x + p.cb * g.Tn;
+    if (ia0 >= 0 && ia0 + LDS_N <= g.Tn && p.has_b && ib0 >= 0 && ib0 + LDS_N <= g.Tn) {     // interior pair: no checks
         const R *pa = xa + ia0 + j, *pb = xb + ib0 + j;
 #pragma unroll
         for (int t = 0; t < 16; ++t) v[t] = mk<R>(pa[256 * t], pb[256 * t]);
@@ -205,25 +352,24 @@ ols_lds4096_kernel(const R *__restrict__ x, R *__restrict__ y, const cx<R> *__re
         for (int t = 0; t < 16; ++t) {
             const int64_t ia = ia0 + j + 256 * t, ib = ib0 + j + 256 * t;
             R re = (ia >= 0 && ia < g.Tn) ? xa[ia] : (R)0;
-            R im = (has_b && ib >= 0 && ib < g.Tn) ? xb[ib] : (R)0;
+            R im = (p.has_b && ib >= 0 && ib < g.Tn) ? xb[ib] : (R)0;
             if (g.hist) {
-                if (ia < 0 && ia >= -g.H) re = g.hist[ca * g.H + g.H + ia];
-                if (has_b && ib < 0 && ib >= -g.H) im = g.hist[cb * g.H + g.H + ib];
+                if (ia < 0 && ia >= -g.H) re = g.hist[p.ca * g.H + g.H + ia];
+                if (p.has_b && ib < 0 && ib >= -g.H) im = g.hist[p.cb * g.H + g.H + ib];
             }
             v[t] = mk<R>(re, im);
         }
     }
-    fft4096<R, false>(v, lds, twB, twA, j);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < 16; ++t) v[t] = cmul(v[t], Hs[j + 256 * t]);
-    __builtin_amdgcn_sched_barrier(0);
-    fft4096<R, true>(v, lds, twB, twA, j);
+}
 
-    const int64_t oa0 = ra * g.S, ob0 = rb * g.S;
-    R *ya = y + ca * g.Tout + oa0, *yb = y + cb * g.Tout + ob0;
+// the valid part of the block, n < S: real part -> frame a's hop, imaginary part -> frame b's
+template <typename R>
+__device__ __forceinline__ void store_pair(const cx<R> (&v)[16], R *__restrict__ y, const Geom<R> &g, const PairAt<R> &p, int j, char *smem)
+{
+    const int64_t oa0 = p.ra * g.S, ob0 = p.rb * g.S;
+    R *ya = y + p.ca * g.Tout + oa0, *yb = y + p.cb * g.Tout + ob0;
     const bool epi = g.ep_scale | g.ep_clamp | (g.ep_stat >= 0);
-    if (!epi && has_b && oa0 + g.S <= g.Tout && ob0 + g.S <= g.Tout) {     // whole hops inside their rows
+    if (!epi && p.has_b && oa0 + g.S <= g.Tout && ob0 + g.S <= g.Tout) {     // whole hops inside their rows
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int n = j + 256 * k;
@@ -237,7 +383,7 @@ ols_lds4096_kernel(const R *__restrict__ x, R *__restrict__ y, const cx<R> *__re
         const int n = j + 256 * k;
         if (n < g.S) {
             cx<R> o = v[k];
-            const bool wa = oa0 + n < g.Tout, wb = has_b && ob0 + n < g.Tout;
+            const bool wa = oa0 + n < g.Tout, wb = p.has_b && ob0 + n < g.Tout;
             if (epi) {                                       // Gain / clamp / statistic on the stored values (epilogue.h)
                 if (g.ep_scale) { o.x *= g.ep_gain; o.y *= g.ep_gain; }
                 if (g.ep_clamp) { o.x = clamp_unit(o.x); o.y = clamp_unit(o.y); }
@@ -263,8 +409,103 @@ ols_lds4096_kernel(const R *__restrict__ x, R *__restrict__ y, const cx<R> *__re
         if (j == 0) {
             double sa = red[0], sb = red[4];
             for (int u = 1; u < 4; ++u) { sa = red_comb_rt(g.ep_stat, sa, red[u]); sb = red_comb_rt(g.ep_stat, sb, red[4 + u]); }
-            g.ep_partial[fa] = sa;
-            if (has_b) g.ep_partial[fb] = sb;
+            g.ep_partial[p.fa] = sa;
+            if (p.has_b) g.ep_partial[p.fa + 1] = sb;
+        }
+        __syncthreads();                       // the next transform of a persistent workgroup writes this buffer
+    }
+}
+
+// forward transform, spectrum multiply, inverse transform of the sixteen elements a thread holds
+template <typename R>
+__device__ __forceinline__ void transform_pair(cx<R> (&v)[16], cx<R> *lds, const cx<R> *twB, const cx<R> *twA,
+                                               const cx<R> *__restrict__ Hs, int j)
+{
+    fft4096<R, false>(v, lds, twB, twA, j);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = cmul(v[t], Hs[j + 256 * t]);
+    __builtin_amdgcn_sched_barrier(0);
+    fft4096<R, true>(v, lds, twB, twA, j);
+}
+#ifndef TFX_LDS_NO_PK
+template <>
+__device__ __forceinline__ void transform_pair<float>(cx<float> (&v)[16], cx<float> *lds, const cx<float> *twB, const cx<float> *twA,
+                                                      const cx<float> *__restrict__ Hs, int j)
+{
+    const v2f Wc = {0.92387953251128675613f, 0.38268343236508977173f}, Wr = {0.70710678118654752440f, 0.70710678118654752440f};
+    v2f u[16], h[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) u[t] = __builtin_bit_cast(v2f, v[t]);
+    fft4096_pk<false>(u, lds, twB, twA, j, Wc, Wr);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 16; t += 2) {                      // float32 spectra are stored pair-interleaved: one 16-byte load = H[j + 256 t], H[j + 256 (t + 1)]
+        const v4f q = ((const v4f *)Hs)[(t >> 1) * 256 + j];
+        h[t] = v2f{q.x, q.y};
+        h[t + 1] = v2f{q.z, q.w};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) u[t] = pk_cmul<false>(u[t], h[t]);
+    __builtin_amdgcn_sched_barrier(0);
+    fft4096_pk<true>(u, lds, twB, twA, j, Wc, Wr);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = __builtin_bit_cast(cx<float>, u[t]);
+}
+#endif
+
+// Pair -> workgroup: workgroups are dealt to the eight XCDs round robin (observed, MI355X_MICROARCH.md; only speed depends on
+// it).  XCD b % 8 owns the pairs [xcd * per_xcd, (xcd + 1) * per_xcd) and its workgroups (local index m = b / 8, `wpx` of them)
+// walk that range m, m + wpx, m + 2 wpx, ...: the pairs one XCD works on at a time are neighbours in memory, so the K - 1
+// samples two consecutive pairs share are found in that XCD's L2.
+//   PERSIST 0  one pair per workgroup (wpx = per_xcd)
+//   PERSIST 1  resident workgroups loop over their pairs and fetch pair i + 1 into registers before they transform pair i:
+//              the loads are in flight for the whole transform, the stores of pair i drain under the transform of pair i + 1
+template <typename R, int PERSIST>
+__global__ void __launch_bounds__(256, sizeof(R) == 4 ? 4 : 2)
+ols_lds4096_kernel(const R *__restrict__ x, R *__restrict__ y, const cx<R> *__restrict__ Hs,
+                   const cx<R> *__restrict__ tw256g, const cx<R> *__restrict__ t4log, Geom<R> g, int64_t npairs, int64_t per_xcd)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cx<R> *lds = (cx<R> *)smem;                       // [4096 + 256]
+    cx<R> *twB = lds + LDS_N + LDS_N / 16;            // [16][16]  W256^(t k)
+    cx<R> *twA = twB + 256;                           // [16][16]  W4096^(t a)
+    const int j = threadIdx.x;
+    twB[j] = tw256g[((j >> 4) * (j & 15)) & 255];
+    twA[j] = t4log[j];
+    const int64_t wpx = gridDim.x >> 3, m = blockIdx.x >> 3;
+    const int64_t lo = (int64_t)(blockIdx.x & 7u) * per_xcd;
+    const int64_t hi = lo + per_xcd < npairs ? lo + per_xcd : npairs;
+    int64_t pair = lo + m;
+    if (pair >= hi) return;
+    __syncthreads();
+    cx<R> v[16];
+    if (PERSIST == 0) {
+        const PairAt<R> p(pair, g);
+        fetch_pair<R>(v, x, g, p, j);
+        transform_pair<R>(v, lds, twB, twA, Hs, j);
+        store_pair<R>(v, y, g, p, j, smem);
+    } else {
+        cx<R> nx[16];
+        {
+            const PairAt<R> p(pair, g);
+            fetch_pair<R>(nx, x, g, p, j);
+        }
+        for (;;) {
+            const PairAt<R> p(pair, g);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) v[t] = nx[t];
+            const int64_t next = pair + wpx;
+            if (next < hi) {
+                const PairAt<R> pn(next, g);
+                fetch_pair<R>(nx, x, g, pn, j);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            transform_pair<R>(v, lds, twB, twA, Hs, j);
+            store_pair<R>(v, y, g, p, j, smem);
+            if (next >= hi) break;
+            pair = next;
         }
     }
 }
@@ -310,7 +551,12 @@ template <typename R> static Plan get_plan(const R *kf, int64_t K, int64_t lead)
         for (int64_t i = 0; i < K; ++i) re[(size_t)(lead + i)] = (double)kf[i];
         host_fft_f64(re, im);
         std::vector<cx<R>> hs((size_t)LDS_N), t256(256), t4(256);
-        for (int k = 0; k < LDS_N; ++k) { hs[k].x = (R)(re[k] / LDS_N); hs[k].y = (R)(-im[k] / LDS_N); }
+        for (int k = 0; k < LDS_N; ++k) {
+            // float32: thread j multiplies elements j + 256 t; the pairs (t, t + 1) sit next to each other so it loads them 16 bytes at a time
+            const int t = k >> 8, jj = k & 255;
+            const int at = sizeof(R) == 4 ? ((t >> 1) * 256 + jj) * 2 + (t & 1) : k;
+            hs[at].x = (R)(re[k] / LDS_N); hs[at].y = (R)(-im[k] / LDS_N);
+        }
         for (int i = 0; i < 256; ++i) {
             const double a = -2.0 * M_PI * (double)i / 256.0;
             t256[i].x = (R)cos(a); t256[i].y = (R)sin(a);
@@ -392,18 +638,31 @@ static void olslds_typed(const R *x, R *y, int64_t C, int64_t Tn, const R *kf_ho
     const Plan plan = get_plan<R>(kf_host, K, lead);
     const int64_t npairs = ceil_div(g.nframes, 2);
     if (g.ep_stat >= 0) g.ep_partial = (double *)scratch("olslds_ep_partial", (size_t)g.nframes * sizeof(double), stream);
+    typedef void (*kern_t)(const R *, R *, const cx<R> *, const cx<R> *, const cx<R> *, Geom<R>, int64_t, int64_t);
+    static const kern_t kern[2] = {ols_lds4096_kernel<R, 0>, ols_lds4096_kernel<R, 1>};
     static bool attr_tab[TFX_MAX_DEVICES] = {};
+    static int resident_tab[TFX_MAX_DEVICES] = {};          // persistent workgroups the device holds at once
     const int dev = current_device();
     if (!attr_tab[dev]) {
-        TFX_HIP(hipFuncSetAttribute((const void *)ols_lds4096_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<float>()));
-        TFX_HIP(hipFuncSetAttribute((const void *)ols_lds4096_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<double>()));
+        for (int a = 0; a < 2; ++a)
+            TFX_HIP(hipFuncSetAttribute((const void *)kern[a], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<R>()));
+        int per_cu = 0, cus = 0;
+        TFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern[1], 256, lds_bytes<R>()));
+        TFX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        resident_tab[dev] = std::max(8, per_cu * cus / 8 * 8);
         attr_tab[dev] = true;
     }
     const int64_t per_xcd = ceil_div(npairs, 8);
     TFX_CHECK(per_xcd * 8 < ((int64_t)1 << 31), "fft_conv_forward: too many frames for one launch");
+    // persistent workgroups pay once every one of them has at least a few pairs to pipeline
+    int64_t persist = envi("TFX_OLS_LDS_PERSIST", -1);
+    int64_t grid = per_xcd * 8;
+    const int64_t resident = envi("TFX_OLS_LDS_GRID", resident_tab[dev]) / 8 * 8;
+    if (persist < 0) persist = grid >= 3 * resident;
+    if (persist && grid > resident && resident >= 8) grid = resident; else persist = 0;
     {
         ProfScope ps("ols_lds4096_kernel", stream);
-        hipLaunchKernelGGL(ols_lds4096_kernel<R>, dim3((unsigned)(per_xcd * 8)), dim3(256), lds_bytes<R>(), stream,
+        hipLaunchKernelGGL(kern[persist ? 1 : 0], dim3((unsigned)grid), dim3(256), lds_bytes<R>(), stream,
                            x, y, (const cx<R> *)plan.Hs, (const cx<R> *)plan.tw256, (const cx<R> *)plan.t4lo, g, npairs, per_xcd);
         TFX_HIP(hipGetLastError());
     }
