@@ -412,7 +412,6 @@ __device__ __forceinline__ void store_pair(const cx<R> (&v)[16], R *__restrict__
             g.ep_partial[p.fa] = sa;
             if (p.has_b) g.ep_partial[p.fa + 1] = sb;
         }
-        __syncthreads();                       // the next transform of a persistent workgroup writes this buffer
     }
 }
 
@@ -456,13 +455,12 @@ __device__ __forceinline__ void transform_pair<float>(cx<float> (&v)[16], cx<flo
 #endif
 
 // Pair -> workgroup: workgroups are dealt to the eight XCDs round robin (observed, MI355X_MICROARCH.md; only speed depends on
-// it).  XCD b % 8 owns the pairs [xcd * per_xcd, (xcd + 1) * per_xcd) and its workgroups (local index m = b / 8, `wpx` of them)
-// walk that range m, m + wpx, m + 2 wpx, ...: the pairs one XCD works on at a time are neighbours in memory, so the K - 1
-// samples two consecutive pairs share are found in that XCD's L2.
-//   PERSIST 0  one pair per workgroup (wpx = per_xcd)
-//   PERSIST 1  resident workgroups loop over their pairs and fetch pair i + 1 into registers before they transform pair i:
-//              the loads are in flight for the whole transform, the stores of pair i drain under the transform of pair i + 1
-template <typename R, int PERSIST>
+// it).  XCD b % 8 owns the pairs [xcd * per_xcd, (xcd + 1) * per_xcd) and its workgroups (local index m = b / 8) take them in
+// order: the pairs one XCD works on at a time are neighbours in memory, so the K - 1 samples two consecutive pairs share are
+// found in that XCD's L2 (PMC: 8.0 B of HBM traffic per output sample at K = 1024, i.e. 1.00 x algorithmic).
+// (Persistent workgroups that fetch pair i + 1 into registers while they transform pair i were built and measured: 3 waves per
+// SIMD instead of 4 -- or spills at 4 -- cost more than the overlap gains, 0.41 vs 0.375 ms; profiles/r04_experiments.txt.)
+template <typename R>
 __global__ void __launch_bounds__(256, sizeof(R) == 4 ? 4 : 2)
 ols_lds4096_kernel(const R *__restrict__ x, R *__restrict__ y, const cx<R> *__restrict__ Hs,
                    const cx<R> *__restrict__ tw256g, const cx<R> *__restrict__ t4log, Geom<R> g, int64_t npairs, int64_t per_xcd)
@@ -474,40 +472,14 @@ ols_lds4096_kernel(const R *__restrict__ x, R *__restrict__ y, const cx<R> *__re
     const int j = threadIdx.x;
     twB[j] = tw256g[((j >> 4) * (j & 15)) & 255];
     twA[j] = t4log[j];
-    const int64_t wpx = gridDim.x >> 3, m = blockIdx.x >> 3;
-    const int64_t lo = (int64_t)(blockIdx.x & 7u) * per_xcd;
-    const int64_t hi = lo + per_xcd < npairs ? lo + per_xcd : npairs;
-    int64_t pair = lo + m;
-    if (pair >= hi) return;
+    const int64_t pair = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= per_xcd || pair >= npairs) return;
     __syncthreads();
     cx<R> v[16];
-    if (PERSIST == 0) {
-        const PairAt<R> p(pair, g);
-        fetch_pair<R>(v, x, g, p, j);
-        transform_pair<R>(v, lds, twB, twA, Hs, j);
-        store_pair<R>(v, y, g, p, j, smem);
-    } else {
-        cx<R> nx[16];
-        {
-            const PairAt<R> p(pair, g);
-            fetch_pair<R>(nx, x, g, p, j);
-        }
-        for (;;) {
-            const PairAt<R> p(pair, g);
-#pragma unroll
-            for (int t = 0; t < 16; ++t) v[t] = nx[t];
-            const int64_t next = pair + wpx;
-            if (next < hi) {
-                const PairAt<R> pn(next, g);
-                fetch_pair<R>(nx, x, g, pn, j);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            transform_pair<R>(v, lds, twB, twA, Hs, j);
-            store_pair<R>(v, y, g, p, j, smem);
-            if (next >= hi) break;
-            pair = next;
-        }
-    }
+    const PairAt<R> p(pair, g);
+    fetch_pair<R>(v, x, g, p, j);
+    transform_pair<R>(v, lds, twB, twA, Hs, j);
+    store_pair<R>(v, y, g, p, j, smem);
 }
 
 // ---- host: per-filter tables ---------------------------------------------------------------------
@@ -638,31 +610,17 @@ static void olslds_typed(const R *x, R *y, int64_t C, int64_t Tn, const R *kf_ho
     const Plan plan = get_plan<R>(kf_host, K, lead);
     const int64_t npairs = ceil_div(g.nframes, 2);
     if (g.ep_stat >= 0) g.ep_partial = (double *)scratch("olslds_ep_partial", (size_t)g.nframes * sizeof(double), stream);
-    typedef void (*kern_t)(const R *, R *, const cx<R> *, const cx<R> *, const cx<R> *, Geom<R>, int64_t, int64_t);
-    static const kern_t kern[2] = {ols_lds4096_kernel<R, 0>, ols_lds4096_kernel<R, 1>};
     static bool attr_tab[TFX_MAX_DEVICES] = {};
-    static int resident_tab[TFX_MAX_DEVICES] = {};          // persistent workgroups the device holds at once
     const int dev = current_device();
     if (!attr_tab[dev]) {
-        for (int a = 0; a < 2; ++a)
-            TFX_HIP(hipFuncSetAttribute((const void *)kern[a], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<R>()));
-        int per_cu = 0, cus = 0;
-        TFX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern[1], 256, lds_bytes<R>()));
-        TFX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        resident_tab[dev] = std::max(8, per_cu * cus / 8 * 8);
+        TFX_HIP(hipFuncSetAttribute((const void *)ols_lds4096_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<R>()));
         attr_tab[dev] = true;
     }
     const int64_t per_xcd = ceil_div(npairs, 8);
     TFX_CHECK(per_xcd * 8 < ((int64_t)1 << 31), "fft_conv_forward: too many frames for one launch");
-    // persistent workgroups pay once every one of them has at least a few pairs to pipeline
-    int64_t persist = envi("TFX_OLS_LDS_PERSIST", -1);
-    int64_t grid = per_xcd * 8;
-    const int64_t resident = envi("TFX_OLS_LDS_GRID", resident_tab[dev]) / 8 * 8;
-    if (persist < 0) persist = grid >= 3 * resident;
-    if (persist && grid > resident && resident >= 8) grid = resident; else persist = 0;
     {
         ProfScope ps("ols_lds4096_kernel", stream);
-        hipLaunchKernelGGL(kern[persist ? 1 : 0], dim3((unsigned)grid), dim3(256), lds_bytes<R>(), stream,
+        hipLaunchKernelGGL(ols_lds4096_kernel<R>, dim3((unsigned)(per_xcd * 8)), dim3(256), lds_bytes<R>(), stream,
                            x, y, (const cx<R> *)plan.Hs, (const cx<R> *)plan.tw256, (const cx<R> *)plan.t4lo, g, npairs, per_xcd);
         TFX_HIP(hipGetLastError());
     }
