@@ -117,6 +117,10 @@ def make_step(workload: str, x: torch.Tensor):
     if workload == "fir":
         k = fir.kernel.reshape(-1)
         return (lambda: E.fir_direct_forward(x, k)), "cfg3: direct FIR, 1024 taps (exact-f32 MFMA Toeplitz)", None
+    if workload == "fir_fft":
+        from torchfx_amd import filter as F
+        m = F.FIR(fir.b, conv_mode="fft")               # the reference's DEFAULT FIR mode (fir.py:510,552): fft_conv1d
+        return (lambda: m(x)), "cfg3's filter through FIR.forward's default FFT mode: one-launch LDS-resident overlap-save, 1024 taps", None
     if workload == "fftconv":
         k = rev.kernel.reshape(-1)
         return (lambda: E.fft_conv_forward(x, k, (k.numel() - 1, 0))), "cfg4: overlap-save FFT conv, 65536 taps", 65536
@@ -439,7 +443,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="chain",
-                    choices=["chain", "sos", "fir", "fftconv", "chain_iir_kernel", "chain_reference_staging"])
+                    choices=["chain", "sos", "fir", "fir_fft", "fftconv", "chain_iir_kernel", "chain_reference_staging"])
     ap.add_argument("--channels", type=int, default=64, help="channels PER GPU (weak scaling)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--total-channels", type=int, default=512, help="fixed batch of --scaling strong (cfg 5)")
@@ -453,9 +457,21 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1) by
+        # replacing this process with torch.distributed.run on the same command line; rank 0 prints the one JSON line
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("OMP_NUM_THREADS", "8")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
+                         "(or run plain `python bench.py --gpus N`, which starts the ranks itself)")
     import torch.distributed as dist
 
     # TFX_BENCH_SHARE_DEVICE=1 (development only): every rank uses cuda:0 and the collectives go over
@@ -558,7 +574,8 @@ def main() -> None:
         # kernel time from the library's HIP events beside it
         stages = {}
         for key, wl, sec, bound in (("cfg2", "sos", 60.0, "hbm"), ("cfg2_precision_auto", "sos_auto", 60.0, "hbm"),
-                                    ("cfg3", "fir", 60.0, "mfma"), ("cfg4", "fftconv", 600.0, "hbm")):
+                                    ("cfg3", "fir", 60.0, "mfma"), ("cfg3_fft_mode", "fir_fft", 60.0, "hbm"),
+                                    ("cfg4", "fftconv", 600.0, "hbm")):
             try:
                 xs = x if sec == seconds else x[:, : int(sec * FS)].contiguous()
                 sstep, sdesc, _ = make_step(wl, xs)
@@ -632,7 +649,8 @@ def main() -> None:
         line_ols = None
         try:
             from torchfx_amd import torchfx_ext as E
-            model = {"sos_stream_kernel<f64>": 8.0 * samples, "sos_stream_kernel<f32>": 8.0 * samples}
+            model = {"sos_stream_kernel<f64>": 8.0 * samples, "sos_stream_kernel<f32>": 8.0 * samples,
+                     "ols_lds4096_kernel": 8.0 * samples}
             if ols_taps:
                 kk = ols_taps
                 info = E.ols_plan_info(kk, T, (kk - 1, 0))
@@ -743,9 +761,17 @@ def main() -> None:
                 roof["iir_kernel"] = {"name": kn, "achieved": round(a, 1), "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4)}
         dtype = {"chain": "f32 (overlap-save FFT arithmetic for the whole fused chain; f32 I/O)",
                  "chain_iir_kernel": "f64 (IIR) + f32 (FFT); f32 I/O", "chain_reference_staging": "f64 (IIR) + f32 (FFT); f32 I/O",
-                 "sos": "f64; f32 I/O", "fir": "f32", "fftconv": "f32"}[args.workload]
+                 "sos": "f64; f32 I/O", "fir": "f32", "fir_fft": "f32", "fftconv": "f32"}[args.workload]
         if args.workload == "chain" and "sos_stream_kernel<f64>" in kernels:
             dtype = "f64 (IIR) + f32 (FFT); f32 I/O"
+        iir_knob = os.environ.get("TORCHFX_AMD_IIR_PRECISION", "f64")
+        if args.workload == "chain" and not any(n.startswith("sos_stream_kernel") for n in kernels):
+            iir_how = ("folded into the f32 overlap-save pass (fuse_spectral: the cascade's 2418-tap impulse response joins the FIR run; "
+                       f"no recursive kernel runs; roofline.step_frac_reference_arithmetic = the chain with the IIR as its own {iir_knob} pass)")
+        elif args.workload in ("fir", "fir_fft", "fftconv"):
+            iir_how = "n/a (no IIR stage)"
+        else:
+            iir_how = f"{iir_knob} recursion in sos_stream_kernel (TORCHFX_AMD_IIR_PRECISION)"
         line = {
             # BASELINE.json's metric string; `value` is the whole-job aggregate, `per_gpu_value` the per-GPU rate
             "metric": "Msamples/s/GPU (64-ch fused biquad→FIR→FFT-conv chain); % HBM roofline"
@@ -758,7 +784,7 @@ def main() -> None:
             "config": {"workload": desc, "channels_per_gpu": C, "total_channels": C * world, "seconds": seconds, "fs": FS,
                        "samples_per_gpu": samples, "parallelism": f"channel-shard x{world}, no data-path collective",
                        "fusion_policy": os.environ.get("TORCHFX_AMD_FUSION", "auto"),
-                       "iir_precision": os.environ.get("TORCHFX_AMD_IIR_PRECISION", "f64"),
+                       "iir_precision": iir_how,
                        "source_digest": source_digest()},
             "roofline": roof,
             "kernels": kernels, "gpu_ms_per_step_sum_of_kernels": round(gpu_ms, 4),
@@ -789,6 +815,8 @@ def main() -> None:
         if line_ols:
             line["config"]["overlap_save"] = line_ols
         if stages:
+            if first_call_ms is not None:
+                stages["first_ys_ms"] = round(first_call_ms, 2)       # first (Wave(x) | ...).ys of the process, planning included
             line["stages"] = stages
         if variants:
             line["variants"] = variants
@@ -798,6 +826,7 @@ def main() -> None:
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only (contract)
             try:
                 base_wl = "chain" if args.workload.startswith("chain") else args.workload
+                base_wl = "fir" if base_wl == "fir_fft" else base_wl
                 sec, ch = {"chain": (300.0, 64), "sos": (600.0, 64), "fir": (60.0, 32), "fftconv": (300.0, 64)}[base_wl]
                 line["cpu_baseline"] = cpu_baseline(base_wl, sec, ch)     # ~10-20 s of CPU work
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number

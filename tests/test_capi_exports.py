@@ -5,6 +5,8 @@ import os
 import re
 import subprocess
 
+import pytest
+
 from tests.conftest import ROOT
 
 
@@ -157,3 +159,19 @@ def test_plain_c_host_builds_and_runs_without_a_gpu(tmp_path):
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert "tfx_version" in out and "overlap-save plan: N 1048576" in out
     assert "null pointer ->" in out            # error code + message instead of a crash
+
+
+def test_reference_package_binds_to_our_compiled_module():
+    """Build container only (skipped where /root/reference is absent, i.e. on the GPU box): the REAL reference package is
+    imported with our compiled module installed as `torchfx.torchfx_ext`; `torchfx._ops` binds to it and the reference's own
+    call paths (`_ops.*`, `IIR.forward`, `Wave | iir | iir`) end in our C++ (oracle/check_reference_binding.py)."""
+    import os
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("needs /root/reference (build container)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "oracle", "check_reference_binding.py")], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "check_reference_binding: ok" in r.stdout and r.stdout.count("reached the HIP module") == 5

@@ -190,6 +190,32 @@ def test_bench_two_ranks_on_one_device(tmp_path):
         assert "cpu_baseline" not in line and "stages" not in line          # rank 0 at N = 1 only
 
 
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher in front (the shape of the command the driver uses at N = 1): bench.py
+    re-executes itself under torch.distributed.run, one rank per GPU; rank 0 prints ONE JSON line with ranks_seen == 2.
+    (TFX_BENCH_SHARE_DEVICE=1 puts both ranks on cuda:0 over gloo on a one-GPU box; never set by the driver.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["TFX_BENCH_SHARE_DEVICE"] = "1"
+    for extra, scaling, chans in ((["--channels", "4", "--gather"], "weak", 4),
+                                  (["--scaling", "strong", "--total-channels", "6"], "strong", 3)):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                            "--seconds", "30"] + extra, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and len(line["devices"]) == 2
+        assert {d["rank"] for d in line["devices"]} == {0, 1} and all(d["uuid"] for d in line["devices"])
+        assert line["scaling"] == scaling and line["config"]["channels_per_gpu"] == chans and line["value"] > 0
+        if "--gather" in extra:
+            assert 0 < line["value_with_gather"] < line["value"]
+
+
 def test_two_devices_in_one_process_keep_their_own_caches():
     """Every device-side cache is keyed by the device ordinal (plans, taps, spectra, scratch, internal streams):
     the same filters driven alternately on cuda:0 and cuda:1 from ONE process give the single-device results.

@@ -271,3 +271,28 @@ def test_stream_processor_takes_the_fused_chunk_path_on_device(monkeypatch):
     monkeypatch.setenv("TORCHFX_AMD_FUSE_CHUNK", "0")
     ys = StreamProcessor(chain(), chunk_size=512, device=DEV).process_tensor(torch.from_numpy(x), fs)
     close(y, ys.cpu().numpy(), 3e-7, "fused vs staged chunk loop")
+
+
+def test_fused_chunk_run_rezeroes_state_when_the_channel_count_changes():
+    """Advisor, round 3: a `_ChunkRun` that has run on C rows and then gets a chunk with another channel count (a processor
+    reused on another signal) must re-zero the IIR state like `_sos_cascade_forward` and the reference do (iir.py:136-138,
+    tests/test_fused.py:202-214 of the reference) instead of handing the kernel state tensors of the old shape."""
+    from torchfx_amd import filter as F
+    from torchfx_amd.effect import Gain
+    from torchfx_amd.realtime import StatefulFIR, _ChunkRun
+    fs = 48000
+    b = np.hanning(65) / np.hanning(65).sum()
+    iirs = [F.LoButterworth(3000, order=4, fs=fs), F.ParametricEQ(frequency=800, q=2.0, gain=4.0, fs=fs)]
+    run = _ChunkRun(iirs, StatefulFIR(b, conv_mode="fft"), Gain(0.9))
+    x2, x5 = rnd((2, 1024), 1), rnd((5, 1024), 2)
+    assert run.fuses(dev(x2)) and run.fuses(dev(x5))
+    run(dev(x2[:, :512]))
+    run(dev(x2[:, 512:]))                                 # fast path: states carried as views of the combined tensors
+    y5 = run(dev(x5[:, :512]))                            # other channel count: states and history start from zero again
+    y5b = run(dev(x5[:, 512:]))
+    for m in iirs:
+        m.compute_coefficients()
+    sos = np.vstack([m._sos.numpy() for m in iirs])
+    ref = O.fir_direct(O.sos_forward(x5, sos)[0].astype(np.float32), b[::-1].astype(np.float32).copy()) * np.float32(0.9)
+    close(torch.cat([y5, y5b], dim=1), ref, 1e-5, "5-channel signal after a 2-channel one == one shot from zero state")
+    assert tuple(iirs[0]._state_x.shape)[1] == 5

@@ -50,3 +50,23 @@ def test_no_cpu_fallback_branches():
         body = body[:body.index("\n}\n")]
         assert "need_device(" in body or "_impl(" in body or "deinterleave_into_op(" in body, (name, fn)
     assert cpp.count("need_device(") >= 12
+
+
+def test_reference_build_is_fenced_to_the_cpu_baseline_leg():
+    """oracle/_ref/torchfx_ext.so (the reference's own C++ compiled by oracle/Makefile) travels to the GPU box for ONE purpose:
+    bench.py's `cpu_baseline.reference_iir_stage`, which runs oracle/ref_time.py in a subprocess.  No `-m gpu` test, shared GPU
+    helper or `smoke()` may open it or that script; the only other users are the build-container generators under oracle/."""
+    import ast
+    import glob
+    opens = re.compile(r"oracle/_ref|[\"']_ref[\"']|ref_time|_ref/torchfx_ext")
+    for p in sorted(glob.glob(os.path.join(ROOT, "tests", "test_gpu_*.py"))) + [os.path.join(ROOT, "tests", "gpu_common.py")]:
+        for i, line in enumerate(open(p, encoding="utf-8"), 1):
+            assert not opens.search(line), f"{p}:{i}: {line.strip()}"
+    entry = ast.parse(open(os.path.join(ROOT, "__graft_entry__.py")).read())
+    smoke = next(n for n in entry.body if isinstance(n, ast.FunctionDef) and n.name == "smoke")
+    assert not opens.search(ast.unparse(smoke))
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    users = {n.name for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and opens.search(ast.unparse(n))}
+    assert users == {"cpu_baseline", "run_ref"}, users
+    users_oracle = [f for f in glob.glob(os.path.join(ROOT, "oracle", "*.py")) if opens.search(open(f).read())]
+    assert {os.path.basename(f) for f in users_oracle} <= {"make_golden.py", "ref_time.py", "check_reference_binding.py"}

@@ -106,9 +106,12 @@ class _ChunkRun:
     def _states(self, rows: int, device) -> tuple[Tensor | None, Tensor | None]:
         if not self.iirs:
             return None, None
-        if self._sx is not None and len(self._views) == len(self.iirs) and all(
-                m._state_x is vx and m._state_y is vy for m, (vx, vy) in zip(self.iirs, self._views)):
-            return self._sx, self._sy                           # untouched since the last chunk
+        if (self._sx is not None and self._sx.shape[1] == rows and self._sx.device == device
+                and len(self._views) == len(self.iirs) and all(
+                    m._state_x is vx and m._state_y is vy for m, (vx, vy) in zip(self.iirs, self._views))):
+            return self._sx, self._sy                           # untouched since the last chunk, same rows, same device
+        # (a chunk with another channel count or on another device takes the rebuild below, which zero-fills the members
+        # whose state does not fit -- what _sos_cascade_forward and the reference do, iir.py:136-138)
         if all(m._state_x is None for m in self.iirs):
             return None, None                                   # fresh: the kernel treats None as zeros
         xs, ys = [], []

@@ -189,6 +189,11 @@ def _member_key(m: nn.Module, guard: list) -> tuple:
     return k
 
 
+def _lacks_coefficients(m: nn.Module) -> bool:
+    return (hasattr(m, "_sos") and not isinstance(getattr(m, "_sos"), Tensor)) or \
+           (hasattr(m, "kernel") and not isinstance(getattr(m, "kernel"), Tensor))
+
+
 def _instantiate(cached: list) -> list:
     """A runnable plan from a cached one: planner-built cascades carry state while they run, so every
     materialisation gets its own (the reference builds a fresh ``FusedSOSCascade`` per ``.ys`` as well)."""
@@ -245,16 +250,21 @@ class Wave:
         flags = (self.fuse_fir, getattr(self, "fuse_spectral", False), getattr(self, "fuse_gain", False),
                  getattr(self, "fuse_epilogue", False))
         length = int(self._ys.shape[-1]) if self._ys.dim() else 0
+        dtype = self._ys.dtype                       # the overlap-save path (and so the fold decision) depends on it
         guard: list = []
-        key = (tuple(_member_key(m, guard) for m in self._pipeline), flags, length)
-        hit = _lru_get(_PLANS, key)
+        key = (tuple(_member_key(m, guard) for m in self._pipeline), flags, length, dtype)
+        # a member without coefficients yet (IIR.reset_state drops `_sos`; a FIR without a kernel) is keyed by identity alone:
+        # such a pipeline is planned afresh every time instead of being looked up (advisor, round 3)
+        cacheable = all(not _lacks_coefficients(m) for m in self._pipeline)
+        hit = _lru_get(_PLANS, key) if cacheable else None
         if hit is not None:
             return _instantiate(hit[1])
-        built = self._build_plan(length)
-        _lru_put(_PLANS, key, (guard, built))
+        built = self._build_plan(length, dtype)
+        if cacheable:
+            _lru_put(_PLANS, key, (guard, built))
         return _instantiate(built)
 
-    def _build_plan(self, length: int) -> list[nn.Module]:
+    def _build_plan(self, length: int, dtype: torch.dtype = torch.float32) -> list[nn.Module]:
         from torchfx_amd.filter.biquad import Biquad
         from torchfx_amd.filter.fir import FIR
         from torchfx_amd.filter._sos import CascadeTable
@@ -324,7 +334,7 @@ class Wave:
         flush()
         plan.extend(lead)
         if getattr(self, "fuse_spectral", False):
-            plan = self._spectral_plan(plan, length)
+            plan = self._spectral_plan(plan, length, dtype)
         if getattr(self, "fuse_epilogue", False):
             plan = self._epilogue_plan(plan)
         return plan
@@ -361,17 +371,16 @@ class Wave:
         return out
 
     @staticmethod
-    def _ols_bytes_per_sample(taps: int, length: int) -> float:
-        """HBM bytes per output sample of one overlap-save pass with `taps` taps on rows of `length`
-        samples (three passes over a complex workspace of two real frames: 20 N / S + 4; the rocFFT
-        path used for short rows moves ~95)."""
+    def _ols_bytes_per_sample(taps: int, length: int, dtype: torch.dtype = torch.float32) -> float:
+        """HBM bytes per output sample of one overlap-save pass with `taps` taps on rows of `length` samples of
+        `dtype`, for the path that would run (``torchfx_ext.ols_plan_info``): the one-launch LDS kernel
+        e N / S + e (e = element size), the three-pass pipeline 20 N / S + 4, rocFFT ~95 (float64: 190)."""
         from torchfx_amd import torchfx_ext
 
-        info = torchfx_ext.ols_plan_info(taps, length, (taps - 1, 0))
-        return 20.0 * info["N"] / info["S"] + 4.0 if info["native"] else 95.0
+        return float(torchfx_ext.ols_plan_info(taps, length, (taps - 1, 0), dtype)["bytes_per_sample"])
 
     @staticmethod
-    def _spectral_plan(plan: list[nn.Module], length: int = 0) -> list[nn.Module]:
+    def _spectral_plan(plan: list[nn.Module], length: int = 0, dtype: torch.dtype = torch.float32) -> list[nn.Module]:
         """``fuse_spectral``: an LTI run  IIR-cascade | FIR...  is ONE linear system, so a freshly
         created (stateless) cascade that is followed by an FFT-mode FIR is folded into it as its
         impulse response, truncated where the cascade has forgotten its past to float64 round-off --
@@ -396,7 +405,9 @@ class Wave:
                 if eq is not None:
                     k0, k1 = int(nxt.kernel.numel()), int(nxt.kernel.numel()) + int(eq.kernel.numel()) - 1
                     try:
-                        pays = Wave._ols_bytes_per_sample(k1, length) <= Wave._ols_bytes_per_sample(k0, length) + 8.0
+                        esz = 8.0 if dtype == torch.float64 else 4.0        # the recursive pass reads and writes the signal once
+                        pays = (Wave._ols_bytes_per_sample(k1, length, dtype)
+                                <= Wave._ols_bytes_per_sample(k0, length, dtype) + 2.0 * esz)
                     except RuntimeError:          # signal shorter than the taps: nothing to gain
                         pays = False
                     if pays:
