@@ -680,6 +680,7 @@ struct NativePlan {
 };
 static std::mutex g_np_mu;
 static std::map<std::vector<char>, NativePlan *> g_nplans;
+static int64_t g_free_mb[TFX_MAX_DEVICES] = {};                  // per device: free memory (MB) seen at first use, 0 = not asked yet
 static NativePlan *g_last_plan[TFX_MAX_DEVICES] = {};          // per device: the plan used last and its key
 static std::vector<char> g_last_key[TFX_MAX_DEVICES];
 
@@ -826,7 +827,7 @@ void olsnative_clear()
         delete p;
     }
     g_nplans.clear();
-    for (int d = 0; d < TFX_MAX_DEVICES; ++d) g_last_plan[d] = nullptr;
+    for (int d = 0; d < TFX_MAX_DEVICES; ++d) { g_last_plan[d] = nullptr; g_free_mb[d] = 0; }
 }
 
 static int64_t envi(const char *name, int64_t dflt)
@@ -861,7 +862,9 @@ bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out)
 void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const float *kf_host, int64_t K,
                        int64_t pl, int64_t pr, int64_t N, hipStream_t stream, const float *hist, int64_t H, const Epilogue *ep)
 {
-    std::lock_guard<std::mutex> lk(g_np_mu);
+    // g_np_mu guards the plan cache, the one-time function attributes and the creation of the internal streams (the three
+    // short sections below); the launches themselves are not serialised, so two host threads that drive two streams overlap
+    // (each stream has its own scratch slabs; the internal lanes are shared and ordered by the fork / join events)
     OlsGeom g;
     const int64_t L = Tn + pl + pr;
     g.Tn = Tn; g.Tout = L - K + 1; g.pad_left = pl; g.out_shift = 0;
@@ -879,7 +882,11 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     g.pad_left = pl + lead;
     g.S = N - (K + lead) + 1;
     if (align && g.S > 64) g.S -= g.S % 32;
-    NativePlan *plan = get_native_plan(kf_host, K, N, lead);
+    NativePlan *plan;
+    {
+        std::lock_guard<std::mutex> lk(g_np_mu);
+        plan = get_native_plan(kf_host, K, N, lead);
+    }
     g.F = ceil_div(g.Tout + g.out_shift, g.S);
     g.nframes = C * g.F; g.N2 = plan->N2;
     g.P2 = g.N2 + (int)envi("TFX_OLS_PITCH_PAD", 0);
@@ -903,9 +910,20 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
         // tfx_clear_caches); TFX_OLS_SLAB_MB bounds a lane's share, never more than 1/8 of the free memory over all lanes.
         int64_t slab_mb = envi("TFX_OLS_SLAB_MB", 64);
         {
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                const int64_t cap_mb = (int64_t)(free_b >> 20) / (8 * nlanes);
+            // the cap follows the memory free when the device is first used (and again after tfx_clear_caches), not at every call:
+            // a driver query per step costs tens of microseconds, is not allowed while a stream is capturing, and would make the
+            // slab geometry depend on the allocator's state of the moment (advisor, round 3)
+            static std::mutex cap_mu;
+            std::lock_guard<std::mutex> cl(cap_mu);
+            int64_t &cap_free_mb = g_free_mb[current_device()];
+            if (cap_free_mb == 0) {
+                size_t free_b = 0, total_b = 0;
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                const bool capturing = hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+                if (!capturing && hipMemGetInfo(&free_b, &total_b) == hipSuccess) cap_free_mb = std::max<int64_t>(1, (int64_t)(free_b >> 20));
+            }
+            if (cap_free_mb > 0) {
+                const int64_t cap_mb = cap_free_mb / (8 * nlanes);
                 if (slab_mb > cap_mb) slab_mb = std::max<int64_t>(cap_mb, 8);
             }
         }
@@ -940,6 +958,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     static bool attr_tab[TFX_MAX_DEVICES] = {};
     const int dev = current_device();
     bool &attr = attr_tab[dev];
+    std::unique_lock<std::mutex> init_lk(g_np_mu);
     if (!attr) {
         for (int a = 0; a < 6; ++a)
             TFX_HIP(hipFuncSetAttribute((const void *)row_tab[a], hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
@@ -950,6 +969,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
             }
         attr = true;
     }
+    init_lk.unlock();
     const int ncb = g.N2 / OLS_CB;
     // Internal streams (TFX_OLS_STREAMS, default 2), slabs rotate over them: while one slab drains the tail of a pass
     // (the last, partially filled round of workgroups) the other slab's pass fills the idle CUs.
@@ -966,7 +986,16 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     hipEvent_t *ev_join = ln_.join;
     cpx *Tlane[MAXL] = {T, T, T, T, T, T, T, T};
     hipStream_t user_stream = stream;
+    // The lanes and their fork / join events are shared by every caller on the device.  A waiting stream takes the event's MOST
+    // RECENT record, so "record the fork event on my stream, make the lanes wait for it" must not interleave with another host
+    // thread's fork (its lanes would wait for the wrong stream's point); the join is safe either way (a later record on the same
+    // lane is a superset) but takes the same lock.  Only these two short sections are serialised, not the launches.
+    static std::mutex lane_mu;
     if (nlanes > 1) {
+        static const char *tags[MAXL] = {"olsn_T", "olsn_T2", "olsn_T3", "olsn_T4", "olsn_T5", "olsn_T6", "olsn_T7", "olsn_T8"};
+        for (int i = 1; i < nlanes; ++i)
+            Tlane[i] = (cpx *)scratch(tags[i], (size_t)slab * (size_t)OLS_N1 * (size_t)g.P2 * sizeof(cpx), user_stream);
+        std::lock_guard<std::mutex> fl(lane_mu);
         if (!lane_stream[0]) {
             for (int i = 0; i < MAXL; ++i) {
                 TFX_HIP(hipStreamCreateWithFlags(&lane_stream[i], hipStreamNonBlocking));
@@ -974,9 +1003,6 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
             }
             TFX_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         }
-        static const char *tags[MAXL] = {"olsn_T", "olsn_T2", "olsn_T3", "olsn_T4", "olsn_T5", "olsn_T6", "olsn_T7", "olsn_T8"};
-        for (int i = 1; i < nlanes; ++i)
-            Tlane[i] = (cpx *)scratch(tags[i], (size_t)slab * (size_t)OLS_N1 * (size_t)g.P2 * sizeof(cpx), user_stream);
         TFX_HIP(hipEventRecord(ev_fork, user_stream));
         for (int i = 0; i < nlanes; ++i) TFX_HIP(hipStreamWaitEvent(lane_stream[i], ev_fork, 0));
     }
@@ -1021,6 +1047,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
         }
     }
     if (nlanes > 1) {
+        std::lock_guard<std::mutex> jl(lane_mu);
         for (int i = 0; i < nlanes; ++i) {
             TFX_HIP(hipEventRecord(ev_join[i], lane_stream[i]));
             TFX_HIP(hipStreamWaitEvent(user_stream, ev_join[i], 0));

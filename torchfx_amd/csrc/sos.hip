@@ -1254,7 +1254,7 @@ void chunk_forward(const float *x, int64_t x_pitch, float *y, int64_t C, int64_t
     TFX_CHECK(chunk_supported(C, T, K, Kf), "chunk_forward: unsupported geometry C=%lld T=%lld K=%lld taps=%lld "
               "(T <= 4096, K <= 64, T * taps <= 2^22)", (long long)C, (long long)T, (long long)K, (long long)Kf);
     TFX_CHECK(x && y && taps_host && (K == 0 || sos_host), "chunk_forward: null pointer");
-    TFX_CHECK(hist_out != hist_in || Kf == 1, "chunk_forward: the new history needs its own buffer");
+    TFX_CHECK(hist_out == nullptr || hist_out != hist_in, "chunk_forward: the new history needs its own buffer");   // NULL = silence in / no history out
     ChunkParams q{};
     SosParams &p = q.sos;
     p.x = x; p.y = nullptr; p.taps = nullptr;

@@ -49,7 +49,8 @@ def run_sharded(pipeline: nn.Module | list, x_local: Tensor, fs: int | None = No
 
 
 def gather_rows(y_local: Tensor, n_rows: int, dst: int = 0, group=None, out: Tensor | None = None) -> Tensor | None:
-    """Single gather of the per-rank row blocks to ``dst`` -> ``[n_rows, T]`` there, None elsewhere.
+    """Single gather of the per-rank row blocks to ``dst`` -> ``[n_rows, T]`` there, None elsewhere.  ``dst`` is a rank OF
+    ``group`` (0 ... world-1 of that group; ``torch.distributed.gather`` takes a global rank instead).
 
     The root receives every peer's block straight into its row-block view of ONE preallocated ``[n_rows, T]``
     output (``out``, if given, is that buffer): no ``world`` staging buffers and no ``torch.cat`` -- at cfg 5 the
@@ -69,6 +70,11 @@ def gather_rows(y_local: Tensor, n_rows: int, dst: int = 0, group=None, out: Ten
     # "nccl" (= RCCL) moves device buffers peer to root directly; a gloo group (CPU collectives: the
     # development set-up where several ranks share one GPU) stages device rows through host memory
     staged = y_local.is_cuda and dist.get_backend(group) == "gloo"
+    # Ranks with an empty block (n_rows < world) have nothing to send.  On RCCL the FIRST communication of a group creates
+    # the communicator and every rank has to take part in it, so when anybody sits the batch out a cheap all-reduce comes
+    # first: every rank enters it, later point-to-point batches may then involve any subset (advisor, round 3).
+    if any(rhi == rlo for rlo, rhi in sizes) and dist.get_backend(group) == "nccl":
+        dist.all_reduce(torch.zeros(1, dtype=torch.int32, device=y_local.device), group=group)
     if rank != dst:
         if hi > lo:
             wire = y_local.contiguous()
