@@ -118,8 +118,8 @@ def make_step(workload: str, x: torch.Tensor):
         k = fir.kernel.reshape(-1)
         return (lambda: E.fir_direct_forward(x, k)), "cfg3: direct FIR, 1024 taps (exact-f32 MFMA Toeplitz)", None
     if workload == "fir_fft":
-        from torchfx_amd import filter as F
-        m = F.FIR(fir.b, conv_mode="fft")               # the reference's DEFAULT FIR mode (fir.py:510,552): fft_conv1d
+        m = fir                                         # F.FIR(firwin(1024, ...)): conv_mode "fft" is the reference's DEFAULT (fir.py:510,552)
+        assert m._conv_mode == "fft"
         return (lambda: m(x)), "cfg3's filter through FIR.forward's default FFT mode: one-launch LDS-resident overlap-save, 1024 taps", None
     if workload == "fftconv":
         k = rev.kernel.reshape(-1)

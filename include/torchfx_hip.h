@@ -261,6 +261,13 @@ int tfx_ols_plan_info(int64_t K, int64_t T, int64_t pad_left, int64_t pad_right,
 int tfx_ols_plan_info2(int64_t K, int64_t T, int64_t pad_left, int64_t pad_right, int dtype,
                        int64_t *N, int64_t *S, int64_t *F, int *path);
 
+/* Start, on a helper thread, the one-time per-device set-up of the overlap-save path (kernel attributes = load of the
+ * library's code object, internal streams and events: 20-35 ms of driver time in the first call of a process) for the
+ * device current at the call; returns at once, the first overlap-save call waits for it.  Optional: a caller that has
+ * host work of its own before its first call (the Python planner merges taps, src/torchfx/wave.py:207-239 is the
+ * reference's counterpart) overlaps the two.  No reference counterpart; needs a device. */
+int tfx_prewarm(void);
+
 /* ---------------------------------------------------------------------------
  * tfx_delay_line_forward -- kept because the reference extension exports it
  * (binding.cpp:68-81,92-95; tests/test_ops_dispatch.py:29-35); out of the

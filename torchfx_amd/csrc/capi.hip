@@ -39,6 +39,7 @@ void fftconv_clear();
 void olsnative_clear();
 bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out);
 void olslds_clear();
+void olsnative_prewarm();
 bool olslds_supported(int64_t K, int64_t *N_out);
 void olslds_geometry(int64_t K, int64_t Tn, int64_t pl, int64_t pr, int elem_bytes, int64_t *lead_out, int64_t *S_out);
 // effects.hip
@@ -371,6 +372,13 @@ int tfx_ols_plan_info2(int64_t K, int64_t T, int64_t pad_left, int64_t pad_right
 {
     TFX_API_BEGIN
     ols_plan(K, T, pad_left, pad_right, dtype, N, S, F, path);
+    TFX_API_END
+}
+
+int tfx_prewarm(void)
+{
+    TFX_API_BEGIN
+    olsnative_prewarm();
     TFX_API_END
 }
 

@@ -32,8 +32,10 @@
 #include "../../include/torchfx_hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
+#include <future>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -684,50 +686,84 @@ static int64_t g_free_mb[TFX_MAX_DEVICES] = {};                  // per device: 
 static NativePlan *g_last_plan[TFX_MAX_DEVICES] = {};          // per device: the plan used last and its key
 static std::vector<char> g_last_key[TFX_MAX_DEVICES];
 
-// In-place radix-2 forward FFT in float64 (the spectrum of the taps, once per filter).  One twiddle table for all stages,
-// the butterflies of a stage split over a few host threads: a 2^20-point transform in ~15 ms instead of ~100 (it sits in
-// the latency of the first call with a new filter).
-static void host_fft(std::vector<double> &re, std::vector<double> &im)
+// Forward FFT in float64 of a real sequence of L samples zero-padded to n = 2^m points (the spectrum of the taps, once per
+// filter; it sits in the latency of the first call with a new filter).  One decimation-in-frequency step of radix R = 16
+// turns the transform into 16 INDEPENDENT n/16-point transforms
+//     X[16 m + r] = FFT_{n/16}( W_n^(n' r) * sum_q x[n' + (n/16) q] W_16^(q r) )[m],      q < ceil(L / (n/16)),
+// each run by its own host thread on 1 MB of data (n = 2^20) with no synchronisation between them; the zero padding prunes
+// the q sum to one or two terms.  2^20 points in ~4 ms instead of ~40 for the staged radix-2 with a thread fork per stage.
+static void fft_radix2_inplace(double *re, double *im, size_t n, const double *wr, const double *wi, size_t wstride)
 {
-    const size_t n = re.size();
     for (size_t i = 1, j = 0; i < n; ++i) {
         size_t bit = n >> 1;
         for (; j & bit; bit >>= 1) j ^= bit;
         j ^= bit;
         if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
     }
-    const size_t half_n = n / 2;
-    std::vector<double> wr(half_n ? half_n : 1), wi(half_n ? half_n : 1);
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const size_t half = len / 2, step = (n / len) * wstride;
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < half; ++k) {
+                const double cr = wr[k * step], ci = wi[k * step];
+                const size_t a = i + k, b = a + half;
+                const double vr = re[b] * cr - im[b] * ci, vi = re[b] * ci + im[b] * cr;
+                re[b] = re[a] - vr; im[b] = im[a] - vi;
+                re[a] += vr; im[a] += vi;
+            }
+    }
+}
+
+static void host_fft(std::vector<double> &re, std::vector<double> &im)
+{
+    const size_t n = re.size();
+    size_t L = n;                                  // support of the input: trailing zeros are pruned
+    while (L > 0 && re[L - 1] == 0.0 && im[L - 1] == 0.0) --L;
     const unsigned hw = std::thread::hardware_concurrency();
-    const size_t nthr = n >= (1u << 16) ? std::min<size_t>(8, hw ? hw : 1) : 1;
-    auto parallel = [&](size_t count, auto fn) {                 // fn(begin, end) over [0, count)
-        if (nthr <= 1 || count < 4096) { fn((size_t)0, count); return; }
-        std::vector<std::thread> th;
-        const size_t per = (count + nthr - 1) / nthr;
-        for (size_t t = 0; t < nthr; ++t) {
-            const size_t b0 = t * per, e0 = std::min(count, b0 + per);
-            if (b0 < e0) th.emplace_back([=, &fn] { fn(b0, e0); });
+    const size_t R = n >= 4096 ? 16 : 1;
+    const size_t nthr = R > 1 ? std::min<size_t>(R, hw ? hw : 1) : 1;
+    const size_t M = n / R, Q = (L + M - 1) / M;                 // sub-transform length, non-zero input blocks
+    std::vector<double> wr(M / 2 ? M / 2 : 1), wi(M / 2 ? M / 2 : 1);      // W_M^k, k < M / 2: contiguous, 512 KB at n = 2^20
+    for (size_t k = 0; k < M / 2; ++k) { const double a = -2.0 * M_PI * (double)k / (double)M; wr[k] = cos(a); wi[k] = sin(a); }
+    if (R == 1) { fft_radix2_inplace(re.data(), im.data(), n, wr.data(), wi.data(), 1); return; }
+    const std::vector<double> xr(re.begin(), re.begin() + (ptrdiff_t)std::min(n, Q * M)), xi(im.begin(), im.begin() + (ptrdiff_t)std::min(n, Q * M));
+    std::vector<std::vector<double>> Yr(R), Yi(R);
+    auto sub = [&](size_t r) {
+        std::vector<double> yr(M), yi(M);
+        double cq[16], sq[16];                                    // W_16^(q r)
+        for (size_t q = 0; q < Q; ++q) { const double a = -2.0 * M_PI * (double)((q * r) % R) / (double)R; cq[q] = cos(a); sq[q] = sin(a); }
+        std::vector<double> th_c((M + 255) / 256), th_s((M + 255) / 256), tl_c(256), tl_s(256);
+        for (size_t i = 0; i < th_c.size(); ++i) { const double a = -2.0 * M_PI * (double)((256 * i * r) & (n - 1)) / (double)n; th_c[i] = cos(a); th_s[i] = sin(a); }
+        for (size_t i = 0; i < 256; ++i) { const double a = -2.0 * M_PI * (double)((i * r) & (n - 1)) / (double)n; tl_c[i] = cos(a); tl_s[i] = sin(a); }
+        for (size_t np = 0; np < M; ++np) {
+            double ar = 0.0, ai = 0.0;
+            for (size_t q = 0; q < Q; ++q) {                      // sum_q x[n' + M q] W_16^(q r)
+                const double vr = xr[np + M * q], vi = xi[np + M * q];
+                ar += vr * cq[q] - vi * sq[q]; ai += vr * sq[q] + vi * cq[q];
+            }
+            // W_n^(n' r) = W_n^(256 (n' >> 8) r) * W_n^((n' & 255) r): two small exact tables, one product
+            const size_t hi_ = np >> 8, lo_ = np & 255;
+            const double c = th_c[hi_] * tl_c[lo_] - th_s[hi_] * tl_s[lo_], s_ = th_c[hi_] * tl_s[lo_] + th_s[hi_] * tl_c[lo_];
+            yr[np] = ar * c - ai * s_; yi[np] = ar * s_ + ai * c;
         }
+        fft_radix2_inplace(yr.data(), yi.data(), M, wr.data(), wi.data(), 1);
+        Yr[r].swap(yr); Yi[r].swap(yi);
+    };
+    // X[16 m + r] = Y_r[m]: interleaved by ranges of m (contiguous writes per thread -- writing with stride 16 from 16 threads
+    // makes every cache line bounce between all of them)
+    auto weave = [&](size_t part) {
+        const size_t m0 = M * part / R, m1 = M * (part + 1) / R;
+        for (size_t m = m0; m < m1; ++m)
+            for (size_t r = 0; r < R; ++r) { re[R * m + r] = Yr[r][m]; im[R * m + r] = Yi[r][m]; }
+    };
+    auto run = [&](auto &fn) {
+        if (nthr <= 1) { for (size_t r = 0; r < R; ++r) fn(r); return; }
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nthr; ++t)
+            th.emplace_back([=, &fn] { for (size_t r = t; r < R; r += nthr) fn(r); });
         for (auto &t : th) t.join();
     };
-    parallel(half_n, [&](size_t b0, size_t e0) {
-        for (size_t k = b0; k < e0; ++k) { const double a = -2.0 * M_PI * (double)k / (double)n; wr[k] = cos(a); wi[k] = sin(a); }
-    });
-    for (size_t len = 2; len <= n; len <<= 1) {
-        const size_t half = len / 2, step = n / len;
-        // butterfly index q in [0, n/2): block q / half, position k = q % half, twiddle W_n^(k * step)
-        parallel(half_n, [&](size_t b0, size_t e0) {
-            for (size_t q = b0; q < e0; ++q) {
-                const size_t k = q % half, i = (q / half) * len + k;
-                const double cr = wr[k * step], ci = wi[k * step];
-                const double ur = re[i], ui = im[i];
-                const double vr = re[i + half] * cr - im[i + half] * ci;
-                const double vi = re[i + half] * ci + im[i + half] * cr;
-                re[i] = ur + vr; im[i] = ui + vi;
-                re[i + half] = ur - vr; im[i + half] = ui - vi;
-            }
-        });
-    }
+    run(sub);
+    run(weave);
 }
 
 void host_fft_f64(std::vector<double> &re, std::vector<double> &im) { host_fft(re, im); }     // olslds.hip's spectra
@@ -748,6 +784,97 @@ static std::vector<cpx> twiddles(int64_t n, int64_t count, int64_t step)   // W_
     }
     return t;
 }
+
+static int64_t envi(const char *name, int64_t dflt)
+{
+    const char *e = getenv(name);
+    return (e && *e) ? atoll(e) : dflt;
+}
+
+// ---- per-device one-time set-up: kernel attributes (the first touch of a kernel loads the library's code object: 10-25 ms)
+// and the internal streams with their fork / join events (the first stream of a process costs ~5 ms each).  The first call
+// on a device runs this on a helper thread WHILE the calling thread computes the filter's spectrum on the host.
+typedef void (*colf_t)(const float *, cpx *, const cpx *, OlsGeom, int64_t);
+typedef void (*coli_t)(const cpx *, float *, const cpx *, OlsGeom, int64_t);
+typedef void (*row_t)(cpx *, const cpx *, const cpx *, const cpx *, const cpx *, const cpx *, const cpx *, const cpx *,
+                      int64_t, int, int64_t);
+static const colf_t colf_tab[2][4] = {
+    {ols_col_fwd16_kernel<2, 0>, ols_col_fwd16_kernel<2, 1>, ols_col_fwd16_kernel<2, 2>, ols_col_fwd16_kernel<2, 3>},
+    {ols_col_fwd16_kernel<1, 0>, ols_col_fwd16_kernel<1, 1>, ols_col_fwd16_kernel<1, 2>, ols_col_fwd16_kernel<1, 3>}};
+static const coli_t coli_tab[2][4] = {
+    {ols_col_inv16_kernel<2, 0>, ols_col_inv16_kernel<2, 1>, ols_col_inv16_kernel<2, 2>, ols_col_inv16_kernel<2, 3>},
+    {ols_col_inv16_kernel<1, 0>, ols_col_inv16_kernel<1, 1>, ols_col_inv16_kernel<1, 2>, ols_col_inv16_kernel<1, 3>}};
+static const row_t row_tab[6] = {ols_row4096_kernel<0, 0>, ols_row4096_kernel<1, 0>, ols_row4096_kernel<0, 1>, ols_row4096_kernel<1, 1>,
+                                 ols_row4096_kernel<0, 2>, ols_row4096_kernel<1, 2>};
+constexpr int MAXL = 8;
+struct Lanes {                      // internal streams and fork/join events of one device
+    hipStream_t stream[MAXL] = {};
+    hipEvent_t fork = nullptr, join[MAXL] = {};
+};
+static Lanes lanes_tab[TFX_MAX_DEVICES];
+static bool attr_tab[TFX_MAX_DEVICES] = {};
+// The lanes and their fork / join events are shared by every caller on the device.  A waiting stream takes the event's MOST
+// RECENT record, so "record the fork event on my stream, make the lanes wait for it" must not interleave with another host
+// thread's fork (its lanes would wait for the wrong stream's point); the join is safe either way (a later record on the same
+// lane is a superset) but takes the same lock.  Only these two short sections are serialised, not the launches.
+static std::mutex lane_mu;
+constexpr size_t OLS_SHM_COL = (size_t)(OLS_N1 * OLS_CB + 256) * sizeof(cpx);
+
+static std::mutex g_attr_mu;
+static void ols_set_attributes(int dev)
+{
+    std::lock_guard<std::mutex> lk(g_attr_mu);            // not the plan lock: this runs beside the spectrum computation
+    if (attr_tab[dev]) return;
+    for (int a = 0; a < 6; ++a)
+        TFX_HIP(hipFuncSetAttribute((const void *)row_tab[a], hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 4; ++b) {
+            TFX_HIP(hipFuncSetAttribute((const void *)colf_tab[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, (int)OLS_SHM_COL));
+            TFX_HIP(hipFuncSetAttribute((const void *)coli_tab[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, (int)OLS_SHM_COL));
+        }
+    attr_tab[dev] = true;
+}
+static void ols_make_lanes(int dev, int nlanes)           // lanes are created when first used
+{
+    std::lock_guard<std::mutex> fl(lane_mu);
+    Lanes &ln = lanes_tab[dev];
+    for (int i = 0; i < nlanes; ++i)
+        if (!ln.stream[i]) {
+            TFX_HIP(hipStreamCreateWithFlags(&ln.stream[i], hipStreamNonBlocking));
+            TFX_HIP(hipEventCreateWithFlags(&ln.join[i], hipEventDisableTiming));
+        }
+    if (!ln.fork) TFX_HIP(hipEventCreateWithFlags(&ln.fork, hipEventDisableTiming));
+}
+
+static std::mutex g_warm_mu;
+static std::shared_future<void> g_warm[TFX_MAX_DEVICES];
+void olsnative_prewarm()
+{
+    const int dev = current_device();
+    const int want_lanes = (int)std::min<int64_t>(MAXL, std::max<int64_t>(1, envi("TFX_OLS_STREAMS", 2)));
+    std::lock_guard<std::mutex> lk(g_warm_mu);
+    if (g_warm[dev].valid()) return;                         // started before (its result, or error, is kept)
+    if (attr_tab[dev] && (want_lanes <= 1 || lanes_tab[dev].stream[want_lanes - 1])) return;
+    g_warm[dev] = std::async(std::launch::async, [dev, want_lanes] {
+        TFX_HIP(hipSetDevice(dev));
+        ols_set_attributes(dev);
+        if (want_lanes > 1) ols_make_lanes(dev, want_lanes);
+    }).share();
+}
+
+// TFX_OLS_TRACE=1: host milliseconds of the set-up phases of a call on stderr (where the first call of a process goes)
+struct HostTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    HostTrace() : on(envi("TFX_OLS_TRACE", 0) != 0), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char *what)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[tfx ols] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
 
 static NativePlan *get_native_plan(const float *kf, int64_t K, int64_t N, int64_t lead)
 {
@@ -787,15 +914,32 @@ static NativePlan *get_native_plan(const float *kf, int64_t K, int64_t N, int64_
     // same convolution, but the causal left padding grows to K-1+lead, which lets the frames start
     // on 128-byte boundaries while the outputs stay unshifted
     for (int64_t i = 0; i < K; ++i) re[(size_t)(lead + i)] = (double)kf[i];
+    HostTrace tr;
     host_fft(re, im);
+    tr.mark("  spectrum: host FFT");
     std::vector<cpx> hp((size_t)N);
     const int N2 = pl->N2;
-    for (int k1 = 0; k1 < OLS_N1; ++k1)
-        for (int k2 = 0; k2 < N2; ++k2) {
-            const size_t k = (size_t)k1 + (size_t)OLS_N1 * (size_t)k2;
-            hp[(size_t)k1 * N2 + k2] = make_float2((float)(re[k] / (double)N), (float)(-im[k] / (double)N));
+    {
+        const double inv_n = 1.0 / (double)N;                  // exact: N is a power of two
+        auto rows = [&](int lo, int hi) {
+            for (int k1 = lo; k1 < hi; ++k1)
+                for (int k2 = 0; k2 < N2; ++k2) {
+                    const size_t k = (size_t)k1 + (size_t)OLS_N1 * (size_t)k2;
+                    hp[(size_t)k1 * N2 + k2] = make_float2((float)(re[k] * inv_n), (float)(-im[k] * inv_n));
+                }
+        };
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int nt = N >= (1 << 18) ? (int)std::min<unsigned>(16, hw ? hw : 1) : 1;
+        if (nt <= 1) rows(0, OLS_N1);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t) th.emplace_back(rows, OLS_N1 * t / nt, OLS_N1 * (t + 1) / nt);
+            for (auto &t : th) t.join();
         }
+    }
+    tr.mark("  spectrum: permute");
     pl->Hp = upload_cpx(hp);
+    tr.mark("  spectrum: upload");
     pl->tw256 = upload_cpx(twiddles(256, 256, 1));
     pl->twr = upload_cpx(twiddles(N2, N2, 1));
     pl->tlo = upload_cpx(twiddles(N, 512, 1));
@@ -812,6 +956,7 @@ static NativePlan *get_native_plan(const float *kf, int64_t K, int64_t N, int64_
         pl->t4lo = upload_cpx(ta);
     }
     pl->t4hi = upload_cpx(twiddles(4096, 64, 64));
+    tr.mark("  twiddle tables");
     g_nplans[key] = pl;
     last[dev_] = pl; last_key[dev_] = key;
     return pl;
@@ -830,11 +975,6 @@ void olsnative_clear()
     for (int d = 0; d < TFX_MAX_DEVICES; ++d) { g_last_plan[d] = nullptr; g_free_mb[d] = 0; }
 }
 
-static int64_t envi(const char *name, int64_t dflt)
-{
-    const char *e = getenv(name);
-    return (e && *e) ? atoll(e) : dflt;
-}
 
 // block sizes this path implements: N = 256 * N2, N2 in {256, 1024, 4096}
 bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out)
@@ -862,6 +1002,7 @@ bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out)
 void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const float *kf_host, int64_t K,
                        int64_t pl, int64_t pr, int64_t N, hipStream_t stream, const float *hist, int64_t H, const Epilogue *ep)
 {
+    HostTrace tr;
     // g_np_mu guards the plan cache, the one-time function attributes and the creation of the internal streams (the three
     // short sections below); the launches themselves are not serialised, so two host threads that drive two streams overlap
     // (each stream has its own scratch slabs; the internal lanes are shared and ordered by the fork / join events)
@@ -882,11 +1023,27 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     g.pad_left = pl + lead;
     g.S = N - (K + lead) + 1;
     if (align && g.S > 64) g.S -= g.S % 32;
-    NativePlan *plan;
-    {
+    const int dev = current_device();
+    // first call on this device: kernel attributes (code-object load) and the internal streams are set up on a helper thread
+    // while this thread computes the spectrum (both are tens of milliseconds, one bound by the driver, one by the host's cores);
+    // tfx_prewarm() starts the same helper earlier (the Python planner calls it before it merges taps)
+    olsnative_prewarm();
+    NativePlan *plan = nullptr;
+    std::exception_ptr plan_err;
+    try {
         std::lock_guard<std::mutex> lk(g_np_mu);
         plan = get_native_plan(kf_host, K, N, lead);
+    } catch (...) { plan_err = std::current_exception(); }
+    {
+        std::shared_future<void> w;
+        {
+            std::lock_guard<std::mutex> lk(g_warm_mu);
+            w = g_warm[dev];
+        }
+        if (w.valid()) w.get();                              // rethrows what the helper threw
     }
+    if (plan_err) std::rethrow_exception(plan_err);
+    tr.mark("plan (spectrum, tables)");
     g.F = ceil_div(g.Tout + g.out_shift, g.S);
     g.nframes = C * g.F; g.N2 = plan->N2;
     g.P2 = g.N2 + (int)envi("TFX_OLS_PITCH_PAD", 0);
@@ -899,7 +1056,6 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     // B and C find the slab pass A / B just wrote in the cache instead of in HBM and the whole step gains 8-11 % despite
     // the smaller launches -- cfg 4: 9.4-9.5 ms at 3 x 1 GB, 8.4-8.5 ms at 2 x 64 MB; 48 MB x 3 is as good, 4 lanes or
     // >= 128 MB slabs are not (profiles/r03_experiments.txt).  Default: 64 MB slabs on two lanes.
-    constexpr int MAXL = 8;
     int nlanes = (int)envi("TFX_OLS_STREAMS", 2);
     if (nlanes < 1) nlanes = 1;
     if (nlanes > MAXL) nlanes = MAXL;
@@ -933,79 +1089,42 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     }
     if (slab > npairs) slab = npairs;
     cpx *T = (cpx *)scratch("olsn_T", (size_t)slab * (size_t)OLS_N1 * (size_t)g.P2 * sizeof(cpx), stream);
-    const size_t shm_col = (size_t)(OLS_N1 * OLS_CB + 256) * sizeof(cpx);
+    tr.mark("workspace lane 0");
+    const size_t shm_col = OLS_SHM_COL;
     const size_t shm_row = (size_t)(g.N2 * 5) * sizeof(cpx);
     const int probe = (int)envi("TFX_OLS_PROBE", 0);           // development only (tools/ols_knobs.py)
     const int nbf = envi("TFX_OLS_COL_THREADS", 512) == 512 ? 1 : 2;
     // XCD-aware row map (1) pays when a slab holds many pairs per spectrum row; with cache-sized slabs the plain map is faster
     const int rowmap = (int)envi("TFX_OLS_ROWMAP", slab >= 32 ? 1 : 0);
-    typedef void (*colf_t)(const float *, cpx *, const cpx *, OlsGeom, int64_t);
-    typedef void (*coli_t)(const cpx *, float *, const cpx *, OlsGeom, int64_t);
-    typedef void (*row_t)(cpx *, const cpx *, const cpx *, const cpx *, const cpx *, const cpx *, const cpx *, const cpx *,
-                          int64_t, int, int64_t);
-    static const colf_t colf_tab[2][4] = {
-        {ols_col_fwd16_kernel<2, 0>, ols_col_fwd16_kernel<2, 1>, ols_col_fwd16_kernel<2, 2>, ols_col_fwd16_kernel<2, 3>},
-        {ols_col_fwd16_kernel<1, 0>, ols_col_fwd16_kernel<1, 1>, ols_col_fwd16_kernel<1, 2>, ols_col_fwd16_kernel<1, 3>}};
-    static const coli_t coli_tab[2][4] = {
-        {ols_col_inv16_kernel<2, 0>, ols_col_inv16_kernel<2, 1>, ols_col_inv16_kernel<2, 2>, ols_col_inv16_kernel<2, 3>},
-        {ols_col_inv16_kernel<1, 0>, ols_col_inv16_kernel<1, 1>, ols_col_inv16_kernel<1, 2>, ols_col_inv16_kernel<1, 3>}};
-    static const row_t row_tab[6] = {ols_row4096_kernel<0, 0>, ols_row4096_kernel<1, 0>, ols_row4096_kernel<0, 1>, ols_row4096_kernel<1, 1>,
-                                     ols_row4096_kernel<0, 2>, ols_row4096_kernel<1, 2>};
     const colf_t colf = colf_tab[nbf == 1][probe & 3];
     const coli_t coli = coli_tab[nbf == 1][probe & 3];
     const int xch = (int)envi("TFX_OLS_ROW_XCH", 2);
     const row_t rowk = row_tab[(rowmap == 0 ? 0 : 1) + 2 * (xch < 0 || xch > 2 ? 2 : xch)];
-    static bool attr_tab[TFX_MAX_DEVICES] = {};
-    const int dev = current_device();
-    bool &attr = attr_tab[dev];
-    std::unique_lock<std::mutex> init_lk(g_np_mu);
-    if (!attr) {
-        for (int a = 0; a < 6; ++a)
-            TFX_HIP(hipFuncSetAttribute((const void *)row_tab[a], hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
-        for (int a = 0; a < 2; ++a)
-            for (int b = 0; b < 4; ++b) {
-                TFX_HIP(hipFuncSetAttribute((const void *)colf_tab[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_col));
-                TFX_HIP(hipFuncSetAttribute((const void *)coli_tab[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_col));
-            }
-        attr = true;
-    }
-    init_lk.unlock();
+    ols_set_attributes(dev);
+    tr.mark("function attributes");
     const int ncb = g.N2 / OLS_CB;
     // Internal streams (TFX_OLS_STREAMS, default 2), slabs rotate over them: while one slab drains the tail of a pass
     // (the last, partially filled round of workgroups) the other slab's pass fills the idle CUs.
     // Fork/join with events on the caller's stream; each lane has its own workspace.
     if (npairs <= slab) nlanes = 1;
-    struct Lanes {                      // internal streams and fork/join events of one device
-        hipStream_t stream[MAXL] = {};
-        hipEvent_t fork = nullptr, join[MAXL] = {};
-    };
-    static Lanes lanes_tab[TFX_MAX_DEVICES];
     Lanes &ln_ = lanes_tab[dev];
     hipStream_t *lane_stream = ln_.stream;
     hipEvent_t &ev_fork = ln_.fork;
     hipEvent_t *ev_join = ln_.join;
     cpx *Tlane[MAXL] = {T, T, T, T, T, T, T, T};
     hipStream_t user_stream = stream;
-    // The lanes and their fork / join events are shared by every caller on the device.  A waiting stream takes the event's MOST
-    // RECENT record, so "record the fork event on my stream, make the lanes wait for it" must not interleave with another host
-    // thread's fork (its lanes would wait for the wrong stream's point); the join is safe either way (a later record on the same
-    // lane is a superset) but takes the same lock.  Only these two short sections are serialised, not the launches.
-    static std::mutex lane_mu;
     if (nlanes > 1) {
         static const char *tags[MAXL] = {"olsn_T", "olsn_T2", "olsn_T3", "olsn_T4", "olsn_T5", "olsn_T6", "olsn_T7", "olsn_T8"};
         for (int i = 1; i < nlanes; ++i)
             Tlane[i] = (cpx *)scratch(tags[i], (size_t)slab * (size_t)OLS_N1 * (size_t)g.P2 * sizeof(cpx), user_stream);
+        tr.mark("  lane workspaces");
+        ols_make_lanes(dev, nlanes);
+        tr.mark("  lane streams / events");
         std::lock_guard<std::mutex> fl(lane_mu);
-        if (!lane_stream[0]) {
-            for (int i = 0; i < MAXL; ++i) {
-                TFX_HIP(hipStreamCreateWithFlags(&lane_stream[i], hipStreamNonBlocking));
-                TFX_HIP(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
-            }
-            TFX_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        }
         TFX_HIP(hipEventRecord(ev_fork, user_stream));
         for (int i = 0; i < nlanes; ++i) TFX_HIP(hipStreamWaitEvent(lane_stream[i], ev_fork, 0));
     }
+    tr.mark("lanes, workspaces, fork");
     int64_t slab_idx = 0;
     for (int64_t p0 = 0; p0 < npairs; p0 += slab, ++slab_idx) {
         const int64_t np = (npairs - p0 < slab) ? (npairs - p0) : slab;
@@ -1046,6 +1165,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
             TFX_HIP(hipGetLastError());
         }
     }
+    tr.mark("launches");
     if (nlanes > 1) {
         std::lock_guard<std::mutex> jl(lane_mu);
         for (int i = 0; i < nlanes; ++i) {

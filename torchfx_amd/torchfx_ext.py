@@ -34,7 +34,7 @@ from torchfx_amd import native
 __all__ = [
     "biquad_forward", "sos_forward", "sos_bank_forward", "sos_bank_sum_forward", "delay_line_forward",
     "fir_direct_forward", "fft_conv_forward", "fir_stream_forward", "chunk_forward", "chunk_supported", "normalize_apply", "Epilogue", "sum_forward", "gain_forward", "quantile_abs", "stat_forward", "normalize_forward",
-    "deinterleave_forward", "interleave_forward", "sos_plan_info", "ols_plan_info",
+    "deinterleave_forward", "interleave_forward", "sos_plan_info", "ols_plan_info", "prewarm",
 ]
 
 
@@ -261,6 +261,16 @@ def sos_plan_info(sos) -> dict:
                                   ctypes.byref(prec), ctypes.byref(warm), ctypes.byref(eb)))
     return {"auto_precision": "f32" if prec.value == L.PREC_F32 else "f64",
             "warmup": warm.value, "f32_error_bound": eb.value}
+
+
+def prewarm(device=None) -> None:
+    """Start the one-time per-device set-up of the overlap-save path on a helper thread (``tfx_prewarm``); returns at once."""
+    lib = L.load()
+    if device is not None and torch.device(device).type == "cuda":
+        with torch.cuda.device(device):
+            L.check(lib.tfx_prewarm())
+    else:
+        L.check(lib.tfx_prewarm())
 
 
 def ols_plan_info(K: int, T: int, padding: tuple[int, int] = (0, 0), dtype: torch.dtype = torch.float32) -> dict:

@@ -259,6 +259,9 @@ class Wave:
         hit = _lru_get(_PLANS, key) if cacheable else None
         if hit is not None:
             return _instantiate(hit[1])
+        if self._ys.is_cuda and any(_plain_fir(m) for m in self._pipeline):
+            from torchfx_amd import torchfx_ext
+            torchfx_ext.prewarm(self._ys.device)     # the device-side one-time set-up runs while the taps are merged here
         built = self._build_plan(length, dtype)
         if cacheable:
             _lru_put(_PLANS, key, (guard, built))
