@@ -29,6 +29,7 @@
 // stored flipped kernel, output length T + l + r - K + 1.
 #include "common.h"
 #include "epilogue.h"
+#include "fftpk.h"
 #include "../../include/torchfx_hip.h"
 
 #include <algorithm>
@@ -122,10 +123,45 @@ __device__ __forceinline__ void dft16(cpx (&v)[16])
 // thread (col = tid & 31, q = tid >> 5) owns butterflies j = q + 8 i (i < 2) of its column, 16 rows
 // each (rows j + 16 t).  LDS: one [256][32] complex buffer (64 KB), one exchange per direction.
 // ---------------------------------------------------------------------------------------------
-template <bool INV, int NBF>
+// PK: the butterflies in packed arithmetic (fftpk.h: a 16-point DFT in 80 vector instructions instead of ~160, a twiddle
+// product in 2 instead of 4); the exchange and its addresses are the same.  TFX_OLS_PK=0 selects the compiler-scheduled form.
+template <bool INV, int NBF, bool PK>
 __device__ __forceinline__ void col_stages16(cpx (&v)[NBF][16], cpx *lds, const cpx *tw256, int col, int q)
 {
     constexpr int QS = 16 / NBF;               // butterfly j = q + QS * i
+    if (PK) {
+        using pk::v2f;
+        const v2f Wc = {0.92387953251128675613f, 0.38268343236508977173f}, Wr = {0.70710678118654752440f, 0.70710678118654752440f};
+        v2f *L = (v2f *)lds;
+        const v2f *TW = (const v2f *)tw256;
+#pragma unroll
+        for (int i = 0; i < NBF; ++i) {
+            v2f u[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) u[t] = __builtin_bit_cast(v2f, v[i][t]);
+            pk::pk_dft16<INV>(u, Wc, Wr);
+            const int j = q + QS * i;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) L[(16 * j + k) * OLS_CB + col] = u[PK_DFT16_AT(k)];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NBF; ++i) {
+            const int j = q + QS * i;
+            v2f d[16], w[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) d[t] = L[(j + 16 * t) * OLS_CB + col];
+#pragma unroll
+            for (int t = 1; t < 16; ++t) w[t] = TW[(t * j) & 255];
+            __builtin_amdgcn_sched_barrier(0);       // all reads are issued before the first product (asm consumers: the scheduler would sink them)
+#pragma unroll
+            for (int t = 1; t < 16; ++t) d[t] = pk::pk_cmul<INV>(d[t], w[t]);
+            pk::pk_dft16<INV>(d, Wc, Wr);          // natural-order output row j + 16 k sits at d[PK_DFT16_AT(k)]
+#pragma unroll
+            for (int t = 0; t < 16; ++t) v[i][t] = __builtin_bit_cast(cpx, d[t]);
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < NBF; ++i) {
         dft16<INV>(v[i]);
@@ -207,7 +243,7 @@ ols_col_fwd16_kernel(const float *__restrict__ x, cpx *__restrict__ T, const cpx
             }
     }
     __syncthreads();
-    if (PROBE == 0) col_stages16<false, NBF>(v, lds, tw256, col, q);
+    if (PROBE == 0 || PROBE == 4) col_stages16<false, NBF, PROBE == 0>(v, lds, tw256, col, q);
     cpx *Tp = T + pair * ((int64_t)OLS_N1 * g.P2);
     if (PROBE == 2) {
         float acc = 0.f;
@@ -254,7 +290,7 @@ ols_col_inv16_kernel(const cpx *__restrict__ T, float *__restrict__ y, const cpx
             for (int t = 0; t < 16; ++t) v[i][t] = Tp[(int64_t)(q + QS * i + 16 * t) * g.P2 + n2];
     }
     __syncthreads();
-    if (PROBE == 0) col_stages16<true, NBF>(v, lds, tw256, col, q);
+    if (PROBE == 0 || PROBE == 4) col_stages16<true, NBF, PROBE == 0>(v, lds, tw256, col, q);
 
     const int64_t fa = frame0 + 2 * pair, fb = fa + 1;
     const int64_t ca = fa / g.F, oa0 = (fa % g.F) * g.S;
@@ -646,6 +682,41 @@ ols_row4096_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *_
     const cpx wl = cmul(tlo[ml & 511], thi[ml >> 9]);
     {
         cpx *base = T + (p * OLS_N1 + k1) * P2;
+        if (XCH == 3) {
+            // packed arithmetic (fftpk.h): same exchange layout as XCH 1 / 2, the butterflies and products as v_pk_* with operand
+            // selectors: ~900 instead of 1420 vector instructions per wave and row
+            using pk::v2f;
+            const v2f Wc = {0.92387953251128675613f, 0.38268343236508977173f}, Wr = {0.70710678118654752440f, 0.70710678118654752440f};
+            v2f u[16], h[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) h[t] = ((const v2f *)base)[j + 256 * t];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const unsigned iu = 2u * ((unsigned)(k1 * t) & umask);
+                const cpx w = cmul(wl, make_float2(tuc[iu], tuc[iu + 1]));          // W_N^(k1 (j + 256 t))
+                u[t] = pk::pk_cmul<false>(h[t], __builtin_bit_cast(v2f, w));
+            }
+            pk::fft4096_pk<false>(u, (v2f *)lds, (const v2f *)twB, (const v2f *)twA, j, Wc, Wr);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) h[t] = ((const v2f *)hrow)[j + 256 * t];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) u[t] = pk::pk_cmul<false>(u[t], h[t]);
+            __builtin_amdgcn_sched_barrier(0);
+            pk::fft4096_pk<true>(u, (v2f *)lds, (const v2f *)twB, (const v2f *)twA, j, Wc, Wr);
+            float wlx = wl.x, wly = wl.y;
+            asm volatile("" : "+v"(wlx), "+v"(wly));
+            const cpx wl2 = make_float2(wlx, wly);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const unsigned iu = 2u * ((unsigned)(k1 * t) & umask);
+                const cpx w = cmul(wl2, make_float2(tuc[iu], tuc[iu + 1]));
+                ((v2f *)base)[j + 256 * t] = pk::pk_cmul<true>(u[t], __builtin_bit_cast(v2f, w));
+            }
+            return;
+        }
         cpx v[16];
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
@@ -653,12 +724,12 @@ ols_row4096_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *_
             const cpx ut = make_float2(tuc[iu], tuc[iu + 1]);
             v[t] = cmul(base[j + 256 * t], cmul(wl, ut));
         }
-        row_fft4096<false, XCH>(v, lds, twB, twA, j);
+        row_fft4096<false, XCH == 3 ? 2 : XCH>(v, lds, twB, twA, j);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 16; ++t) v[t] = cmul(v[t], hrow[j + 256 * t]);
         __builtin_amdgcn_sched_barrier(0);
-        row_fft4096<true, XCH>(v, lds, twB, twA, j);
+        row_fft4096<true, XCH == 3 ? 2 : XCH>(v, lds, twB, twA, j);
         float wlx = wl.x, wly = wl.y;
         asm volatile("" : "+v"(wlx), "+v"(wly));     // recompute, do not keep 16 twiddles live (see row1024)
         const cpx wl2 = make_float2(wlx, wly);
@@ -798,14 +869,14 @@ typedef void (*colf_t)(const float *, cpx *, const cpx *, OlsGeom, int64_t);
 typedef void (*coli_t)(const cpx *, float *, const cpx *, OlsGeom, int64_t);
 typedef void (*row_t)(cpx *, const cpx *, const cpx *, const cpx *, const cpx *, const cpx *, const cpx *, const cpx *,
                       int64_t, int, int64_t);
-static const colf_t colf_tab[2][4] = {
-    {ols_col_fwd16_kernel<2, 0>, ols_col_fwd16_kernel<2, 1>, ols_col_fwd16_kernel<2, 2>, ols_col_fwd16_kernel<2, 3>},
-    {ols_col_fwd16_kernel<1, 0>, ols_col_fwd16_kernel<1, 1>, ols_col_fwd16_kernel<1, 2>, ols_col_fwd16_kernel<1, 3>}};
-static const coli_t coli_tab[2][4] = {
-    {ols_col_inv16_kernel<2, 0>, ols_col_inv16_kernel<2, 1>, ols_col_inv16_kernel<2, 2>, ols_col_inv16_kernel<2, 3>},
-    {ols_col_inv16_kernel<1, 0>, ols_col_inv16_kernel<1, 1>, ols_col_inv16_kernel<1, 2>, ols_col_inv16_kernel<1, 3>}};
-static const row_t row_tab[6] = {ols_row4096_kernel<0, 0>, ols_row4096_kernel<1, 0>, ols_row4096_kernel<0, 1>, ols_row4096_kernel<1, 1>,
-                                 ols_row4096_kernel<0, 2>, ols_row4096_kernel<1, 2>};
+static const colf_t colf_tab[2][5] = {
+    {ols_col_fwd16_kernel<2, 0>, ols_col_fwd16_kernel<2, 1>, ols_col_fwd16_kernel<2, 2>, ols_col_fwd16_kernel<2, 3>, ols_col_fwd16_kernel<2, 4>},
+    {ols_col_fwd16_kernel<1, 0>, ols_col_fwd16_kernel<1, 1>, ols_col_fwd16_kernel<1, 2>, ols_col_fwd16_kernel<1, 3>, ols_col_fwd16_kernel<1, 4>}};
+static const coli_t coli_tab[2][5] = {
+    {ols_col_inv16_kernel<2, 0>, ols_col_inv16_kernel<2, 1>, ols_col_inv16_kernel<2, 2>, ols_col_inv16_kernel<2, 3>, ols_col_inv16_kernel<2, 4>},
+    {ols_col_inv16_kernel<1, 0>, ols_col_inv16_kernel<1, 1>, ols_col_inv16_kernel<1, 2>, ols_col_inv16_kernel<1, 3>, ols_col_inv16_kernel<1, 4>}};
+static const row_t row_tab[8] = {ols_row4096_kernel<0, 0>, ols_row4096_kernel<1, 0>, ols_row4096_kernel<0, 1>, ols_row4096_kernel<1, 1>,
+                                 ols_row4096_kernel<0, 2>, ols_row4096_kernel<1, 2>, ols_row4096_kernel<0, 3>, ols_row4096_kernel<1, 3>};
 constexpr int MAXL = 8;
 struct Lanes {                      // internal streams and fork/join events of one device
     hipStream_t stream[MAXL] = {};
@@ -825,10 +896,10 @@ static void ols_set_attributes(int dev)
 {
     std::lock_guard<std::mutex> lk(g_attr_mu);            // not the plan lock: this runs beside the spectrum computation
     if (attr_tab[dev]) return;
-    for (int a = 0; a < 6; ++a)
+    for (int a = 0; a < 8; ++a)
         TFX_HIP(hipFuncSetAttribute((const void *)row_tab[a], hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
     for (int a = 0; a < 2; ++a)
-        for (int b = 0; b < 4; ++b) {
+        for (int b = 0; b < 5; ++b) {
             TFX_HIP(hipFuncSetAttribute((const void *)colf_tab[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, (int)OLS_SHM_COL));
             TFX_HIP(hipFuncSetAttribute((const void *)coli_tab[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, (int)OLS_SHM_COL));
         }
@@ -1096,10 +1167,11 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     const int nbf = envi("TFX_OLS_COL_THREADS", 512) == 512 ? 1 : 2;
     // XCD-aware row map (1) pays when a slab holds many pairs per spectrum row; with cache-sized slabs the plain map is faster
     const int rowmap = (int)envi("TFX_OLS_ROWMAP", slab >= 32 ? 1 : 0);
-    const colf_t colf = colf_tab[nbf == 1][probe & 3];
-    const coli_t coli = coli_tab[nbf == 1][probe & 3];
-    const int xch = (int)envi("TFX_OLS_ROW_XCH", 2);
-    const row_t rowk = row_tab[(rowmap == 0 ? 0 : 1) + 2 * (xch < 0 || xch > 2 ? 2 : xch)];
+    const int colv = (probe & 3) ? (probe & 3) : (envi("TFX_OLS_PK", 1) ? 0 : 4);     // 4 = compiler-scheduled butterflies
+    const colf_t colf = colf_tab[nbf == 1][colv];
+    const coli_t coli = coli_tab[nbf == 1][colv];
+    const int xch = (int)envi("TFX_OLS_ROW_XCH", envi("TFX_OLS_PK", 1) ? 3 : 2);
+    const row_t rowk = row_tab[(rowmap == 0 ? 0 : 1) + 2 * (xch < 0 || xch > 3 ? 3 : xch)];
     ols_set_attributes(dev);
     tr.mark("function attributes");
     const int ncb = g.N2 / OLS_CB;
