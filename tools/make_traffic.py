@@ -38,7 +38,7 @@ def main() -> None:
                        "WRITE_SIZE in separate runs, tools/profile_gpu.sh). read = 2 x FETCH_SIZE (gfx950 tallies 64 B per 128-B request "
                        "for coalesced streams), write = WRITE_SIZE. Sources: profiles/%s_<workload>.{txt,json}." % tag,
            "source_digest": bench.source_digest()}
-    for wl in ("chain", "chain_iir_kernel", "sos", "fir", "fftconv"):
+    for wl in ("chain", "chain_iir_kernel", "sos", "fir", "fir_fft", "fftconv"):
         p = os.path.join(src, f"{tag}_{wl}.json")
         if not os.path.exists(p):
             continue
@@ -58,7 +58,7 @@ def main() -> None:
             if k in times:
                 e["avg_us_under_rocprofv3"] = round(times[k], 2)
         total = sum((e["read"] + e["write"]) * e["launches_per_step"] for e in per.values()) * 1e9
-        seconds = 60.0 if wl in ("sos", "fir") else 600.0
+        seconds = 60.0 if wl in ("sos", "fir", "fir_fft") else 600.0
         alg = 8.0 * 64 * seconds * 48000
         out[wl] = {"seconds": seconds, "bytes_per_step": round(total), "algorithmic_bytes_per_step": alg,
                    "traffic_over_algorithmic": round(total / alg, 3), "per_kernel_GB_per_launch": per}
