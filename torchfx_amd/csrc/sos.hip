@@ -69,6 +69,7 @@ struct SosParams {
     int *nf_flag;        // [C * nseg]: stream ended with a non-finite carried state (nseg > 1 only; every stream writes its slot)
     const void *ep_host; // host side only: the Epilogue this launch serves
     int ep_fused;        // host side only: the kernel applies it (else separate passes follow the launch)
+    int fair;            // > 0: waves that share a SIMD alternate their issue priority every 2^fair clocks
 };
 
 __device__ __forceinline__ void wave_sync()
@@ -150,6 +151,12 @@ __device__ __forceinline__ void sos_stream_body(const SosParams &p, const int64_
 
     const int K = p.K;
     if (sid >= p.C * p.nseg) return;                       // wave-uniform
+    unsigned slot_parity = 0;
+    if (p.fair) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        slot_parity = hw & 1u;                             // wave slot within the SIMD
+    }
     const int64_t c = sid / p.nseg;
     const int g = (int)(sid - c * p.nseg);
     const int nbl = SUMB ? p.nsum : 1;                     // bands handled inside this stream
@@ -269,6 +276,15 @@ __device__ __forceinline__ void sos_stream_body(const SosParams &p, const int64_
         const int64_t tband = SUMB ? bnd : band;
         TC *const carry_s = carry + bnd * K * 4;
         for (int s = 0; s < K; ++s) {
+            if (p.fair) {
+                // Fair share of the SIMD.  The waves of two workgroups share each SIMD for the whole launch, and the issue arbiter
+                // serves them by priority, then AGE: the older wave runs almost unimpeded, the younger one on the leftover slots
+                // (per-stream time stamps, round 4: the first wave of every SIMD finished after 251 us, the second after 347 us,
+                // the last 96 us with one wave per SIMD and half the issue rate).  Both waves read the same clock, and each takes
+                // the high priority in alternate epochs according to its slot parity, so they advance together and finish together.
+                const unsigned e = (unsigned)(__builtin_readcyclecounter() >> p.fair);
+                if ((e ^ slot_parity) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+            }
             const ctab_t tb = tab + (SUMB ? (int64_t)bnd * K * TS : 0) + s * TS;
             const TC b0 = tb[0], b1 = tb[1], b2 = tb[2], na1 = tb[3], na2 = tb[4];
             TC mqa[4], mqb[4];                  // P^(lane%16 + 1), P^(lane%32 + 1)
@@ -1117,6 +1133,7 @@ void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C_in,
     p.sx_in = sx_in; p.sy_in = sy_in; p.sx_out = sx_out; p.sy_out = sy_out;
     p.C = C; p.C_in = C_in; p.T = T; p.K = (int)K; p.x_pitch = T;
     p.nt = env_int("TFX_SOS_NT", 1);
+    p.fair = env_int("TFX_SOS_FAIR", 15);
     p.nsum = sum_bands ? (int)NB : 0;
     p.ep_gain = ep->gain; p.ep_scale = ep->scale; p.ep_clamp = ep->clamp; p.ep_stat = ep->stat_mode;
     p.ep_partial = nullptr; p.ep_host = ep;
