@@ -790,7 +790,7 @@ static void host_fft(std::vector<double> &re, std::vector<double> &im)
     size_t L = n;                                  // support of the input: trailing zeros are pruned
     while (L > 0 && re[L - 1] == 0.0 && im[L - 1] == 0.0) --L;
     const unsigned hw = std::thread::hardware_concurrency();
-    const size_t R = n >= 4096 ? 16 : 1;
+    const size_t R = n >= 65536 ? 16 : 1;                 // small transforms (the 4096-point spectra of olslds.hip): not worth the threads
     const size_t nthr = R > 1 ? std::min<size_t>(R, hw ? hw : 1) : 1;
     const size_t M = n / R, Q = (L + M - 1) / M;                 // sub-transform length, non-zero input blocks
     std::vector<double> wr(M / 2 ? M / 2 : 1), wi(M / 2 ? M / 2 : 1);      // W_M^k, k < M / 2: contiguous, 512 KB at n = 2^20
@@ -821,20 +821,28 @@ static void host_fft(std::vector<double> &re, std::vector<double> &im)
     };
     // X[16 m + r] = Y_r[m]: interleaved by ranges of m (contiguous writes per thread -- writing with stride 16 from 16 threads
     // makes every cache line bounce between all of them)
+    // real input (the taps): X[n - k] = conj(X[k]), i.e. sub-transform 16 - r is the mirrored conjugate of sub-transform r --
+    // nine of the sixteen are computed
+    bool real_in = true;
+    for (size_t i = 0; i < xi.size() && real_in; ++i) real_in = xi[i] == 0.0;
     auto weave = [&](size_t part) {
         const size_t m0 = M * part / R, m1 = M * (part + 1) / R;
         for (size_t m = m0; m < m1; ++m)
-            for (size_t r = 0; r < R; ++r) { re[R * m + r] = Yr[r][m]; im[R * m + r] = Yi[r][m]; }
+            for (size_t r = 0; r < R; ++r) {
+                if (real_in && r > R / 2) { re[R * m + r] = Yr[R - r][M - 1 - m]; im[R * m + r] = -Yi[R - r][M - 1 - m]; }
+                else { re[R * m + r] = Yr[r][m]; im[R * m + r] = Yi[r][m]; }
+            }
     };
-    auto run = [&](auto &fn) {
-        if (nthr <= 1) { for (size_t r = 0; r < R; ++r) fn(r); return; }
+    auto run = [&](auto &fn, size_t count) {
+        const size_t nt = std::min(nthr, count);
+        if (nt <= 1) { for (size_t r = 0; r < count; ++r) fn(r); return; }
         std::vector<std::thread> th;
-        for (size_t t = 0; t < nthr; ++t)
-            th.emplace_back([=, &fn] { for (size_t r = t; r < R; r += nthr) fn(r); });
+        for (size_t t = 0; t < nt; ++t)
+            th.emplace_back([=, &fn] { for (size_t r = t; r < count; r += nt) fn(r); });
         for (auto &t : th) t.join();
     };
-    run(sub);
-    run(weave);
+    run(sub, real_in ? R / 2 + 1 : R);
+    run(weave, R);
 }
 
 void host_fft_f64(std::vector<double> &re, std::vector<double> &im) { host_fft(re, im); }     // olslds.hip's spectra
