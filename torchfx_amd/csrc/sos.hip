@@ -70,6 +70,7 @@ struct SosParams {
     const void *ep_host; // host side only: the Epilogue this launch serves
     int ep_fused;        // host side only: the kernel applies it (else separate passes follow the launch)
     int fair;            // > 0: waves that share a SIMD alternate their issue priority every 2^fair clocks
+    int fair_nw;         // waves per SIMD of this launch (the priority levels that rotate): 2 ... 4
 };
 
 __device__ __forceinline__ void wave_sync()
@@ -151,11 +152,11 @@ __device__ __forceinline__ void sos_stream_body(const SosParams &p, const int64_
 
     const int K = p.K;
     if (sid >= p.C * p.nseg) return;                       // wave-uniform
-    unsigned slot_parity = 0;
+    unsigned wave_slot = 0;
     if (p.fair) {
         unsigned hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        slot_parity = hw & 1u;                             // wave slot within the SIMD
+        wave_slot = hw & 15u;                              // wave slot within the SIMD
     }
     const int64_t c = sid / p.nseg;
     const int g = (int)(sid - c * p.nseg);
@@ -281,9 +282,14 @@ __device__ __forceinline__ void sos_stream_body(const SosParams &p, const int64_
                 // serves them by priority, then AGE: the older wave runs almost unimpeded, the younger one on the leftover slots
                 // (per-stream time stamps, round 4: the first wave of every SIMD finished after 251 us, the second after 347 us,
                 // the last 96 us with one wave per SIMD and half the issue rate).  Both waves read the same clock, and each takes
-                // the high priority in alternate epochs according to its slot parity, so they advance together and finish together.
+                // the high priority in alternate epochs according to its slot, so they advance together and finish together.
+                // (more than two waves per SIMD: the priority levels 0 ... nw - 1 rotate over the slots, s_setprio has four)
                 const unsigned e = (unsigned)(__builtin_readcyclecounter() >> p.fair);
-                if ((e ^ slot_parity) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                const unsigned lvl = (e + wave_slot) % (unsigned)p.fair_nw;
+                if (lvl == 0) __builtin_amdgcn_s_setprio(0);
+                else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
+                else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
+                else __builtin_amdgcn_s_setprio(3);
             }
             const ctab_t tb = tab + (SUMB ? (int64_t)bnd * K * TS : 0) + s * TS;
             const TC b0 = tb[0], b1 = tb[1], b2 = tb[2], na1 = tb[3], na2 = tb[4];
@@ -988,6 +994,8 @@ static void launch_one(SosParams p, int64_t plan_warm, hipStream_t stream)
         blocks_shmem = shmem;
     }
     plan_segments(p, plan_warm, 64 * LC, blocks_per_cu * 4);
+    p.fair_nw = blocks_per_cu < 2 ? 1 : (blocks_per_cu > 4 ? 4 : blocks_per_cu);      // one wave of every resident workgroup per SIMD
+    if (p.fair_nw < 2) p.fair = 0;
     const int64_t nstreams = p.C * p.nseg;
     const unsigned grid = (unsigned)ceil_div(nstreams, 4);
     if (p.ep_stat >= 0) {                  // streams that have nothing to store leave their (zeroed) slot alone
