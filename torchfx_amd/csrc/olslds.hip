@@ -364,7 +364,7 @@ template <typename R> static Plan get_plan(const R *kf, int64_t K, int64_t lead)
     if (it == g_plans.end()) {
         if (g_plans.size() > 64) {
             (void)hipDeviceSynchronize();
-            for (auto &kv : g_plans) { (void)hipFree(kv.second.Hs); (void)hipFree(kv.second.tw256); (void)hipFree(kv.second.t4lo); }
+            for (auto &kv : g_plans) (void)hipFree(kv.second.Hs);
             g_plans.clear();
             for (int d = 0; d < TFX_MAX_DEVICES; ++d) { g_last_key[d] = nullptr; g_last[d] = nullptr; }
         }
@@ -388,10 +388,12 @@ template <typename R> static Plan get_plan(const R *kf, int64_t K, int64_t lead)
                 const double ang = -2.0 * M_PI * (double)(t * a2) / 4096.0;
                 t4[16 * t + a2].x = (R)cos(ang); t4[16 * t + a2].y = (R)sin(ang);
             }
-        Plan p;
+        Plan p;                                               // one allocation, one copy: spectrum | W256 | W4096 table
+        hs.insert(hs.end(), t256.begin(), t256.end());
+        hs.insert(hs.end(), t4.begin(), t4.end());
         p.Hs = upload<R>(hs);
-        p.tw256 = upload<R>(t256);
-        p.t4lo = upload<R>(t4);
+        p.tw256 = (char *)p.Hs + (size_t)LDS_N * sizeof(cx<R>);
+        p.t4lo = (char *)p.tw256 + 256 * sizeof(cx<R>);
         it = g_plans.emplace(std::move(key), p).first;
     }
     g_last_key[dev] = &it->first;
@@ -412,7 +414,7 @@ void olslds_clear()
     using namespace ldsfft;
     std::lock_guard<std::mutex> lk(g_mu);
     (void)hipDeviceSynchronize();
-    for (auto &kv : g_plans) { (void)hipFree(kv.second.Hs); (void)hipFree(kv.second.tw256); (void)hipFree(kv.second.t4lo); }
+    for (auto &kv : g_plans) (void)hipFree(kv.second.Hs);
     g_plans.clear();
     for (int d = 0; d < TFX_MAX_DEVICES; ++d) { g_last_key[d] = nullptr; g_last[d] = nullptr; }
 }

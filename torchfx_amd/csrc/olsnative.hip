@@ -743,6 +743,44 @@ ols_row4096_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *_
 }
 
 
+// The spectrum of a long kernel on the device (N = 2^20): the taps go through the forward column pass as a one-frame
+// "signal" (zero fill outside the taps) and then through this FORWARD-ONLY row pass, which leaves conj(X[k1 + 256 k2]) / N at
+// [k1][k2] -- exactly the layout and scaling the row pass multiplies by.  Replaces a float64 host FFT of 2^20 points
+// (4-40 ms of the first call with a new filter, depending on how many host cores the process gets) by two launches.
+__global__ void __launch_bounds__(256, 4)
+ols_rowspec4096_kernel(cpx *__restrict__ T, const cpx *__restrict__ tw256g, const cpx *__restrict__ t4log,
+                       const cpx *__restrict__ tlo, const cpx *__restrict__ thi, const cpx *__restrict__ tu,
+                       int64_t Nmask, int P2, float inv_n)
+{
+    using pk::v2f;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cpx *lds = (cpx *)smem;
+    cpx *twB = lds + 4096 + 256;
+    cpx *twA = twB + 256;
+    const int j = threadIdx.x;
+    twB[j] = tw256g[((j >> 4) * (j & 15)) & 255];
+    twA[j] = t4log[j];
+    typedef const float __attribute__((address_space(4))) *cfp;
+    const cfp tuc = (cfp)(uintptr_t)tu;
+    const unsigned umask = (unsigned)(Nmask >> 8);
+    const int k1 = (int)blockIdx.x;
+    __syncthreads();
+    const unsigned ml = (unsigned)(k1 * j);
+    const cpx wl = cmul(tlo[ml & 511], thi[ml >> 9]);
+    cpx *base = T + (int64_t)k1 * P2;
+    const v2f Wc = {0.92387953251128675613f, 0.38268343236508977173f}, Wr = {0.70710678118654752440f, 0.70710678118654752440f};
+    v2f u[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const unsigned iu = 2u * ((unsigned)(k1 * t) & umask);
+        const cpx w = cmul(wl, make_float2(tuc[iu], tuc[iu + 1]));
+        u[t] = pk::pk_cmul<false>(((const v2f *)base)[j + 256 * t], __builtin_bit_cast(v2f, w));
+    }
+    pk::fft4096_pk<false>(u, (v2f *)lds, (const v2f *)twB, (const v2f *)twA, j, Wc, Wr);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) base[j + 256 * t] = make_float2(u[t].x * inv_n, -u[t].y * inv_n);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host: plan (tables + permuted spectrum) cache and orchestration
 // ---------------------------------------------------------------------------------------------
@@ -750,6 +788,10 @@ struct NativePlan {
     int64_t N = 0, K = 0;
     int N2 = 0;
     cpx *Hp = nullptr, *tw256 = nullptr, *twr = nullptr, *tlo = nullptr, *thi = nullptr, *tu = nullptr, *t4lo = nullptr, *t4hi = nullptr;
+    float *taps_dev = nullptr;      // device copy of the taps while the spectrum kernels may still read it (N = 2^20)
+    cpx *tables = nullptr;          // the one allocation tw256 ... t4hi point into
+    hipEvent_t ready = nullptr;     // recorded behind the spectrum kernels: other streams wait for it before they read Hp
+    hipStream_t ready_stream = nullptr;
 };
 static std::mutex g_np_mu;
 static std::map<std::vector<char>, NativePlan *> g_nplans;
@@ -955,7 +997,7 @@ struct HostTrace {
     }
 };
 
-static NativePlan *get_native_plan(const float *kf, int64_t K, int64_t N, int64_t lead)
+static NativePlan *get_native_plan(const float *kf, int64_t K, int64_t N, int64_t lead, hipStream_t stream)
 {
     // steady state (the same filter call after call, e.g. streaming chunks): one memcmp against the plan
     // used last, no key construction
@@ -980,62 +1022,95 @@ static NativePlan *get_native_plan(const float *kf, int64_t K, int64_t N, int64_
         (void)hipDeviceSynchronize();
         for (auto &kv : g_nplans) {
             NativePlan *p = kv.second;
-            for (cpx *q : {p->Hp, p->tw256, p->twr, p->tlo, p->thi, p->tu, p->t4lo, p->t4hi}) if (q) (void)hipFree(q);
+            for (cpx *q : {p->Hp, p->tables}) if (q) (void)hipFree(q);
+            if (p->taps_dev) (void)hipFree(p->taps_dev);
+            if (p->ready) (void)hipEventDestroy(p->ready);
             delete p;
         }
         g_nplans.clear();
     }
     NativePlan *pl = new NativePlan();
     pl->N = N; pl->K = K; pl->N2 = (int)(N / OLS_N1);
-    // spectrum in float64: conj(FFT(kf zero-padded)) / N   (_fftconv.py:123-124,131 + irfft scaling)
-    std::vector<double> re((size_t)N, 0.0), im((size_t)N, 0.0);
-    // `lead` zeros in front of the flipped taps (= trailing zeros of the true impulse response):
-    // same convolution, but the causal left padding grows to K-1+lead, which lets the frames start
-    // on 128-byte boundaries while the outputs stay unshifted
-    for (int64_t i = 0; i < K; ++i) re[(size_t)(lead + i)] = (double)kf[i];
     HostTrace tr;
-    host_fft(re, im);
-    tr.mark("  spectrum: host FFT");
-    std::vector<cpx> hp((size_t)N);
     const int N2 = pl->N2;
-    {
-        const double inv_n = 1.0 / (double)N;                  // exact: N is a power of two
-        auto rows = [&](int lo, int hi) {
-            for (int k1 = lo; k1 < hi; ++k1)
-                for (int k2 = 0; k2 < N2; ++k2) {
-                    const size_t k = (size_t)k1 + (size_t)OLS_N1 * (size_t)k2;
-                    hp[(size_t)k1 * N2 + k2] = make_float2((float)(re[k] * inv_n), (float)(-im[k] * inv_n));
-                }
-        };
-        const unsigned hw = std::thread::hardware_concurrency();
-        const int nt = N >= (1 << 18) ? (int)std::min<unsigned>(16, hw ? hw : 1) : 1;
-        if (nt <= 1) rows(0, OLS_N1);
-        else {
-            std::vector<std::thread> th;
-            for (int t = 0; t < nt; ++t) th.emplace_back(rows, OLS_N1 * t / nt, OLS_N1 * (t + 1) / nt);
-            for (auto &t : th) t.join();
+    const bool dev_spectrum = N2 == 4096 && envi("TFX_OLS_GPU_SPECTRUM", 1) != 0;
+    if (!dev_spectrum) {
+        // spectrum in float64 on the host: conj(FFT(kf zero-padded)) / N   (_fftconv.py:123-124,131 + irfft scaling)
+        std::vector<double> re((size_t)N, 0.0), im((size_t)N, 0.0);
+        // `lead` zeros in front of the flipped taps (= trailing zeros of the true impulse response):
+        // same convolution, but the causal left padding grows to K-1+lead, which lets the frames start
+        // on 128-byte boundaries while the outputs stay unshifted
+        for (int64_t i = 0; i < K; ++i) re[(size_t)(lead + i)] = (double)kf[i];
+        host_fft(re, im);
+        tr.mark("  spectrum: host FFT");
+        std::vector<cpx> hp((size_t)N);
+        {
+            const double inv_n = 1.0 / (double)N;                  // exact: N is a power of two
+            auto rows = [&](int lo, int hi) {
+                for (int k1 = lo; k1 < hi; ++k1)
+                    for (int k2 = 0; k2 < N2; ++k2) {
+                        const size_t k = (size_t)k1 + (size_t)OLS_N1 * (size_t)k2;
+                        hp[(size_t)k1 * N2 + k2] = make_float2((float)(re[k] * inv_n), (float)(-im[k] * inv_n));
+                    }
+            };
+            const unsigned hw = std::thread::hardware_concurrency();
+            const int nt = N >= (1 << 18) ? (int)std::min<unsigned>(16, hw ? hw : 1) : 1;
+            if (nt <= 1) rows(0, OLS_N1);
+            else {
+                std::vector<std::thread> th;
+                for (int t = 0; t < nt; ++t) th.emplace_back(rows, OLS_N1 * t / nt, OLS_N1 * (t + 1) / nt);
+                for (auto &t : th) t.join();
+            }
         }
+        tr.mark("  spectrum: permute");
+        pl->Hp = upload_cpx(hp);
+        tr.mark("  spectrum: upload");
     }
-    tr.mark("  spectrum: permute");
-    pl->Hp = upload_cpx(hp);
-    tr.mark("  spectrum: upload");
-    pl->tw256 = upload_cpx(twiddles(256, 256, 1));
-    pl->twr = upload_cpx(twiddles(N2, N2, 1));
-    pl->tlo = upload_cpx(twiddles(N, 512, 1));
-    pl->thi = upload_cpx(twiddles(N, N / 512, 512));
-    // row-uniform factors: W_N^(64 i) for the 1024-point rows, W_N^(256 i) for the 4096-point rows
-    pl->tu = (N2 == 4096) ? upload_cpx(twiddles(N, N / 256, 256)) : upload_cpx(twiddles(N, N / 64, 64));
-    {   // twA[16 t + a] = W4096^(t a)
-        std::vector<cpx> ta(256);
+    {
+        // all twiddle tables in ONE allocation and ONE copy (eight hipMalloc + hipMemcpy pairs cost 7-9 ms of the first call)
+        std::vector<cpx> ta(256);                        // twA[16 t + a] = W4096^(t a)
         for (int t = 0; t < 16; ++t)
             for (int a2 = 0; a2 < 16; ++a2) {
                 const double ang = -2.0 * M_PI * (double)(t * a2) / 4096.0;
                 ta[16 * t + a2] = make_float2((float)cos(ang), (float)sin(ang));
             }
-        pl->t4lo = upload_cpx(ta);
+        // row-uniform factors: W_N^(64 i) for the 1024-point rows, W_N^(256 i) for the 4096-point rows
+        const std::vector<cpx> parts[7] = {twiddles(256, 256, 1), twiddles(N2, N2, 1), twiddles(N, 512, 1), twiddles(N, N / 512, 512),
+                                           (N2 == 4096) ? twiddles(N, N / 256, 256) : twiddles(N, N / 64, 64), ta, twiddles(4096, 64, 64)};
+        cpx **slots[7] = {&pl->tw256, &pl->twr, &pl->tlo, &pl->thi, &pl->tu, &pl->t4lo, &pl->t4hi};
+        std::vector<cpx> all;
+        size_t off[7];
+        for (int i = 0; i < 7; ++i) {
+            off[i] = all.size();
+            all.insert(all.end(), parts[i].begin(), parts[i].end());
+            all.resize((all.size() + 31) & ~(size_t)31);          // 256-byte aligned sub-tables
+        }
+        cpx *basep = upload_cpx(all);
+        for (int i = 0; i < 7; ++i) *slots[i] = basep + off[i];
+        pl->tables = basep;
     }
-    pl->t4hi = upload_cpx(twiddles(4096, 64, 64));
     tr.mark("  twiddle tables");
+    if (dev_spectrum) {
+        // N = 2^20: the spectrum is computed by the pipeline's own kernels on the caller's stream (see ols_rowspec4096_kernel)
+        TFX_HIP(hipMalloc((void **)&pl->taps_dev, (size_t)K * sizeof(float)));
+        TFX_HIP(hipMemcpy(pl->taps_dev, kf, (size_t)K * sizeof(float), hipMemcpyHostToDevice));
+        TFX_HIP(hipMalloc((void **)&pl->Hp, (size_t)N * sizeof(cpx)));
+        ols_set_attributes(current_device());                 // the column pass needs more than 64 KB of dynamic LDS
+        OlsGeom g{};
+        g.Tn = K; g.Tout = K; g.F = 1; g.S = N; g.pad_left = lead; g.out_shift = 0; g.nframes = 1;
+        g.hist = nullptr; g.H = 0; g.ep_gain = 1.0f; g.ep_scale = 0; g.ep_clamp = 0; g.ep_stat = -1; g.ep_partial = nullptr;
+        g.N2 = N2; g.P2 = N2;
+        hipLaunchKernelGGL(colf_tab[1][0], dim3((unsigned)(N2 / OLS_CB)), dim3(512), OLS_SHM_COL, stream,
+                           (const float *)pl->taps_dev, pl->Hp, pl->tw256, g, (int64_t)0);
+        TFX_HIP(hipGetLastError());
+        hipLaunchKernelGGL(ols_rowspec4096_kernel, dim3(OLS_N1), dim3(256), (size_t)(4096 + 256 + 512) * sizeof(cpx), stream,
+                           pl->Hp, pl->tw256, pl->t4lo, pl->tlo, pl->thi, pl->tu, N - 1, N2, (float)(1.0 / (double)N));
+        TFX_HIP(hipGetLastError());
+        TFX_HIP(hipEventCreateWithFlags(&pl->ready, hipEventDisableTiming));
+        TFX_HIP(hipEventRecord(pl->ready, stream));
+        pl->ready_stream = stream;
+        tr.mark("  spectrum: device (2 launches)");
+    }
     g_nplans[key] = pl;
     last[dev_] = pl; last_key[dev_] = key;
     return pl;
@@ -1047,7 +1122,9 @@ void olsnative_clear()
     (void)hipDeviceSynchronize();
     for (auto &kv : g_nplans) {
         NativePlan *p = kv.second;
-        for (cpx *q : {p->Hp, p->tw256, p->twr, p->tlo, p->thi, p->tu, p->t4lo, p->t4hi}) if (q) (void)hipFree(q);
+        for (cpx *q : {p->Hp, p->tables}) if (q) (void)hipFree(q);
+        if (p->taps_dev) (void)hipFree(p->taps_dev);
+        if (p->ready) (void)hipEventDestroy(p->ready);
         delete p;
     }
     g_nplans.clear();
@@ -1111,7 +1188,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     std::exception_ptr plan_err;
     try {
         std::lock_guard<std::mutex> lk(g_np_mu);
-        plan = get_native_plan(kf_host, K, N, lead);
+        plan = get_native_plan(kf_host, K, N, lead, stream);
     } catch (...) { plan_err = std::current_exception(); }
     {
         std::shared_future<void> w;
@@ -1122,6 +1199,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
         if (w.valid()) w.get();                              // rethrows what the helper threw
     }
     if (plan_err) std::rethrow_exception(plan_err);
+    if (plan->ready && plan->ready_stream != stream) TFX_HIP(hipStreamWaitEvent(stream, plan->ready, 0));   // spectrum computed on another stream
     tr.mark("plan (spectrum, tables)");
     g.F = ceil_div(g.Tout + g.out_shift, g.S);
     g.nframes = C * g.F; g.N2 = plan->N2;

@@ -33,7 +33,26 @@ def load():
                 raise RuntimeError(
                     "torchfx_amd: the compiled extension torchfx_amd/native/torchfx_ext*.so is missing or does not load "
                     f"({e}); build it with `python __graft_entry__.py` (make -C torchfx_amd/csrc).") from e
+            _prewarm()
     return _mod
+
+
+def _prewarm() -> None:
+    """With a ROCm device present, start the library's one-time device set-up (load of its code object, internal streams)
+    on a helper thread as soon as the module is loaded (`tfx_prewarm`): it costs 20-80 ms of driver time that would otherwise
+    sit in the first filter call.  Best effort; `TORCHFX_AMD_PREWARM=0` turns it off."""
+    import os
+
+    import torch
+
+    if os.environ.get("TORCHFX_AMD_PREWARM", "1") == "0" or not torch.cuda.is_available():
+        return
+    try:
+        from torchfx_amd import _lib
+
+        _lib.load().tfx_prewarm()
+    except Exception:           # never a reason to fail an import
+        pass
 
 
 def ops():
