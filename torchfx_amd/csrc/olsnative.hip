@@ -433,6 +433,92 @@ ols_row_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *__res
 }
 
 // ---------------------------------------------------------------------------------------------
+// Row pass B, N2 = 256 (N = 2^16: 2048 < K <= 16384), packed arithmetic (fftpk.h): SIXTEEN LANES per row, four rows per
+// wavefront; lane i of a row holds n2 = i + 16 t, so both radix-16 stages of a direction run in registers and a direction
+// needs ONE exchange -- a 16 x 16 transposition inside the 16-lane group through a wave-local LDS tile (stride 17: conflict-free
+// both ways), no workgroup barrier (the radix-4 kernel above: one row per wavefront, four exchanges per direction).
+//   forward   lane i: DFT over t -> A[k0], * W256^(i k0), transpose -> lane k0 holds A_i[k0] over i, DFT over i -> X[k0 + 16 k1]
+//   inverse   lane k0: DFT over k1 -> m0, * conj W256^(k0 m0), transpose -> lane m0, DFT over k0 -> x[m0 + 16 m1]
+// The lane's fifteen W256^(i k) are registers for the whole launch (workgroups walk the rows with a grid stride); the four-step
+// factors W_N^(k1 (i + 16 t)) = W_N^(k1 i) (W_N^(16 k1))^t come from two table look-ups and a depth-4 product tree.
+__global__ void __launch_bounds__(256, 3)
+ols_row256pk_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *__restrict__ tw256g,
+                    const cpx *__restrict__ tlo, const cpx *__restrict__ thi, int64_t nrows, int P2)
+{
+    using pk::v2f;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, r = lane >> 4;
+    v2f *L = (v2f *)smem + (wave * 4 + r) * 272;               // this row's 16 x 17 tile
+    const v2f Wc = {0.92387953251128675613f, 0.38268343236508977173f}, Wr = {0.70710678118654752440f, 0.70710678118654752440f};
+    v2f tw[16];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) tw[k] = ((const v2f *)tw256g)[(i * k) & 255];
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * 4; row0 < nrows; row0 += (int64_t)gridDim.x * 16) {
+        const int64_t row = row0 + r;
+        const bool live = row < nrows;
+        const int k1 = (int)((live ? row : 0) % OLS_N1);
+        v2f *base = (v2f *)(T + (live ? row : 0) * P2);
+        const v2f *hrow = (const v2f *)(Hp + (int64_t)k1 * 256);
+        v2f w[16];
+        {   // w[t] = W_N^(k1 i) * s^t, s = W_N^(16 k1), N = 65536
+            const unsigned ma = (unsigned)(k1 * i), mb = (unsigned)(16 * k1);
+            const v2f wl = pk::pk_cmul<false>(((const v2f *)tlo)[ma & 511], ((const v2f *)thi)[ma >> 9]);
+            v2f u[16];
+            u[1] = pk::pk_cmul<false>(((const v2f *)tlo)[mb & 511], ((const v2f *)thi)[mb >> 9]);
+            u[2] = pk::pk_cmul<false>(u[1], u[1]);
+            u[3] = pk::pk_cmul<false>(u[2], u[1]);
+            u[4] = pk::pk_cmul<false>(u[2], u[2]);
+            u[5] = pk::pk_cmul<false>(u[4], u[1]);
+            u[6] = pk::pk_cmul<false>(u[4], u[2]);
+            u[7] = pk::pk_cmul<false>(u[4], u[3]);
+            u[8] = pk::pk_cmul<false>(u[4], u[4]);
+#pragma unroll
+            for (int t = 9; t < 16; ++t) u[t] = pk::pk_cmul<false>(u[8], u[t - 8]);
+            w[0] = wl;
+#pragma unroll
+            for (int t = 1; t < 16; ++t) w[t] = pk::pk_cmul<false>(wl, u[t]);
+        }
+        v2f v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = live ? base[i + 16 * t] : v2f{0.f, 0.f};
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = pk::pk_cmul<false>(v[t], w[t]);
+        // ---- forward
+        pk::pk_dft16<false>(v, Wc, Wr);
+        L[17 * i] = v[PK_DFT16_AT(0)];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) L[17 * i + k] = pk::pk_cmul<false>(v[PK_DFT16_AT(k)], tw[k]);
+        wave_sync2();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = L[17 * t + i];
+        wave_sync2();
+        pk::pk_dft16<false>(v, Wc, Wr);                        // X[i + 16 k] at v[PK_DFT16_AT(k)]
+        v2f h[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) h[k] = hrow[i + 16 * k];
+        __builtin_amdgcn_sched_barrier(0);
+        v2f z[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) z[k] = pk::pk_cmul<false>(v[PK_DFT16_AT(k)], h[k]);
+        // ---- inverse
+        pk::pk_dft16<true>(z, Wc, Wr);
+        L[17 * i] = z[PK_DFT16_AT(0)];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) L[17 * i + k] = pk::pk_cmul<true>(z[PK_DFT16_AT(k)], tw[k]);
+        wave_sync2();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) z[t] = L[17 * t + i];
+        wave_sync2();
+        pk::pk_dft16<true>(z, Wc, Wr);                         // x[i + 16 m] at z[PK_DFT16_AT(m)]
+        if (live) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) base[i + 16 * t] = pk::pk_cmul<true>(z[PK_DFT16_AT(t)], w[t]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Row pass B, N2 = 1024, radix (16, 16, 4) Stockham: the lane's 16 elements  n2 = lane + 64 t  are
 // exactly the inputs of one radix-16 butterfly, so two of the three stages run in registers and a
 // direction needs only two LDS exchanges (the radix-4 version above needs four).  LDS positions
@@ -484,6 +570,56 @@ __device__ __forceinline__ void row_fft1024(cpx (&v)[16], cpx *lds, const cpx *t
     wave_sync2();
 }
 
+// the same wavefront transform in packed arithmetic (fftpk.h): in: v[t] = element lane + 64 t, out: the same arrangement
+template <bool INV>
+__device__ __forceinline__ void row_fft1024_pk(pk::v2f (&v)[16], pk::v2f *lds, const pk::v2f *twr, int lane, pk::v2f Wc, pk::v2f Wr)
+{
+    using pk::v2f;
+    pk::pk_dft16<INV>(v, Wc, Wr);                              // stage A: radix 16, Ns = 1
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[pad16(16 * lane + k)] = v[PK_DFT16_AT(k)];
+    wave_sync2();
+    const int kb = lane & 15;
+    {                                                          // stage B: inputs lane + 64 t, twiddle W256^(t k) = W1024^(4 t k)
+        v2f d[16], w[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) d[t] = lds[pad16(lane + 64 * t)];
+#pragma unroll
+        for (int t = 1; t < 16; ++t) w[t] = twr[(4 * t * kb) & 1023];
+        __builtin_amdgcn_sched_barrier(0);
+        v[0] = d[0];
+#pragma unroll
+        for (int t = 1; t < 16; ++t) v[t] = pk::pk_cmul<INV>(d[t], w[t]);
+    }
+    wave_sync2();
+    pk::pk_dft16<INV>(v, Wc, Wr);
+    const int j0 = (lane >> 4) * 256 + kb;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[pad16(j0 + 16 * k)] = v[PK_DFT16_AT(k)];
+    wave_sync2();
+    {                                                          // stage C: radix 4, butterflies j = lane + 64 i, inputs j + 256 r
+        v2f d[16], w[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                d[i + 4 * r] = lds[pad16(lane + 64 * i + 256 * r)];
+                if (r > 0) w[i + 4 * r] = twr[(r * (lane + 64 * i)) & 1023];
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 1; r < 4; ++r) d[i + 4 * r] = pk::pk_cmul<INV>(d[i + 4 * r], w[i + 4 * r]);
+            pk::pk_dft4<INV, false>(d[i], d[i + 4], d[i + 8], d[i + 12]);      // outputs j + 256 r -> t = i + 4 r
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = d[t];
+    }
+    wave_sync2();
+}
+
+template <bool PK>
 __global__ void __launch_bounds__(256, 3)
 ols_row1024_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *__restrict__ twrg,
                    const cpx *__restrict__ tlo, const cpx *__restrict__ thi, const cpx *__restrict__ tu,
@@ -508,6 +644,39 @@ ols_row1024_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *_
     // W_N^(k1 n2), n2 = lane + 64 t  =  W_N^(k1 lane) * W_N^(64 k1 t)
     const unsigned ml = (unsigned)(k1 * lane);
     const cpx wl = cmul(tlo[ml & 511], thi[ml >> 9]);
+    if (PK) {
+        using pk::v2f;
+        const v2f Wc = {0.92387953251128675613f, 0.38268343236508977173f}, Wr = {0.70710678118654752440f, 0.70710678118654752440f};
+        v2f u[16], h[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) h[t] = ((const v2f *)base)[lane + 64 * t];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const unsigned iu = 2u * ((unsigned)(k1 * t) & (unsigned)(Nmask >> 6));
+            const cpx w = cmul(wl, make_float2(tuc[iu], tuc[iu + 1]));
+            u[t] = pk::pk_cmul<false>(h[t], __builtin_bit_cast(v2f, w));
+        }
+        row_fft1024_pk<false>(u, (v2f *)lds, (const v2f *)twr, lane, Wc, Wr);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) h[t] = ((const v2f *)hrow)[lane + 64 * t];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) u[t] = pk::pk_cmul<false>(u[t], h[t]);
+        __builtin_amdgcn_sched_barrier(0);
+        row_fft1024_pk<true>(u, (v2f *)lds, (const v2f *)twr, lane, Wc, Wr);
+        float wlx = wl.x, wly = wl.y;
+        asm volatile("" : "+v"(wlx), "+v"(wly));
+        const cpx wl2 = make_float2(wlx, wly);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const unsigned iu = 2u * ((unsigned)(k1 * t) & (unsigned)(Nmask >> 6));
+            const cpx w = cmul(wl2, make_float2(tuc[iu], tuc[iu + 1]));
+            ((v2f *)base)[lane + 64 * t] = pk::pk_cmul<true>(u[t], __builtin_bit_cast(v2f, w));
+        }
+        return;
+    }
     cpx v[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
@@ -1305,13 +1474,18 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
             } else if (g.N2 == 4096) {
             }
             else if (g.N2 == 1024 && envi("TFX_OLS_ROW_R4", 0) == 0)
-                hipLaunchKernelGGL(ols_row1024_kernel, dim3((unsigned)ceil_div(nrows, 4)), dim3(256),
+                hipLaunchKernelGGL(envi("TFX_OLS_PK", 1) ? ols_row1024_kernel<true> : ols_row1024_kernel<false>, dim3((unsigned)ceil_div(nrows, 4)), dim3(256),
                                    (size_t)(1024 + 4 * (1024 + 64)) * sizeof(cpx), stream,
                                    T, plan->Hp, plan->twr, plan->tlo, plan->thi, plan->tu, nrows, N - 1, g.P2);
             else if (g.N2 == 1024)
                 hipLaunchKernelGGL(ols_row_kernel<5>, dim3((unsigned)ceil_div(nrows, 4)), dim3(256), shm_row, stream,
                                    T, plan->Hp, plan->twr, plan->tlo, plan->thi, nrows, g.P2);
-            else
+            else if (envi("TFX_OLS_PK", 1) != 0 && envi("TFX_OLS_ROW_R4", 0) == 0) {
+                const int64_t groups = ceil_div(nrows, 16);
+                const int64_t cap = 8 * 256 * 3;                 // a few rounds of resident workgroups: the lane twiddles are loaded once per workgroup
+                hipLaunchKernelGGL(ols_row256pk_kernel, dim3((unsigned)std::min(groups, cap)), dim3(256), (size_t)16 * 272 * sizeof(cpx), stream,
+                                   T, plan->Hp, plan->tw256, plan->tlo, plan->thi, nrows, g.P2);
+            } else
                 hipLaunchKernelGGL(ols_row_kernel<4>, dim3((unsigned)ceil_div(nrows, 4)), dim3(256), shm_row, stream,
                                    T, plan->Hp, plan->twr, plan->tlo, plan->thi, nrows, g.P2);
             TFX_HIP(hipGetLastError());
