@@ -35,4 +35,11 @@ def test_traffic_file_is_consistent():
     assert abs(mc["measured_write"] / mc["row_pass_slab_GB_per_launch"] - 1) < 0.02
     # ... plus the spectrum rows: once per slab with the XCD-aware row map (1 GB slabs, round 2: < 1.05), once per frame pair with
     # the plain map that wins for cache-sized slabs (8 MB of spectrum per 8-pair slab and what L2 loses in between: ~1.23)
-    assert 1.0 <= mc["measured_read"] / mc["row_pass_slab_GB_per_launch"] < 1.30
+    # Tight bounds per row-map mode (advisor, round 3): a launch reads its slab once plus the 8.4 MB spectrum at least once
+    # (XCD-aware map, PMC round 4: slab + 1.08 spectra) and at most ~2.2 times (plain map, the default for 8-pair slabs: every
+    # spectrum row is re-fetched by about every fourth of the 8 pairs that use it); anything above means workspace re-reads.
+    slab = mc["row_pass_slab_GB_per_launch"]
+    pairs = round(slab * 1e9 / (256 * 4096 * 8))
+    spectrum = 256 * 4096 * 8 / 1e9
+    extra = (mc["measured_read"] - slab) / spectrum
+    assert pairs == 8 and 0.95 <= extra <= 2.4, (pairs, extra)
