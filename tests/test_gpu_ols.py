@@ -173,11 +173,44 @@ def test_lds_ols_padding_alignment_and_env_switch(dtype, monkeypatch):
         assert not torch.equal(y, y3)            # a different kernel really ran
 
 
+@pytest.mark.parametrize("C,T,K", [(2, 44100, 2049), (3, 100_000, 4096), (1, 30_000, 8192), (5, 250_003, 5000), (2, 12_289, 4097),
+                                   (64, 40_000, 3441), (1, 5000, 2500), (4, 98_304, 8000)])
+def test_lds16k_ols_vs_float64(C, T, K, monkeypatch):
+    """2048 < K <= 8192 (float32): the 16 384-point workgroup transform (fftpk16k.h) against a float64 FFT convolution and against
+    the other paths.  By default it takes the rows the three-pass pipeline does not reach (padded length < 65 536, where the
+    alternative is rocFFT); TFX_OLS_LDS16K=2 forces it everywhere."""
+    short = T + K - 1 < 65536
+    info = ext().ols_plan_info(K, T, (K - 1, 0))
+    assert (info["path"], info["N"]) == (("lds", 16384) if short else ("passes", 65536))
+    assert ext().ols_plan_info(K, T, (K - 1, 0), torch.float64)["path"] == "rocfft"          # float64 would need 272 KB of LDS
+    rng = np.random.default_rng(K + T)
+    kf = (rng.standard_normal(K) * np.exp(-np.arange(K) / (K / 5)) / np.sqrt(K)).astype(np.float32)
+    x = rnd((C, T), T + K)
+    exp = _f64_corr(x, kf, K - 1, 0).astype(np.float32)
+    y_default = ext().fft_conv_forward(dev(x), kf, (K - 1, 0))
+    close(y_default, exp, 4e-6, "default route")
+    monkeypatch.setenv("TFX_OLS_LDS16K", "2")
+    assert ext().ols_plan_info(K, T, (K - 1, 0))["path"] == "lds" and ext().ols_plan_info(K, T, (K - 1, 0))["N"] == 16384
+    y16 = ext().fft_conv_forward(dev(x), kf, (K - 1, 0))
+    close(y16, exp, 4e-6, f"C={C} T={T} K={K} 16k")
+    if short:
+        assert torch.equal(y16, y_default)
+    for pad in ((100, 77), (0, K)):
+        if T + pad[0] + pad[1] >= K:
+            close(ext().fft_conv_forward(dev(x), kf, pad), _f64_corr(x, kf, *pad).astype(np.float32), 4e-6, f"pad={pad}")
+    monkeypatch.setenv("TFX_OLS_LDS16K", "0")
+    assert ext().ols_plan_info(K, T, (K - 1, 0))["path"] == ("rocfft" if short else "passes")
+    close(ext().fft_conv_forward(dev(x), kf, (K - 1, 0)), exp, 4e-6, "three passes / rocFFT")
+
+
 def test_lds_ols_plan_info_paths():
     e = ext()
     assert e.ols_plan_info(1024, 2_880_000, (1023, 0))["path"] == "lds"
     assert e.ols_plan_info(2048, 2_880_000, (2047, 0), torch.float64)["path"] == "lds"
-    assert e.ols_plan_info(2049, 2_880_000, (2048, 0))["path"] == "passes"
+    assert e.ols_plan_info(2049, 2_880_000, (2048, 0))["path"] == "passes"            # long rows: the three-pass pipeline is faster
+    i = e.ols_plan_info(4096, 44100, (4095, 0))                                         # short rows: one launch instead of rocFFT
+    assert (i["path"], i["N"]) == ("lds", 16384)
+    assert e.ols_plan_info(8193, 44100, (8192, 0))["path"] == "rocfft"
     assert e.ols_plan_info(2049, 2_880_000, (2048, 0), torch.float64)["path"] == "rocfft"
     i = e.ols_plan_info(1024, 2_880_000, (1023, 0))
     assert i["S"] == 3072 and i["F"] == 938 and abs(i["bytes_per_sample"] - (4 * 4096 / 3072 + 4)) < 1e-9

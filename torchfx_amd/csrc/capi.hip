@@ -40,8 +40,8 @@ void olsnative_clear();
 bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out);
 void olslds_clear();
 void olsnative_prewarm();
-bool olslds_supported(int64_t K, int64_t *N_out);
-void olslds_geometry(int64_t K, int64_t Tn, int64_t pl, int64_t pr, int elem_bytes, int64_t *lead_out, int64_t *S_out);
+bool olslds_supported(int64_t K, int dtype, int64_t L, int64_t *N_out);
+void olslds_geometry(int64_t K, int64_t Tn, int64_t pl, int64_t pr, int elem_bytes, int64_t N, int64_t *lead_out, int64_t *S_out);
 // effects.hip
 void gain_forward(const void *x, void *y, int dtype, int64_t n, double gain, int clamp, hipStream_t stream);
 void stat_forward(const void *x, int dtype, int64_t C, int64_t T, int mode, int per_row, double *out_dev, hipStream_t stream);
@@ -336,9 +336,9 @@ static void ols_plan(int64_t K, int64_t T, int64_t pad_left, int64_t pad_right, 
     TFX_CHECK(dtype == TFX_F32 || dtype == TFX_F64, "ols_plan_info: bad dtype %d", dtype);
     int64_t n = 0, hop = 0;
     int p = 0;
-    if (olslds_supported(K, &n)) {
+    if (olslds_supported(K, dtype, L, &n)) {
         int64_t lead = 0;
-        olslds_geometry(K, T, pad_left, pad_right, dtype == TFX_F32 ? 4 : 8, &lead, &hop);
+        olslds_geometry(K, T, pad_left, pad_right, dtype == TFX_F32 ? 4 : 8, n, &lead, &hop);
         p = 2;
     } else if (dtype == TFX_F32 && olsnative_supported(K, L, &n)) {
         const int64_t tout = L - K + 1;

@@ -31,7 +31,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
                        int64_t pl, int64_t pr, int64_t N, hipStream_t stream, const float *hist, int64_t H, const Epilogue *ep);
 
 // olslds.hip: one launch, the whole 4096-point transform in LDS (K <= 2048 taps, float32 and float64, rows of any length)
-bool olslds_supported(int64_t K, int64_t *N_out);
+bool olslds_supported(int64_t K, int dtype, int64_t L, int64_t *N_out);
 void olslds_forward(const void *x, void *y, int dtype, int64_t C, int64_t Tn, const void *kf_host, int64_t K,
                     int64_t pl, int64_t pr, hipStream_t stream, const void *hist, int64_t H, const Epilogue *ep);
 
@@ -332,7 +332,7 @@ void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, c
     TFX_CHECK(C > 0 && T >= 0, "fft_conv_forward: negative size");
     TFX_CHECK(y && kernel_host && (x || T == 0), "fft_conv_forward: null pointer");
     int64_t Nn = 0;
-    if (olslds_supported(K, &Nn)) {
+    if (olslds_supported(K, dtype, L, &Nn)) {
         // kernels that fit on chip: no workspace, epilogue in the store of the inverse transform
         olslds_forward(x, y, dtype, C, T, kernel_host, K, pad_left, pad_right, stream, hist, H, (ep && ep->any()) ? ep : nullptr);
         return;

@@ -23,6 +23,7 @@
 #include "common.h"
 #include "epilogue.h"
 #include "fftpk.h"
+#include "fftpk16k.h"
 #include "../../include/torchfx_hip.h"
 
 #include <algorithm>
@@ -188,19 +189,20 @@ template <typename R> struct PairAt {
 };
 
 // thread j's sixteen elements j + 256 t of z = frame_a + i frame_b, gathered from the signal (zero fill / history outside the row)
-template <typename R>
+template <typename R, int NP = 4096>
 __device__ __forceinline__ void fetch_pair(cx<R> (&v)[16], const R *__restrict__ x, const Geom<R> &g, const PairAt<R> &p, int j)
 {
+    constexpr int TPB = NP / 16;                  // threads per block: thread j holds elements j + TPB t
     const int64_t ia0 = p.ra * g.S - g.pad_left, ib0 = p.rb * g.S - g.pad_left;
     const R *xa = x + p.ca * g.Tn, *xb = x + p.cb * g.Tn;
-    if (ia0 >= 0 && ia0 + LDS_N <= g.Tn && p.has_b && ib0 >= 0 && ib0 + LDS_N <= g.Tn) {     // interior pair: no checks
+    if (ia0 >= 0 && ia0 + NP <= g.Tn && p.has_b && ib0 >= 0 && ib0 + NP <= g.Tn) {     // interior pair: no checks
         const R *pa = xa + ia0 + j, *pb = xb + ib0 + j;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) v[t] = mk<R>(pa[256 * t], pb[256 * t]);
+        for (int t = 0; t < 16; ++t) v[t] = mk<R>(pa[TPB * t], pb[TPB * t]);
     } else {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            const int64_t ia = ia0 + j + 256 * t, ib = ib0 + j + 256 * t;
+            const int64_t ia = ia0 + j + TPB * t, ib = ib0 + j + TPB * t;
             R re = (ia >= 0 && ia < g.Tn) ? xa[ia] : (R)0;
             R im = (p.has_b && ib >= 0 && ib < g.Tn) ? xb[ib] : (R)0;
             if (g.hist) {
@@ -213,16 +215,17 @@ __device__ __forceinline__ void fetch_pair(cx<R> (&v)[16], const R *__restrict__
 }
 
 // the valid part of the block, n < S: real part -> frame a's hop, imaginary part -> frame b's
-template <typename R>
+template <typename R, int NP = 4096>
 __device__ __forceinline__ void store_pair(const cx<R> (&v)[16], R *__restrict__ y, const Geom<R> &g, const PairAt<R> &p, int j, char *smem)
 {
+    constexpr int TPB = NP / 16, NW = TPB / 64;   // threads and wavefronts per block
     const int64_t oa0 = p.ra * g.S, ob0 = p.rb * g.S;
     R *ya = y + p.ca * g.Tout + oa0, *yb = y + p.cb * g.Tout + ob0;
     const bool epi = g.ep_scale | g.ep_clamp | (g.ep_stat >= 0);
     if (!epi && p.has_b && oa0 + g.S <= g.Tout && ob0 + g.S <= g.Tout) {     // whole hops inside their rows
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const int n = j + 256 * k;
+            const int n = j + TPB * k;
             if (n < g.S) { ya[n] = v[k].x; yb[n] = v[k].y; }
         }
         return;
@@ -230,7 +233,7 @@ __device__ __forceinline__ void store_pair(const cx<R> (&v)[16], R *__restrict__
     double acc_a = 0.0, acc_b = 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const int n = j + 256 * k;
+        const int n = j + TPB * k;
         if (n < g.S) {
             cx<R> o = v[k];
             const bool wa = oa0 + n < g.Tout, wb = p.has_b && ob0 + n < g.Tout;
@@ -254,11 +257,11 @@ __device__ __forceinline__ void store_pair(const cx<R> (&v)[16], R *__restrict__
             acc_b = red_comb_rt(g.ep_stat, acc_b, __shfl_xor(acc_b, off));
         }
         const int w = j >> 6;
-        if ((j & 63) == 0) { red[w] = acc_a; red[4 + w] = acc_b; }
+        if ((j & 63) == 0) { red[w] = acc_a; red[NW + w] = acc_b; }
         __syncthreads();
         if (j == 0) {
-            double sa = red[0], sb = red[4];
-            for (int u = 1; u < 4; ++u) { sa = red_comb_rt(g.ep_stat, sa, red[u]); sb = red_comb_rt(g.ep_stat, sb, red[4 + u]); }
+            double sa = red[0], sb = red[NW];
+            for (int u = 1; u < NW; ++u) { sa = red_comb_rt(g.ep_stat, sa, red[u]); sb = red_comb_rt(g.ep_stat, sb, red[NW + u]); }
             g.ep_partial[p.fa] = sa;
             if (p.has_b) g.ep_partial[p.fa + 1] = sb;
         }
@@ -332,6 +335,63 @@ ols_lds4096_kernel(const R *__restrict__ x, R *__restrict__ y, const cx<R> *__re
     store_pair<R>(v, y, g, p, j, smem);
 }
 
+// ---- second block size: 16 384 points, one 1024-thread workgroup per pair of frames (float32; 2048 < K <= 8192) ----------
+// fftpk16k.h: radix 16 x 16 x 16 x 4, three exchanges per direction through 136 KB of LDS -- ONE workgroup per CU, sixteen
+// wavefronts that run their phases in lockstep.  Measured against the three-pass pipeline on rows long enough for it
+// (64 x 2.88 M, 4096 taps): 0.97 ms against 0.79 -- nothing overlaps the load, exchange and store phases of the one
+// workgroup, and the register prefetch of the next pair that would (a second set of 32 VGPRs on top of 108) spills at the
+// 128 registers sixteen wavefronts leave (1.42 ms).  So this kernel serves the rows the three-pass pipeline does NOT take --
+// shorter than its 65 536-sample block, where the alternative is the five-launch rocFFT path -- and TFX_OLS_LDS16K=2 forces it
+// everywhere.  The spectrum is stored in the transform's "spectral ownership" (thread r, register s <-> bin
+// (r & 255) + 256 (4 (r >> 8) + s / 4) + 4096 (s % 4)), register pairs interleaved for 16-byte loads.
+constexpr int LDS16K = 16384;
+constexpr size_t lds16k_bytes() { return (size_t)(pk::X16K_SLOTS + pk::X16K_TABLES) * sizeof(v2f); }
+
+__device__ __forceinline__ void transform_pair16k(cx<float> (&v)[16], v2f *L, const pk::Tab16k &tb, const v4f *__restrict__ Hq, int j)
+{
+    const v2f Wc = {0.92387953251128675613f, 0.38268343236508977173f}, Wr = {0.70710678118654752440f, 0.70710678118654752440f};
+    v2f u[16];
+    v4f hq[8];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) u[t] = __builtin_bit_cast(v2f, v[t]);
+    pk::fft16384_fwd(u, L, tb, j, Wc, Wr);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) hq[m] = Hq[m * 1024 + j];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        u[2 * m] = pk::pk_cmul<false>(u[2 * m], v2f{hq[m].x, hq[m].y});
+        u[2 * m + 1] = pk::pk_cmul<false>(u[2 * m + 1], v2f{hq[m].z, hq[m].w});
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    pk::fft16384_inv(u, L, tb, j, Wc, Wr);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) v[t] = __builtin_bit_cast(cx<float>, u[t]);
+}
+
+__global__ void __launch_bounds__(1024, 4)
+ols_lds16k_kernel(const float *__restrict__ x, float *__restrict__ y, const v4f *__restrict__ Hq, const v2f *__restrict__ gtab,
+                  Geom<float> g, int64_t npairs, int64_t per_xcd)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v2f *L = (v2f *)smem;
+    const int j = threadIdx.x;
+    const pk::Tab16k tb = pk::fill_tab16k(L + pk::X16K_SLOTS, gtab, j);
+    const int64_t wpx = gridDim.x >> 3, m = blockIdx.x >> 3;
+    const int64_t lo = (int64_t)(blockIdx.x & 7u) * per_xcd;
+    const int64_t hi = lo + per_xcd < npairs ? lo + per_xcd : npairs;
+    __syncthreads();
+    for (int64_t pair = lo + m; pair < hi; pair += wpx) {
+        cx<float> v[16];
+        const PairAt<float> p(pair, g);
+        fetch_pair<float, LDS16K>(v, x, g, p, j);
+        transform_pair16k(v, L, tb, Hq, j);
+        store_pair<float, LDS16K>(v, y, g, p, j, smem);
+        __syncthreads();                         // the statistic's scratch is the transform buffer
+    }
+}
+
 // ---- host: per-filter tables ---------------------------------------------------------------------
 struct Plan {
     void *Hs = nullptr, *tw256 = nullptr, *t4lo = nullptr;
@@ -349,12 +409,12 @@ template <typename R> static void *upload(const std::vector<cx<R>> &h)
     return d;
 }
 
-template <typename R> static Plan get_plan(const R *kf, int64_t K, int64_t lead)
+template <typename R> static Plan get_plan(const R *kf, int64_t K, int64_t lead, int N)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     const int dev = current_device();
     const size_t nb = (size_t)K * sizeof(R);
-    const char tail[3] = {(char)sizeof(R), (char)lead, (char)dev};
+    const char tail[3] = {(char)(sizeof(R) + (N == LDS16K ? 64 : 0)), (char)lead, (char)dev};
     if (const std::vector<char> *lk_ = g_last_key[dev]) {       // steady state: one memcmp, no key construction
         if (lk_->size() == nb + 3 && memcmp(lk_->data(), kf, nb) == 0 && memcmp(lk_->data() + nb, tail, 3) == 0) return *g_last[dev];
     }
@@ -369,31 +429,53 @@ template <typename R> static Plan get_plan(const R *kf, int64_t K, int64_t lead)
             for (int d = 0; d < TFX_MAX_DEVICES; ++d) { g_last_key[d] = nullptr; g_last[d] = nullptr; }
         }
         // conj(FFT(taps behind `lead` zeros, zero padded to N)) / N in float64  (_fftconv.py:123-124,131 + irfft scaling)
-        std::vector<double> re((size_t)LDS_N, 0.0), im((size_t)LDS_N, 0.0);
+        std::vector<double> re((size_t)N, 0.0), im((size_t)N, 0.0);
         for (int64_t i = 0; i < K; ++i) re[(size_t)(lead + i)] = (double)kf[i];
         host_fft_f64(re, im);
-        std::vector<cx<R>> hs((size_t)LDS_N), t256(256), t4(256);
-        for (int k = 0; k < LDS_N; ++k) {
-            // float32: thread j multiplies elements j + 256 t; the pairs (t, t + 1) sit next to each other so it loads them 16 bytes at a time
-            const int t = k >> 8, jj = k & 255;
-            const int at = sizeof(R) == 4 ? ((t >> 1) * 256 + jj) * 2 + (t & 1) : k;
-            hs[at].x = (R)(re[k] / LDS_N); hs[at].y = (R)(-im[k] / LDS_N);
-        }
-        for (int i = 0; i < 256; ++i) {
-            const double a = -2.0 * M_PI * (double)i / 256.0;
-            t256[i].x = (R)cos(a); t256[i].y = (R)sin(a);
-        }
-        for (int t = 0; t < 16; ++t)
-            for (int a2 = 0; a2 < 16; ++a2) {
-                const double ang = -2.0 * M_PI * (double)(t * a2) / 4096.0;
-                t4[16 * t + a2].x = (R)cos(ang); t4[16 * t + a2].y = (R)sin(ang);
+        std::vector<cx<R>> hs((size_t)N);
+        auto W = [](double num, double den) {
+            const double a = -2.0 * M_PI * num / den;
+            cx<R> w; w.x = (R)cos(a); w.y = (R)sin(a);
+            return w;
+        };
+        Plan p;
+        if (N == LDS16K) {
+            // spectral ownership of fftpk16k.h: thread r, register s <-> bin (r & 255) + 256 (4 (r >> 8) + s / 4) + 4096 (s % 4);
+            // registers (2 m, 2 m + 1) of a thread sit next to each other: one 16-byte load
+            for (int r = 0; r < 1024; ++r)
+                for (int sl = 0; sl < 16; ++sl) {
+                    const int k = (r & 255) + 256 * (4 * (r >> 8) + (sl >> 2)) + 4096 * (sl & 3);
+                    const int at = ((sl >> 1) * 1024 + r) * 2 + (sl & 1);
+                    hs[at].x = (R)(re[k] / N); hs[at].y = (R)(-im[k] / N);
+                }
+            std::vector<cx<R>> tab(pk::X16K_TABLES);          // [twA 256 | twB 256 | tA 64 | tB 64 | tC 64]
+            for (int a = 0; a < 16; ++a)
+                for (int b = 0; b < 16; ++b) { tab[16 * a + b] = W(a * b, 4096); tab[256 + 16 * a + b] = W(a * b, 256); }
+            for (int d = 0; d < 4; ++d)
+                for (int b = 0; b < 16; ++b) {
+                    tab[512 + 16 * d + b] = W(d * b, 16384); tab[576 + 16 * d + b] = W(d * b, 1024); tab[640 + 16 * d + b] = W(d * b, 64);
+                }
+            hs.insert(hs.end(), tab.begin(), tab.end());
+            p.Hs = upload<R>(hs);                             // one allocation, one copy: spectrum | tables
+            p.tw256 = (char *)p.Hs + (size_t)N * sizeof(cx<R>);
+            p.t4lo = nullptr;
+        } else {
+            std::vector<cx<R>> t256(256), t4(256);
+            for (int k = 0; k < LDS_N; ++k) {
+                // float32: thread j multiplies elements j + 256 t; the pairs (t, t + 1) sit next to each other so it loads them 16 bytes at a time
+                const int t = k >> 8, jj = k & 255;
+                const int at = sizeof(R) == 4 ? ((t >> 1) * 256 + jj) * 2 + (t & 1) : k;
+                hs[at].x = (R)(re[k] / LDS_N); hs[at].y = (R)(-im[k] / LDS_N);
             }
-        Plan p;                                               // one allocation, one copy: spectrum | W256 | W4096 table
-        hs.insert(hs.end(), t256.begin(), t256.end());
-        hs.insert(hs.end(), t4.begin(), t4.end());
-        p.Hs = upload<R>(hs);
-        p.tw256 = (char *)p.Hs + (size_t)LDS_N * sizeof(cx<R>);
-        p.t4lo = (char *)p.tw256 + 256 * sizeof(cx<R>);
+            for (int i = 0; i < 256; ++i) t256[i] = W(i, 256);
+            for (int t = 0; t < 16; ++t)
+                for (int a2 = 0; a2 < 16; ++a2) t4[16 * t + a2] = W(t * a2, 4096);
+            hs.insert(hs.end(), t256.begin(), t256.end());    // one allocation, one copy: spectrum | W256 | W4096 table
+            hs.insert(hs.end(), t4.begin(), t4.end());
+            p.Hs = upload<R>(hs);
+            p.tw256 = (char *)p.Hs + (size_t)LDS_N * sizeof(cx<R>);
+            p.t4lo = (char *)p.tw256 + 256 * sizeof(cx<R>);
+        }
         it = g_plans.emplace(std::move(key), p).first;
     }
     g_last_key[dev] = &it->first;
@@ -419,25 +501,33 @@ void olslds_clear()
     for (int d = 0; d < TFX_MAX_DEVICES; ++d) { g_last_key[d] = nullptr; g_last[d] = nullptr; }
 }
 
-// taps this path takes: at least half of every 4096-point block must be valid output
-bool olslds_supported(int64_t K, int64_t *N_out)
+// taps this path takes: at least half of every block must be valid output -- 4096 points for K <= 2048 (float32 and float64),
+// 16 384 points for 2048 < K <= 8192 on rows the three-pass pipeline does not take (float32: float64 would need 272 KB of LDS)
+bool olslds_supported(int64_t K, int dtype, int64_t L, int64_t *N_out)
 {
     if (ldsfft::envi("TFX_OLS_LDS", 1) == 0 || ldsfft::envi("TFX_OLS_NATIVE", 1) == 0) return false;
-    if (ldsfft::envi("TFX_FFT_LOG2N", 0) != 0 && ldsfft::envi("TFX_FFT_LOG2N", 0) != 12) return false;   // a forced block size
-    if (K < 1 || K > ldsfft::LDS_N / 2) return false;
-    if (N_out) *N_out = ldsfft::LDS_N;
+    const int64_t lg = ldsfft::envi("TFX_FFT_LOG2N", 0);
+    if (lg != 0 && lg != 12 && lg != 14) return false;                     // a forced block size of another path
+    int64_t N = 0;
+    const int64_t use16k = ldsfft::envi("TFX_OLS_LDS16K", 1);                // 0 never, 1 where the three-pass pipeline does not reach, 2 always
+    if (K >= 1 && K <= ldsfft::LDS_N / 2 && lg != 14) N = ldsfft::LDS_N;
+    else if (K >= 1 && K <= ldsfft::LDS16K / 2 && dtype == TFX_F32 && lg != 12 &&
+             (use16k >= 2 || lg == 14 || (use16k == 1 && L < 65536)))
+        N = ldsfft::LDS16K;
+    if (!N) return false;
+    if (N_out) *N_out = N;
     return true;
 }
 
 // frame geometry shared with tfx_ols_plan_info: `lead` zero taps in front of the flipped kernel move the frame starts
 // onto 128-byte lines when the rows themselves are aligned, and the hop is rounded down to whole lines
-void olslds_geometry(int64_t K, int64_t Tn, int64_t pl, int64_t pr, int elem_bytes, int64_t *lead_out, int64_t *S_out)
+void olslds_geometry(int64_t K, int64_t Tn, int64_t pl, int64_t pr, int elem_bytes, int64_t N, int64_t *lead_out, int64_t *S_out)
 {
     const int64_t line = 128 / elem_bytes;
     const int64_t Tout = Tn + pl + pr - K + 1;
     const bool align = (Tn % line == 0) && (Tout % line == 0) && ldsfft::envi("TFX_OLS_ALIGN", 1) != 0;
     const int64_t lead = align ? (line - (pl % line)) % line : 0;
-    int64_t S = ldsfft::LDS_N - (K + lead) + 1;
+    int64_t S = N - (K + lead) + 1;
     if (align && S > 2 * line) S -= S % line;
     *lead_out = lead;
     *S_out = S;
@@ -454,16 +544,40 @@ static void olslds_typed(const R *x, R *y, int64_t C, int64_t Tn, const R *kf_ho
     g.hist = hist; g.H = hist ? H : 0;
     g.ep_gain = ep ? (R)ep->gain : (R)1; g.ep_scale = ep ? ep->scale : 0; g.ep_clamp = ep ? ep->clamp : 0;
     g.ep_stat = ep ? ep->stat_mode : -1; g.ep_partial = nullptr;
-    int64_t lead = 0;
-    olslds_geometry(K, Tn, pl, pr, (int)sizeof(R), &lead, &g.S);
+    int64_t lead = 0, N = 0;
+    TFX_CHECK(olslds_supported(K, sizeof(R) == 4 ? TFX_F32 : TFX_F64, Tn + pl + pr, &N), "olslds_forward: %lld taps are not for this path", (long long)K);
+    olslds_geometry(K, Tn, pl, pr, (int)sizeof(R), N, &lead, &g.S);
     g.pad_left = pl + lead;
     g.F = ceil_div(g.Tout, g.S);
     g.nframes = C * g.F;
-    const Plan plan = get_plan<R>(kf_host, K, lead);
+    const Plan plan = get_plan<R>(kf_host, K, lead, (int)N);
     const int64_t npairs = ceil_div(g.nframes, 2);
     if (g.ep_stat >= 0) g.ep_partial = (double *)scratch("olslds_ep_partial", (size_t)g.nframes * sizeof(double), stream);
-    static bool attr_tab[TFX_MAX_DEVICES] = {};
     const int dev = current_device();
+    if constexpr (sizeof(R) == 4) {
+        if (N == LDS16K) {
+            static int cus_tab[TFX_MAX_DEVICES] = {};
+            if (!cus_tab[dev]) {
+                TFX_HIP(hipFuncSetAttribute((const void *)ols_lds16k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16k_bytes()));
+                int cus = 0;
+                TFX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+                cus_tab[dev] = std::max(8, cus / 8 * 8);      // one 1024-thread workgroup per CU
+            }
+            const int64_t per_xcd16 = ceil_div(npairs, 8);
+            int64_t grid = std::min<int64_t>(envi("TFX_OLS_LDS16K_GRID", cus_tab[dev]) / 8 * 8, per_xcd16 * 8);
+            if (grid < 8) grid = 8;
+            {
+                ProfScope ps("ols_lds16k_kernel", stream);
+                hipLaunchKernelGGL(ols_lds16k_kernel, dim3((unsigned)grid), dim3(1024), lds16k_bytes(), stream,
+                                   (const float *)x, (float *)y, (const v4f *)plan.Hs, (const v2f *)plan.tw256, g, npairs, per_xcd16);
+                TFX_HIP(hipGetLastError());
+            }
+            if (g.ep_stat >= 0)
+                stat_finish(g.ep_partial, ep->per_row ? C : 1, ep->per_row ? g.F : g.nframes, g.ep_stat, ep->stat_out, stream);
+            return;
+        }
+    }
+    static bool attr_tab[TFX_MAX_DEVICES] = {};
     if (!attr_tab[dev]) {
         TFX_HIP(hipFuncSetAttribute((const void *)ols_lds4096_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<R>()));
         attr_tab[dev] = true;
