@@ -111,8 +111,15 @@ fir_direct_mfma_kernel(const float *__restrict__ x, float *__restrict__ y,
     float *kp = xw + ((XW_PAD + 3) & ~3);                   // [31 + FIR_KC + 33]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t c = blockIdx.x / tiles_per_row;
-    const int64_t n0 = (blockIdx.x % tiles_per_row) * (int64_t)NOUT;
+    // Tile -> workgroup: workgroups are dealt to the eight XCDs round robin (observed; only speed and traffic depend on it), so
+    // XCD b % 8 takes the tiles [xcd * per_xcd, (xcd + 1) * per_xcd) in order: neighbouring tiles of a row, whose windows share
+    // K - 1 + 32 samples, are worked on by ONE XCD and the overlap is an L2 hit instead of a second fetch (round 4: PMC read
+    // traffic of cfg 3 1.2 x -> see profiles/r04_traffic.json).
+    const int64_t ntiles = C * tiles_per_row, per_xcd = (ntiles + 7) / 8;
+    const int64_t bid = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= per_xcd || bid >= ntiles) return;
+    const int64_t c = bid / tiles_per_row;
+    const int64_t n0 = (bid % tiles_per_row) * (int64_t)NOUT;
     const float *xrow = x + c * T;
     float *yrow = y + c * T;
 
@@ -348,7 +355,7 @@ void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
                 done = true;
             }
             ProfScope ps("fir_direct_mfma_kernel", stream);
-            hipLaunchKernelGGL(kern, dim3((unsigned)(C * tiles)), dim3(256), shmem, stream, (const float *)x,
+            hipLaunchKernelGGL(kern, dim3((unsigned)(ceil_div(C * tiles, 8) * 8)), dim3(256), shmem, stream, (const float *)x,
                                (float *)y, (const float *)kdev, C, T, (int)K, nchunks, tiles, (const float *)hist, (int)H);
             TFX_HIP(hipGetLastError());
         };
