@@ -58,6 +58,14 @@ def cases(dev, seconds_long=300.0):
     yield "cascade f64", lambda: E.sos_forward(x_mid, None, sos, None, None)[0]
     yield "cascade f32", lambda: E.sos_forward(x_mid, None, sos, None, None, precision="f32")[0]
     yield "direct FIR 1024", lambda: E.fir_direct_forward(x_mid, b1024[::-1].copy())
+    k1024 = b1024[::-1].copy()
+    yield "FIR 1024 through the FFT mode (one launch, transform in LDS)", lambda: E.fft_conv_forward(x_mid, k1024, (1023, 0))
+    k4096 = (np.random.default_rng(1).standard_normal(4096) / 4096).astype(np.float32)
+    x_short = x_mid[:8, :44100].contiguous()
+    yield "4096 taps on short rows (16 384-point workgroup transform)", lambda: E.fft_conv_forward(x_short, k4096, (4095, 0))
+    yield "4096 taps on long rows (three passes, 256-point rows)", lambda: E.fft_conv_forward(x_mid, k4096, (4095, 0))
+    x64 = x_mid[:16].double()
+    yield "FIR 1024 float64 (LDS)", lambda: E.fft_conv_forward(x64, k1024.astype(np.float64), (1023, 0))
     xc = x_mid[:2, :512].contiguous()
     taps = b1024[:256][::-1].copy()
 
