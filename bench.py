@@ -489,6 +489,9 @@ def main() -> None:
 
     from torchfx_amd import _lib
     lib = _lib.load()                      # fails loudly if the HIP extension is missing
+    from torchfx_amd import torchfx_ext as _E
+    _E.prewarm(dev)                        # what a latency-conscious caller does at start-up: the library's one-time device set-up
+    #                                        (code-object load, internal streams) runs on a helper thread while the signal is generated
 
     chainlike = args.workload.startswith("chain") or args.workload == "fftconv"
     seconds = args.seconds if args.seconds is not None else (600.0 if chainlike else 60.0)

@@ -1149,6 +1149,14 @@ void olsnative_prewarm()
         TFX_HIP(hipSetDevice(dev));
         ols_set_attributes(dev);
         if (want_lanes > 1) ols_make_lanes(dev, want_lanes);
+        // the first raw hipMalloc + pageable host-to-device copy of a process set up the runtime's staging path (7-36 ms on the
+        // boxes of round 4, TFX_OLS_TRACE): done here once so that the first plan's table upload does not pay for it
+        void *p = nullptr;
+        std::vector<char> h((size_t)1 << 20, 0);
+        if (hipMalloc(&p, h.size()) == hipSuccess) {
+            (void)hipMemcpy(p, h.data(), h.size(), hipMemcpyHostToDevice);
+            (void)hipFree(p);
+        }
     }).share();
 }
 
