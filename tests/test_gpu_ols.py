@@ -138,7 +138,7 @@ def test_lds_ols_reference_shapes_vs_float64(C, T, K, dtype):
     tests/test_fftconv.py:64-122: [2, 44100], K = 5 ... 1024) run on the single-launch LDS kernel -- not rocFFT --
     in float32 and float64, odd frame counts (an unpaired last frame), rows shorter than one block, T < K."""
     info = ext().ols_plan_info(K, T, (K - 1, 0), torch.float32 if dtype == np.float32 else torch.float64)
-    assert info["path"] == "lds" and info["N"] == 4096
+    assert info["path"] == "lds" and info["N"] == (8192 if (dtype == np.float32 and K > 1024) else 4096)
     rng = np.random.default_rng(K * 7 + T)
     kf = (rng.standard_normal(K) / np.sqrt(K)).astype(np.float32).astype(dtype)      # taps are float32 values (fir.py:516)
     x = rnd((C, T), T + K, dtype)
@@ -177,11 +177,11 @@ def test_lds_ols_padding_alignment_and_env_switch(dtype, monkeypatch):
                                    (64, 40_000, 3441), (1, 5000, 2500), (4, 98_304, 8000)])
 def test_lds16k_ols_vs_float64(C, T, K, monkeypatch):
     """2048 < K <= 8192 (float32): the 16 384-point workgroup transform (fftpk16k.h) against a float64 FFT convolution and against
-    the other paths.  By default it takes the rows the three-pass pipeline does not reach (padded length < 65 536, where the
-    alternative is rocFFT); TFX_OLS_LDS16K=2 forces it everywhere."""
+    the other paths.  By default it takes 4096 < K <= 8192 on the rows the three-pass pipeline does not reach (padded length
+    < 65 536, where the alternative is rocFFT); K <= 4096 belongs to the 8192-point kernel; TFX_FFT_LOG2N=14 forces it."""
     short = T + K - 1 < 65536
     info = ext().ols_plan_info(K, T, (K - 1, 0))
-    assert (info["path"], info["N"]) == (("lds", 16384) if short else ("passes", 65536))
+    assert (info["path"], info["N"]) == (("lds", 8192) if K <= 4096 else ("lds", 16384) if short else ("passes", 65536))
     assert ext().ols_plan_info(K, T, (K - 1, 0), torch.float64)["path"] == "rocfft"          # float64 would need 272 KB of LDS
     rng = np.random.default_rng(K + T)
     kf = (rng.standard_normal(K) * np.exp(-np.arange(K) / (K / 5)) / np.sqrt(K)).astype(np.float32)
@@ -189,27 +189,61 @@ def test_lds16k_ols_vs_float64(C, T, K, monkeypatch):
     exp = _f64_corr(x, kf, K - 1, 0).astype(np.float32)
     y_default = ext().fft_conv_forward(dev(x), kf, (K - 1, 0))
     close(y_default, exp, 4e-6, "default route")
-    monkeypatch.setenv("TFX_OLS_LDS16K", "2")
+    monkeypatch.setenv("TFX_FFT_LOG2N", "14")
     assert ext().ols_plan_info(K, T, (K - 1, 0))["path"] == "lds" and ext().ols_plan_info(K, T, (K - 1, 0))["N"] == 16384
     y16 = ext().fft_conv_forward(dev(x), kf, (K - 1, 0))
     close(y16, exp, 4e-6, f"C={C} T={T} K={K} 16k")
-    if short:
+    if short and K > 4096:
         assert torch.equal(y16, y_default)
     for pad in ((100, 77), (0, K)):
         if T + pad[0] + pad[1] >= K:
             close(ext().fft_conv_forward(dev(x), kf, pad), _f64_corr(x, kf, *pad).astype(np.float32), 4e-6, f"pad={pad}")
+    monkeypatch.delenv("TFX_FFT_LOG2N")
     monkeypatch.setenv("TFX_OLS_LDS16K", "0")
+    monkeypatch.setenv("TFX_OLS_LDS8K_MINK", "0")
     assert ext().ols_plan_info(K, T, (K - 1, 0))["path"] == ("rocfft" if short else "passes")
     close(ext().fft_conv_forward(dev(x), kf, (K - 1, 0)), exp, 4e-6, "three passes / rocFFT")
+
+
+@pytest.mark.parametrize("C,T,K", [(2, 44100, 1025), (2, 44100, 2048), (3, 100_003, 4096), (1, 9000, 5), (5, 250_003, 3000), (2, 12_289, 2049),
+                                   (64, 40_000, 1500), (1, 1, 1), (4, 98_304, 4000), (1, 8193, 4096), (3, 20_481, 4095)])
+def test_lds8k_ols_vs_float64(C, T, K, monkeypatch):
+    """The 8192-point block of the one-launch kernel (float32, default for 1024 < K <= 4096; TFX_FFT_LOG2N=13 forces it for
+    smaller K): one radix-2 step in registers around two 4096-point transforms.  Against a float64 FFT convolution for every
+    padding flavour, and against the 4096-point kernel / the three-pass pipeline on the same input."""
+    monkeypatch.setenv("TFX_FFT_LOG2N", "13")
+    rng = np.random.default_rng(K * 3 + T)
+    kf = (rng.standard_normal(K) / np.sqrt(K)).astype(np.float32)
+    x = rnd((C, T), T + K)
+    for pad in ((K - 1, 0), (100, 77), (0, K)):
+        if T + pad[0] + pad[1] < K:
+            continue
+        info = ext().ols_plan_info(K, T, pad)
+        assert (info["path"], info["N"]) == ("lds", 8192)
+        y = ext().fft_conv_forward(dev(x), kf, pad)
+        close(y, _f64_corr(x, kf, *pad).astype(np.float32), 4e-6, f"C={C} T={T} K={K} pad={pad}")
+    y8 = ext().fft_conv_forward(dev(x), kf, (K - 1, 0))
+    monkeypatch.delenv("TFX_FFT_LOG2N")
+    monkeypatch.setenv("TFX_OLS_LDS8K_MINK", "0")
+    other = ext().ols_plan_info(K, T, (K - 1, 0))
+    assert other["N"] != 8192
+    y_other = ext().fft_conv_forward(dev(x), kf, (K - 1, 0))
+    close(y8, y_other.cpu().numpy(), 4e-6, f"8192-point kernel vs {other['path']} N={other['N']}")
+    if C * T > 100:
+        assert not torch.equal(y8, y_other)          # a different kernel really ran
 
 
 def test_lds_ols_plan_info_paths():
     e = ext()
     assert e.ols_plan_info(1024, 2_880_000, (1023, 0))["path"] == "lds"
     assert e.ols_plan_info(2048, 2_880_000, (2047, 0), torch.float64)["path"] == "lds"
-    assert e.ols_plan_info(2049, 2_880_000, (2048, 0))["path"] == "passes"            # long rows: the three-pass pipeline is faster
-    i = e.ols_plan_info(4096, 44100, (4095, 0))                                         # short rows: one launch instead of rocFFT
+    i = e.ols_plan_info(2049, 2_880_000, (2048, 0))                                     # up to 4096 taps: the 8192-point block, any row length
+    assert (i["path"], i["N"]) == ("lds", 8192)
+    assert e.ols_plan_info(4097, 2_880_000, (4096, 0))["path"] == "passes"            # long rows: the three-pass pipeline is faster
+    i = e.ols_plan_info(8000, 44100, (7999, 0))                                         # short rows: one launch instead of rocFFT
     assert (i["path"], i["N"]) == ("lds", 16384)
+    i = e.ols_plan_info(4096, 44100, (4095, 0))
+    assert (i["path"], i["N"]) == ("lds", 8192)
     assert e.ols_plan_info(8193, 44100, (8192, 0))["path"] == "rocfft"
     assert e.ols_plan_info(2049, 2_880_000, (2048, 0), torch.float64)["path"] == "rocfft"
     i = e.ols_plan_info(1024, 2_880_000, (1023, 0))

@@ -49,23 +49,28 @@ def test_cfg5_small_chain_golden_staged_and_fused(golden):
     close(wd.ys, g["yc"], TOL_CONV_F32, "default plan (IIR folded into the merged FIR)")
 
 
-@pytest.mark.parametrize("policy", ["auto", "fir_only", "reference"])
-def test_chain_with_iir_gain_golden(golden, policy):
+@pytest.mark.parametrize("policy", ["auto", "auto_fold", "fir_only", "reference"])
+def test_chain_with_iir_gain_golden(golden, policy, monkeypatch):
     """tests/golden/chain_gain.npz (reference staged output; IIR run with +12 dB shelf, +9 dB Q=4 peak, 80 Hz
-    high-pass, then FIR-257 | FIR-2049) under the three plans: default (one overlap-save pass for the whole
-    chain), cascade kernel + merged FIR, and the reference's staging."""
+    high-pass, then FIR-257 | FIR-2049) under the plans: default, one overlap-save pass for the whole chain, cascade
+    kernel + merged FIR, and the reference's staging.  The merged 2305-tap FIR runs on the one-launch 8192-point kernel
+    (9.6 B/sample), so by the planner's byte model the cascade stays its own 8 B/sample pass by default: folding its
+    impulse response in would push the run past 4096 taps onto the three-pass pipeline (~26 B/sample).  Without that
+    kernel (`auto_fold`) the fold pays and the whole chain is one pass."""
     from scipy.signal import firwin
     from torchfx_amd import Wave
     from torchfx_amd import filter as F
     g = golden("chain_gain")
     w = Wave(g["x"], 48000, device=DEV)
-    if policy != "auto":
+    if policy == "auto_fold":
+        monkeypatch.setenv("TFX_OLS_LDS8K_MINK", "0")
+    elif policy != "auto":
         w.fuse_spectral = False
         w.fuse_fir = policy == "fir_only"
     irg = np.random.default_rng(2).standard_normal(2049) * np.exp(-np.arange(2049) / 300.0)
     w = (w | F.HiShelving(3000, q=0.7, gain=4.0) | F.ParametricEQ(frequency=500, q=4.0, gain=9.0)
          | F.HiButterworth(80, order=2) | F.FIR(firwin(257, 6000, fs=48000)) | F.FIR(8.0 * irg / np.abs(irg).sum()))
-    assert len(w.plan()) == {"auto": 1, "fir_only": 2, "reference": 3}[policy]
+    assert len(w.plan()) == {"auto": 2, "auto_fold": 1, "fir_only": 2, "reference": 3}[policy]
     close(w.ys, g["y"], TOL_CONV_F32, f"chain with IIR gain, plan {policy}")
 
 

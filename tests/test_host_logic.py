@@ -453,10 +453,17 @@ def _gain_chain(wave):
             | F.HiButterworth(80, order=2) | F.FIR(firwin(257, 6000, fs=48000)) | F.FIR(8.0 * irg / np.abs(irg).sum()))
 
 
-def test_default_plan_folds_a_cascade_with_gain_into_the_fir_run(oracle_backend, golden):
-    """Reference output of the staged chain (tests/golden/chain_gain.npz) vs the default plan, which is a
-    single FIR: the 3-filter IIR run as taps, convolved with both FIRs."""
+def test_default_plan_folds_a_cascade_with_gain_into_the_fir_run(oracle_backend, golden, monkeypatch):
+    """Reference output of the staged chain (tests/golden/chain_gain.npz) vs the folded plan, which is a
+    single FIR: the 3-filter IIR run as taps, convolved with both FIRs.  The planner prices the fold in HBM bytes
+    (`Wave._ols_bytes_per_sample`): the merged 2305-tap FIR alone runs on the one-launch 8192-point kernel at 9.6 B/sample,
+    with the cascade's impulse response folded in it would need the three-pass pipeline (~26 B/sample) -- so by default the
+    cascade stays its own 8 B/sample pass; without the 8192-point kernel the fold pays."""
     g = golden("chain_gain")
+    w = _gain_chain(fx.Wave(g["x"], 48000))
+    assert [type(m).__name__ for m in w.plan()] == ["FusedSOSCascade", "FIR"]
+    close(w.ys, g["y"], 2e-5)
+    monkeypatch.setenv("TFX_OLS_LDS8K_MINK", "0")
     w = _gain_chain(fx.Wave(g["x"], 48000))
     plan = w.plan()
     assert [type(m).__name__ for m in plan] == ["FIR"] and plan[0].kernel.numel() > 257 + 2049

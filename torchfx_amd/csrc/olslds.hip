@@ -189,19 +189,19 @@ template <typename R> struct PairAt {
 };
 
 // thread j's sixteen elements j + 256 t of z = frame_a + i frame_b, gathered from the signal (zero fill / history outside the row)
-template <typename R, int NP = 4096>
-__device__ __forceinline__ void fetch_pair(cx<R> (&v)[16], const R *__restrict__ x, const Geom<R> &g, const PairAt<R> &p, int j)
+template <typename R, int NP = 4096, int VPT = 16>
+__device__ __forceinline__ void fetch_pair(cx<R> (&v)[VPT], const R *__restrict__ x, const Geom<R> &g, const PairAt<R> &p, int j)
 {
-    constexpr int TPB = NP / 16;                  // threads per block: thread j holds elements j + TPB t
+    constexpr int TPB = NP / VPT;                 // threads per block: thread j holds elements j + TPB t
     const int64_t ia0 = p.ra * g.S - g.pad_left, ib0 = p.rb * g.S - g.pad_left;
     const R *xa = x + p.ca * g.Tn, *xb = x + p.cb * g.Tn;
     if (ia0 >= 0 && ia0 + NP <= g.Tn && p.has_b && ib0 >= 0 && ib0 + NP <= g.Tn) {     // interior pair: no checks
         const R *pa = xa + ia0 + j, *pb = xb + ib0 + j;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) v[t] = mk<R>(pa[TPB * t], pb[TPB * t]);
+        for (int t = 0; t < VPT; ++t) v[t] = mk<R>(pa[TPB * t], pb[TPB * t]);
     } else {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
+        for (int t = 0; t < VPT; ++t) {
             const int64_t ia = ia0 + j + TPB * t, ib = ib0 + j + TPB * t;
             R re = (ia >= 0 && ia < g.Tn) ? xa[ia] : (R)0;
             R im = (p.has_b && ib >= 0 && ib < g.Tn) ? xb[ib] : (R)0;
@@ -215,16 +215,16 @@ __device__ __forceinline__ void fetch_pair(cx<R> (&v)[16], const R *__restrict__
 }
 
 // the valid part of the block, n < S: real part -> frame a's hop, imaginary part -> frame b's
-template <typename R, int NP = 4096>
-__device__ __forceinline__ void store_pair(const cx<R> (&v)[16], R *__restrict__ y, const Geom<R> &g, const PairAt<R> &p, int j, char *smem)
+template <typename R, int NP = 4096, int VPT = 16>
+__device__ __forceinline__ void store_pair(const cx<R> (&v)[VPT], R *__restrict__ y, const Geom<R> &g, const PairAt<R> &p, int j, char *smem)
 {
-    constexpr int TPB = NP / 16, NW = TPB / 64;   // threads and wavefronts per block
+    constexpr int TPB = NP / VPT, NW = TPB / 64;  // threads and wavefronts per block
     const int64_t oa0 = p.ra * g.S, ob0 = p.rb * g.S;
     R *ya = y + p.ca * g.Tout + oa0, *yb = y + p.cb * g.Tout + ob0;
     const bool epi = g.ep_scale | g.ep_clamp | (g.ep_stat >= 0);
     if (!epi && p.has_b && oa0 + g.S <= g.Tout && ob0 + g.S <= g.Tout) {     // whole hops inside their rows
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
+        for (int k = 0; k < VPT; ++k) {
             const int n = j + TPB * k;
             if (n < g.S) { ya[n] = v[k].x; yb[n] = v[k].y; }
         }
@@ -232,7 +232,7 @@ __device__ __forceinline__ void store_pair(const cx<R> (&v)[16], R *__restrict__
     }
     double acc_a = 0.0, acc_b = 0.0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < VPT; ++k) {
         const int n = j + TPB * k;
         if (n < g.S) {
             cx<R> o = v[k];
@@ -335,6 +335,87 @@ ols_lds4096_kernel(const R *__restrict__ x, R *__restrict__ y, const cx<R> *__re
     store_pair<R>(v, y, g, p, j, smem);
 }
 
+// ---- 8192 points in the same 256-thread workgroup (float32; K <= 4096) ------------------------------------------------------
+// One radix-2 step in registers around TWO 4096-point transforms that run one after the other through the same 34 KB exchange
+// buffer: thread j holds z[j + 256 t], t < 32;  a = z_lo + z_hi,  b = (z_lo - z_hi) W8192^n  (n = j + 256 t < 4096, decimation in
+// frequency), FFT_4096(a) = the even bins, FFT_4096(b) = the odd bins, and the mirror image on the way back.  Same LDS and
+// four workgroups per CU as the 4096-point kernel, 13 butterfly levels instead of 12 for twice the block: the valid part of a
+// block grows from (4096 - K) / 4096 to (8192 - K) / 8192 -- 0.75 -> 0.875 at 1024 taps, fewer points transformed and fewer
+// input samples read per output sample -- and 2048 < K <= 4096 stays in one launch.  W8192^n = W8192^j W32^t: the first factor is
+// one table entry per thread, the second is W256^(8 t) = twB[16 t + 8], already in LDS.  The spectrum is stored as
+// [even bins | odd bins], each half in the pair-interleaved order of the 4096-point kernel.
+constexpr int LDS8K = 8192;
+
+__device__ __forceinline__ void transform_pair8k(cx<float> (&v)[32], cx<float> *lds, const cx<float> *twB_, const cx<float> *twA_,
+                                                 const v4f *__restrict__ Hq, v2f wj, int j)
+{
+    const v2f Wc = {0.92387953251128675613f, 0.38268343236508977173f}, Wr = {0.70710678118654752440f, 0.70710678118654752440f};
+    const v2f *twB = (const v2f *)twB_, *twA = (const v2f *)twA_;
+    v2f a[16], b[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const v2f lo = __builtin_bit_cast(v2f, v[t]), hi = __builtin_bit_cast(v2f, v[t + 16]);
+        const v2f w = t ? pk::pk_cmul<false>(wj, twB[16 * t + 8]) : wj;
+        a[t] = lo + hi;
+        b[t] = pk::pk_cmul<false>(lo - hi, w);
+    }
+    pk::fft4096_pk<false>(a, (v2f *)lds, twB, twA, j, Wc, Wr);
+    {
+        v4f q[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) q[m] = Hq[m * 256 + j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            a[2 * m] = pk::pk_cmul<false>(a[2 * m], v2f{q[m].x, q[m].y});
+            a[2 * m + 1] = pk::pk_cmul<false>(a[2 * m + 1], v2f{q[m].z, q[m].w});
+        }
+    }
+    pk::fft4096_pk<false>(b, (v2f *)lds, twB, twA, j, Wc, Wr);
+    {
+        v4f q[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) q[m] = Hq[(8 + m) * 256 + j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            b[2 * m] = pk::pk_cmul<false>(b[2 * m], v2f{q[m].x, q[m].y});
+            b[2 * m + 1] = pk::pk_cmul<false>(b[2 * m + 1], v2f{q[m].z, q[m].w});
+        }
+    }
+    pk::fft4096_pk<true>(a, (v2f *)lds, twB, twA, j, Wc, Wr);
+    pk::fft4096_pk<true>(b, (v2f *)lds, twB, twA, j, Wc, Wr);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const v2f w = t ? pk::pk_cmul<false>(wj, twB[16 * t + 8]) : wj;
+        const v2f bw = pk::pk_cmul<true>(b[t], w);
+        v[t] = __builtin_bit_cast(cx<float>, a[t] + bw);
+        v[t + 16] = __builtin_bit_cast(cx<float>, a[t] - bw);
+    }
+}
+
+__global__ void __launch_bounds__(256, 4)
+ols_lds8192_kernel(const float *__restrict__ x, float *__restrict__ y, const v4f *__restrict__ Hq, const cx<float> *__restrict__ tw256g,
+                   const cx<float> *__restrict__ t4log, const v2f *__restrict__ w8kg, Geom<float> g, int64_t npairs, int64_t per_xcd)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cx<float> *lds = (cx<float> *)smem;
+    cx<float> *twB = lds + LDS_N + LDS_N / 16;
+    cx<float> *twA = twB + 256;
+    const int j = threadIdx.x;
+    twB[j] = tw256g[((j >> 4) * (j & 15)) & 255];
+    twA[j] = t4log[j];
+    const int64_t pair = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= per_xcd || pair >= npairs) return;
+    const v2f wj = w8kg[j];
+    __syncthreads();
+    cx<float> v[32];
+    const PairAt<float> p(pair, g);
+    fetch_pair<float, LDS8K, 32>(v, x, g, p, j);
+    transform_pair8k(v, lds, twB, twA, Hq, wj, j);
+    store_pair<float, LDS8K, 32>(v, y, g, p, j, smem);
+}
+
 // ---- second block size: 16 384 points, one 1024-thread workgroup per pair of frames (float32; 2048 < K <= 8192) ----------
 // fftpk16k.h: radix 16 x 16 x 16 x 4, three exchanges per direction through 136 KB of LDS -- ONE workgroup per CU, sixteen
 // wavefronts that run their phases in lockstep.  Measured against the three-pass pipeline on rows long enough for it
@@ -394,7 +475,7 @@ ols_lds16k_kernel(const float *__restrict__ x, float *__restrict__ y, const v4f 
 
 // ---- host: per-filter tables ---------------------------------------------------------------------
 struct Plan {
-    void *Hs = nullptr, *tw256 = nullptr, *t4lo = nullptr;
+    void *Hs = nullptr, *tw256 = nullptr, *t4lo = nullptr, *w8k = nullptr;
 };
 static std::mutex g_mu;
 static std::map<std::vector<char>, Plan> g_plans;
@@ -414,7 +495,7 @@ template <typename R> static Plan get_plan(const R *kf, int64_t K, int64_t lead,
     std::lock_guard<std::mutex> lk(g_mu);
     const int dev = current_device();
     const size_t nb = (size_t)K * sizeof(R);
-    const char tail[3] = {(char)(sizeof(R) + (N == LDS16K ? 64 : 0)), (char)lead, (char)dev};
+    const char tail[3] = {(char)(sizeof(R) + (N == LDS16K ? 64 : N == LDS8K ? 32 : 0)), (char)lead, (char)dev};
     if (const std::vector<char> *lk_ = g_last_key[dev]) {       // steady state: one memcmp, no key construction
         if (lk_->size() == nb + 3 && memcmp(lk_->data(), kf, nb) == 0 && memcmp(lk_->data() + nb, tail, 3) == 0) return *g_last[dev];
     }
@@ -461,6 +542,14 @@ template <typename R> static Plan get_plan(const R *kf, int64_t K, int64_t lead,
             p.t4lo = nullptr;
         } else {
             std::vector<cx<R>> t256(256), t4(256);
+            if (N == LDS8K) {
+                // [even bins | odd bins]: bin 2 m + h, m = jj + 256 t, each half pair-interleaved like the 4096-point spectrum
+                for (int k = 0; k < LDS8K; ++k) {
+                    const int h = k & 1, m = k >> 1, t = m >> 8, jj = m & 255;
+                    const int at = ((h * 8 + (t >> 1)) * 256 + jj) * 2 + (t & 1);
+                    hs[at].x = (R)(re[k] / LDS8K); hs[at].y = (R)(-im[k] / LDS8K);
+                }
+            } else
             for (int k = 0; k < LDS_N; ++k) {
                 // float32: thread j multiplies elements j + 256 t; the pairs (t, t + 1) sit next to each other so it loads them 16 bytes at a time
                 const int t = k >> 8, jj = k & 255;
@@ -470,11 +559,14 @@ template <typename R> static Plan get_plan(const R *kf, int64_t K, int64_t lead,
             for (int i = 0; i < 256; ++i) t256[i] = W(i, 256);
             for (int t = 0; t < 16; ++t)
                 for (int a2 = 0; a2 < 16; ++a2) t4[16 * t + a2] = W(t * a2, 4096);
-            hs.insert(hs.end(), t256.begin(), t256.end());    // one allocation, one copy: spectrum | W256 | W4096 table
+            hs.insert(hs.end(), t256.begin(), t256.end());    // one allocation, one copy: spectrum | W256 | W4096 table | W8192^j
             hs.insert(hs.end(), t4.begin(), t4.end());
+            if (N == LDS8K)
+                for (int i = 0; i < 256; ++i) hs.push_back(W(i, 8192));
             p.Hs = upload<R>(hs);
-            p.tw256 = (char *)p.Hs + (size_t)LDS_N * sizeof(cx<R>);
+            p.tw256 = (char *)p.Hs + (size_t)N * sizeof(cx<R>);
             p.t4lo = (char *)p.tw256 + 256 * sizeof(cx<R>);
+            p.w8k = (char *)p.t4lo + 256 * sizeof(cx<R>);
         }
         it = g_plans.emplace(std::move(key), p).first;
     }
@@ -501,17 +593,22 @@ void olslds_clear()
     for (int d = 0; d < TFX_MAX_DEVICES; ++d) { g_last_key[d] = nullptr; g_last[d] = nullptr; }
 }
 
-// taps this path takes: at least half of every block must be valid output -- 4096 points for K <= 2048 (float32 and float64),
-// 16 384 points for 2048 < K <= 8192 on rows the three-pass pipeline does not take (float32: float64 would need 272 KB of LDS)
+// taps this path takes: at least half of every block must be valid output -- 4096 points for K <= 1024 (float32; measured
+// equal to the 8192-point block at 1024 taps, faster below) and K <= 2048 (float64), 8192 points for 1024 < K <= 4096
+// (float32: 64 x 2.88 M, 2048 taps 0.49 -> 0.40 ms, 4096 taps 0.85 (three passes) -> 0.57), 16 384 points for
+// 4096 < K <= 8192 on rows the three-pass pipeline does not take (float32: float64 would need 272 KB of LDS)
 bool olslds_supported(int64_t K, int dtype, int64_t L, int64_t *N_out)
 {
     if (ldsfft::envi("TFX_OLS_LDS", 1) == 0 || ldsfft::envi("TFX_OLS_NATIVE", 1) == 0) return false;
     const int64_t lg = ldsfft::envi("TFX_FFT_LOG2N", 0);
-    if (lg != 0 && lg != 12 && lg != 14) return false;                     // a forced block size of another path
+    if (lg != 0 && lg != 12 && lg != 13 && lg != 14) return false;         // a forced block size of another path
     int64_t N = 0;
     const int64_t use16k = ldsfft::envi("TFX_OLS_LDS16K", 1);                // 0 never, 1 where the three-pass pipeline does not reach, 2 always
-    if (K >= 1 && K <= ldsfft::LDS_N / 2 && lg != 14) N = ldsfft::LDS_N;
-    else if (K >= 1 && K <= ldsfft::LDS16K / 2 && dtype == TFX_F32 && lg != 12 &&
+    const int64_t min8k = ldsfft::envi("TFX_OLS_LDS8K_MINK", 1025);          // taps from which the 8192-point block pays (0: never)
+    const bool can8k = dtype == TFX_F32 && K >= 1 && K <= ldsfft::LDS8K / 2 && min8k > 0 && (lg == 0 || lg == 13);
+    if (can8k && (lg == 13 || K >= min8k || K > ldsfft::LDS_N / 2)) N = ldsfft::LDS8K;
+    else if (K >= 1 && K <= ldsfft::LDS_N / 2 && lg != 14 && lg != 13) N = ldsfft::LDS_N;
+    else if (K >= 1 && K <= ldsfft::LDS16K / 2 && dtype == TFX_F32 && (lg == 0 || lg == 14) &&
              (use16k >= 2 || lg == 14 || (use16k == 1 && L < 65536)))
         N = ldsfft::LDS16K;
     if (!N) return false;
@@ -570,6 +667,27 @@ static void olslds_typed(const R *x, R *y, int64_t C, int64_t Tn, const R *kf_ho
                 ProfScope ps("ols_lds16k_kernel", stream);
                 hipLaunchKernelGGL(ols_lds16k_kernel, dim3((unsigned)grid), dim3(1024), lds16k_bytes(), stream,
                                    (const float *)x, (float *)y, (const v4f *)plan.Hs, (const v2f *)plan.tw256, g, npairs, per_xcd16);
+                TFX_HIP(hipGetLastError());
+            }
+            if (g.ep_stat >= 0)
+                stat_finish(g.ep_partial, ep->per_row ? C : 1, ep->per_row ? g.F : g.nframes, g.ep_stat, ep->stat_out, stream);
+            return;
+        }
+    }
+    if constexpr (sizeof(R) == 4) {
+        if (N == LDS8K) {
+            static bool attr8k[TFX_MAX_DEVICES] = {};
+            if (!attr8k[dev]) {
+                TFX_HIP(hipFuncSetAttribute((const void *)ols_lds8192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<float>()));
+                attr8k[dev] = true;
+            }
+            const int64_t per_xcd8 = ceil_div(npairs, 8);
+            TFX_CHECK(per_xcd8 * 8 < ((int64_t)1 << 31), "fft_conv_forward: too many frames for one launch");
+            {
+                ProfScope ps("ols_lds8192_kernel", stream);
+                hipLaunchKernelGGL(ols_lds8192_kernel, dim3((unsigned)(per_xcd8 * 8)), dim3(256), lds_bytes<float>(), stream,
+                                   (const float *)x, (float *)y, (const v4f *)plan.Hs, (const cx<float> *)plan.tw256,
+                                   (const cx<float> *)plan.t4lo, (const v2f *)plan.w8k, g, npairs, per_xcd8);
                 TFX_HIP(hipGetLastError());
             }
             if (g.ep_stat >= 0)
