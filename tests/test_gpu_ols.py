@@ -138,7 +138,7 @@ def test_lds_ols_reference_shapes_vs_float64(C, T, K, dtype):
     tests/test_fftconv.py:64-122: [2, 44100], K = 5 ... 1024) run on the single-launch LDS kernel -- not rocFFT --
     in float32 and float64, odd frame counts (an unpaired last frame), rows shorter than one block, T < K."""
     info = ext().ols_plan_info(K, T, (K - 1, 0), torch.float32 if dtype == np.float32 else torch.float64)
-    assert info["path"] == "lds" and info["N"] == (8192 if (dtype == np.float32 and K > 1024) else 4096)
+    assert info["path"] == "lds" and info["N"] == (8192 if K >= (1025 if dtype == np.float32 else 700) else 4096)
     rng = np.random.default_rng(K * 7 + T)
     kf = (rng.standard_normal(K) / np.sqrt(K)).astype(np.float32).astype(dtype)      # taps are float32 values (fir.py:516)
     x = rnd((C, T), T + K, dtype)
@@ -182,7 +182,8 @@ def test_lds16k_ols_vs_float64(C, T, K, monkeypatch):
     short = T + K - 1 < 65536
     info = ext().ols_plan_info(K, T, (K - 1, 0))
     assert (info["path"], info["N"]) == (("lds", 8192) if K <= 4096 else ("lds", 16384) if short else ("passes", 65536))
-    assert ext().ols_plan_info(K, T, (K - 1, 0), torch.float64)["path"] == "rocfft"          # float64 would need 272 KB of LDS
+    i64 = ext().ols_plan_info(K, T, (K - 1, 0), torch.float64)                               # float64: 8192 points up to 4096 taps; 16 384 would need 272 KB of LDS
+    assert (i64["path"], i64["N"]) == (("lds", 8192) if K <= 4096 else ("rocfft", i64["N"]))
     rng = np.random.default_rng(K + T)
     kf = (rng.standard_normal(K) * np.exp(-np.arange(K) / (K / 5)) / np.sqrt(K)).astype(np.float32)
     x = rnd((C, T), T + K)
@@ -205,31 +206,39 @@ def test_lds16k_ols_vs_float64(C, T, K, monkeypatch):
     close(ext().fft_conv_forward(dev(x), kf, (K - 1, 0)), exp, 4e-6, "three passes / rocFFT")
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("C,T,K", [(2, 44100, 1025), (2, 44100, 2048), (3, 100_003, 4096), (1, 9000, 5), (5, 250_003, 3000), (2, 12_289, 2049),
                                    (64, 40_000, 1500), (1, 1, 1), (4, 98_304, 4000), (1, 8193, 4096), (3, 20_481, 4095)])
-def test_lds8k_ols_vs_float64(C, T, K, monkeypatch):
-    """The 8192-point block of the one-launch kernel (float32, default for 1024 < K <= 4096; TFX_FFT_LOG2N=13 forces it for
-    smaller K): one radix-2 step in registers around two 4096-point transforms.  Against a float64 FFT convolution for every
-    padding flavour, and against the 4096-point kernel / the three-pass pipeline on the same input."""
+def test_lds8k_ols_vs_float64(C, T, K, dtype, monkeypatch):
+    """The 8192-point block of the one-launch kernel (default for 1024 < K <= 4096 in float32 and 700 <= K <= 4096 in float64;
+    TFX_FFT_LOG2N=13 forces it for smaller K): one radix-2 step in registers around two 4096-point transforms.  Against a
+    float64 FFT convolution for every padding flavour, and against the 4096-point kernel / the three-pass pipeline / rocFFT on
+    the same input."""
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    tol = 4e-6 if dtype == np.float32 else TOL_CONV_F64
+    if K >= (1025 if dtype == np.float32 else 700):
+        info = ext().ols_plan_info(K, T, (K - 1, 0), tdt)
+        assert (info["path"], info["N"]) == ("lds", 8192)            # the default route
     monkeypatch.setenv("TFX_FFT_LOG2N", "13")
     rng = np.random.default_rng(K * 3 + T)
-    kf = (rng.standard_normal(K) / np.sqrt(K)).astype(np.float32)
-    x = rnd((C, T), T + K)
+    kf = (rng.standard_normal(K) / np.sqrt(K)).astype(np.float32).astype(dtype)
+    x = rnd((C, T), T + K, dtype)
     for pad in ((K - 1, 0), (100, 77), (0, K)):
         if T + pad[0] + pad[1] < K:
             continue
-        info = ext().ols_plan_info(K, T, pad)
+        info = ext().ols_plan_info(K, T, pad, tdt)
         assert (info["path"], info["N"]) == ("lds", 8192)
         y = ext().fft_conv_forward(dev(x), kf, pad)
-        close(y, _f64_corr(x, kf, *pad).astype(np.float32), 4e-6, f"C={C} T={T} K={K} pad={pad}")
+        assert y.dtype == tdt
+        close(y, _f64_corr(x, kf, *pad).astype(dtype), tol, f"C={C} T={T} K={K} pad={pad}")
     y8 = ext().fft_conv_forward(dev(x), kf, (K - 1, 0))
     monkeypatch.delenv("TFX_FFT_LOG2N")
     monkeypatch.setenv("TFX_OLS_LDS8K_MINK", "0")
-    other = ext().ols_plan_info(K, T, (K - 1, 0))
+    other = ext().ols_plan_info(K, T, (K - 1, 0), tdt)
     assert other["N"] != 8192
     y_other = ext().fft_conv_forward(dev(x), kf, (K - 1, 0))
-    close(y8, y_other.cpu().numpy(), 4e-6, f"8192-point kernel vs {other['path']} N={other['N']}")
-    if C * T > 100:
+    close(y8, y_other.cpu().numpy(), 4e-6 if dtype == np.float32 else 1e-12, f"8192-point kernel vs {other['path']} N={other['N']}")
+    if C * T > 100 and dtype == np.float32:
         assert not torch.equal(y8, y_other)          # a different kernel really ran
 
 
@@ -245,7 +254,9 @@ def test_lds_ols_plan_info_paths():
     i = e.ols_plan_info(4096, 44100, (4095, 0))
     assert (i["path"], i["N"]) == ("lds", 8192)
     assert e.ols_plan_info(8193, 44100, (8192, 0))["path"] == "rocfft"
-    assert e.ols_plan_info(2049, 2_880_000, (2048, 0), torch.float64)["path"] == "rocfft"
+    i = e.ols_plan_info(2049, 2_880_000, (2048, 0), torch.float64)
+    assert (i["path"], i["N"]) == ("lds", 8192) and abs(i["bytes_per_sample"] - (8 * 8192 / i["S"] + 8)) < 1e-9
+    assert e.ols_plan_info(4097, 2_880_000, (4096, 0), torch.float64)["path"] == "rocfft"
     i = e.ols_plan_info(1024, 2_880_000, (1023, 0))
     assert i["S"] == 3072 and i["F"] == 938 and abs(i["bytes_per_sample"] - (4 * 4096 / 3072 + 4)) < 1e-9
     i = e.ols_plan_info(1024, 2_880_001, (1023, 0))                      # unaligned rows: no lead, odd hop

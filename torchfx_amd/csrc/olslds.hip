@@ -394,26 +394,59 @@ __device__ __forceinline__ void transform_pair8k(cx<float> (&v)[32], cx<float> *
     }
 }
 
-__global__ void __launch_bounds__(256, 4)
-ols_lds8192_kernel(const float *__restrict__ x, float *__restrict__ y, const v4f *__restrict__ Hq, const cx<float> *__restrict__ tw256g,
-                   const cx<float> *__restrict__ t4log, const v2f *__restrict__ w8kg, Geom<float> g, int64_t npairs, int64_t per_xcd)
+// float64 (and the unpacked cross-check): the same radix-2 step with the plain transform; spectrum [even | odd] in natural order
+template <typename R>
+__device__ __forceinline__ void transform_pair8k_plain(cx<R> (&v)[32], cx<R> *lds, const cx<R> *twB, const cx<R> *twA,
+                                                       const cx<R> *__restrict__ Hs, cx<R> wj, int j)
+{
+    cx<R> a[16], b[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const cx<R> w = t ? cmul(wj, twB[16 * t + 8]) : wj;
+        a[t] = cadd(v[t], v[t + 16]);
+        b[t] = cmul(csub(v[t], v[t + 16]), w);
+    }
+    fft4096<R, false>(a, lds, twB, twA, j);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) a[t] = cmul(a[t], Hs[j + 256 * t]);
+    fft4096<R, false>(b, lds, twB, twA, j);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) b[t] = cmul(b[t], Hs[4096 + j + 256 * t]);
+    fft4096<R, true>(a, lds, twB, twA, j);
+    fft4096<R, true>(b, lds, twB, twA, j);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const cx<R> w = t ? cmul(wj, twB[16 * t + 8]) : wj;
+        const cx<R> bw = cmulc(b[t], w);
+        v[t] = cadd(a[t], bw);
+        v[t + 16] = csub(a[t], bw);
+    }
+}
+
+template <typename R>
+__global__ void __launch_bounds__(256, sizeof(R) == 4 ? 4 : 2)
+ols_lds8192_kernel(const R *__restrict__ x, R *__restrict__ y, const cx<R> *__restrict__ Hs, const cx<R> *__restrict__ tw256g,
+                   const cx<R> *__restrict__ t4log, const cx<R> *__restrict__ w8kg, Geom<R> g, int64_t npairs, int64_t per_xcd)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    cx<float> *lds = (cx<float> *)smem;
-    cx<float> *twB = lds + LDS_N + LDS_N / 16;
-    cx<float> *twA = twB + 256;
+    cx<R> *lds = (cx<R> *)smem;
+    cx<R> *twB = lds + LDS_N + LDS_N / 16;
+    cx<R> *twA = twB + 256;
     const int j = threadIdx.x;
     twB[j] = tw256g[((j >> 4) * (j & 15)) & 255];
     twA[j] = t4log[j];
     const int64_t pair = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if ((int64_t)(blockIdx.x >> 3) >= per_xcd || pair >= npairs) return;
-    const v2f wj = w8kg[j];
+    const cx<R> wj = w8kg[j];
     __syncthreads();
-    cx<float> v[32];
-    const PairAt<float> p(pair, g);
-    fetch_pair<float, LDS8K, 32>(v, x, g, p, j);
-    transform_pair8k(v, lds, twB, twA, Hq, wj, j);
-    store_pair<float, LDS8K, 32>(v, y, g, p, j, smem);
+    cx<R> v[32];
+    const PairAt<R> p(pair, g);
+    fetch_pair<R, LDS8K, 32>(v, x, g, p, j);
+    if constexpr (sizeof(R) == 4)
+        transform_pair8k(v, lds, twB, twA, (const v4f *)Hs, __builtin_bit_cast(v2f, wj), j);
+    else
+        transform_pair8k_plain<R>(v, lds, twB, twA, Hs, wj, j);
+    store_pair<R, LDS8K, 32>(v, y, g, p, j, smem);
 }
 
 // ---- second block size: 16 384 points, one 1024-thread workgroup per pair of frames (float32; 2048 < K <= 8192) ----------
@@ -546,7 +579,7 @@ template <typename R> static Plan get_plan(const R *kf, int64_t K, int64_t lead,
                 // [even bins | odd bins]: bin 2 m + h, m = jj + 256 t, each half pair-interleaved like the 4096-point spectrum
                 for (int k = 0; k < LDS8K; ++k) {
                     const int h = k & 1, m = k >> 1, t = m >> 8, jj = m & 255;
-                    const int at = ((h * 8 + (t >> 1)) * 256 + jj) * 2 + (t & 1);
+                    const int at = sizeof(R) == 4 ? ((h * 8 + (t >> 1)) * 256 + jj) * 2 + (t & 1) : h * 4096 + m;
                     hs[at].x = (R)(re[k] / LDS8K); hs[at].y = (R)(-im[k] / LDS8K);
                 }
             } else
@@ -594,9 +627,10 @@ void olslds_clear()
 }
 
 // taps this path takes: at least half of every block must be valid output -- 4096 points for K <= 1024 (float32; measured
-// equal to the 8192-point block at 1024 taps, faster below) and K <= 2048 (float64), 8192 points for 1024 < K <= 4096
-// (float32: 64 x 2.88 M, 2048 taps 0.49 -> 0.40 ms, 4096 taps 0.85 (three passes) -> 0.57), 16 384 points for
-// 4096 < K <= 8192 on rows the three-pass pipeline does not take (float32: float64 would need 272 KB of LDS)
+// equal to the 8192-point block at 1024 taps, faster below) and K < 700 (float64), 8192 points above that up to 4096 taps
+// (float32, 64 x 2.88 M: 2048 taps 0.49 -> 0.40 ms, 4096 taps 0.85 (three passes) -> 0.57; float64, 32 x 2.88 M: 2048 taps
+// 0.60 -> 0.44, 4096 taps 3.0 (rocFFT) -> 0.62), 16 384 points for 4096 < K <= 8192 on rows the three-pass pipeline does
+// not take (float32: float64 would need 272 KB of LDS)
 bool olslds_supported(int64_t K, int dtype, int64_t L, int64_t *N_out)
 {
     if (ldsfft::envi("TFX_OLS_LDS", 1) == 0 || ldsfft::envi("TFX_OLS_NATIVE", 1) == 0) return false;
@@ -604,9 +638,10 @@ bool olslds_supported(int64_t K, int dtype, int64_t L, int64_t *N_out)
     if (lg != 0 && lg != 12 && lg != 13 && lg != 14) return false;         // a forced block size of another path
     int64_t N = 0;
     const int64_t use16k = ldsfft::envi("TFX_OLS_LDS16K", 1);                // 0 never, 1 where the three-pass pipeline does not reach, 2 always
-    const int64_t min8k = ldsfft::envi("TFX_OLS_LDS8K_MINK", 1025);          // taps from which the 8192-point block pays (0: never)
-    const bool can8k = dtype == TFX_F32 && K >= 1 && K <= ldsfft::LDS8K / 2 && min8k > 0 && (lg == 0 || lg == 13);
-    if (can8k && (lg == 13 || K >= min8k || K > ldsfft::LDS_N / 2)) N = ldsfft::LDS8K;
+    // taps from which the 8192-point block pays (0: never): measured equal at 1024 taps in float32, at 512 in float64
+    const int64_t min8k = ldsfft::envi("TFX_OLS_LDS8K_MINK", dtype == TFX_F32 ? 1025 : 700);
+    const bool can8k = K >= 1 && K <= ldsfft::LDS8K / 2 && min8k > 0 && (lg == 0 || lg == 13);
+    if (can8k && (lg == 13 || K >= min8k)) N = ldsfft::LDS8K;
     else if (K >= 1 && K <= ldsfft::LDS_N / 2 && lg != 14 && lg != 13) N = ldsfft::LDS_N;
     else if (K >= 1 && K <= ldsfft::LDS16K / 2 && dtype == TFX_F32 && (lg == 0 || lg == 14) &&
              (use16k >= 2 || lg == 14 || (use16k == 1 && L < 65536)))
@@ -674,26 +709,24 @@ static void olslds_typed(const R *x, R *y, int64_t C, int64_t Tn, const R *kf_ho
             return;
         }
     }
-    if constexpr (sizeof(R) == 4) {
-        if (N == LDS8K) {
-            static bool attr8k[TFX_MAX_DEVICES] = {};
-            if (!attr8k[dev]) {
-                TFX_HIP(hipFuncSetAttribute((const void *)ols_lds8192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<float>()));
-                attr8k[dev] = true;
-            }
-            const int64_t per_xcd8 = ceil_div(npairs, 8);
-            TFX_CHECK(per_xcd8 * 8 < ((int64_t)1 << 31), "fft_conv_forward: too many frames for one launch");
-            {
-                ProfScope ps("ols_lds8192_kernel", stream);
-                hipLaunchKernelGGL(ols_lds8192_kernel, dim3((unsigned)(per_xcd8 * 8)), dim3(256), lds_bytes<float>(), stream,
-                                   (const float *)x, (float *)y, (const v4f *)plan.Hs, (const cx<float> *)plan.tw256,
-                                   (const cx<float> *)plan.t4lo, (const v2f *)plan.w8k, g, npairs, per_xcd8);
-                TFX_HIP(hipGetLastError());
-            }
-            if (g.ep_stat >= 0)
-                stat_finish(g.ep_partial, ep->per_row ? C : 1, ep->per_row ? g.F : g.nframes, g.ep_stat, ep->stat_out, stream);
-            return;
+    if (N == LDS8K) {
+        static bool attr8k[TFX_MAX_DEVICES] = {};
+        if (!attr8k[dev]) {
+            TFX_HIP(hipFuncSetAttribute((const void *)ols_lds8192_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<R>()));
+            attr8k[dev] = true;
         }
+        const int64_t per_xcd8 = ceil_div(npairs, 8);
+        TFX_CHECK(per_xcd8 * 8 < ((int64_t)1 << 31), "fft_conv_forward: too many frames for one launch");
+        {
+            ProfScope ps("ols_lds8192_kernel", stream);
+            hipLaunchKernelGGL(ols_lds8192_kernel<R>, dim3((unsigned)(per_xcd8 * 8)), dim3(256), lds_bytes<R>(), stream,
+                               x, y, (const cx<R> *)plan.Hs, (const cx<R> *)plan.tw256, (const cx<R> *)plan.t4lo,
+                               (const cx<R> *)plan.w8k, g, npairs, per_xcd8);
+            TFX_HIP(hipGetLastError());
+        }
+        if (g.ep_stat >= 0)
+            stat_finish(g.ep_partial, ep->per_row ? C : 1, ep->per_row ? g.F : g.nframes, g.ep_stat, ep->stat_out, stream);
+        return;
     }
     static bool attr_tab[TFX_MAX_DEVICES] = {};
     if (!attr_tab[dev]) {
