@@ -176,12 +176,13 @@ def test_lds_ols_padding_alignment_and_env_switch(dtype, monkeypatch):
 @pytest.mark.parametrize("C,T,K", [(2, 44100, 2049), (3, 100_000, 4096), (1, 30_000, 8192), (5, 250_003, 5000), (2, 12_289, 4097),
                                    (64, 40_000, 3441), (1, 5000, 2500), (4, 98_304, 8000)])
 def test_lds16k_ols_vs_float64(C, T, K, monkeypatch):
-    """2048 < K <= 8192 (float32): the 16 384-point workgroup transform (fftpk16k.h) against a float64 FFT convolution and against
-    the other paths.  By default it takes 4096 < K <= 8192 on the rows the three-pass pipeline does not reach (padded length
-    < 65 536, where the alternative is rocFFT); K <= 4096 belongs to the 8192-point kernel; TFX_FFT_LOG2N=14 forces it."""
+    """2048 < K <= 8192 (float32) at 16 384 points: the 1024-thread workgroup transform (fftpk16k.h; the default for
+    4096 < K <= 8192 on rows shorter than 65 536 samples) and the radix-4 step around four 4096-point transforms in a 256-thread
+    workgroup (the default on longer rows), each forced on every shape, against a float64 FFT convolution and against the
+    three-pass pipeline / rocFFT.  K <= 4096 belongs to the 8192-point kernel by default."""
     short = T + K - 1 < 65536
     info = ext().ols_plan_info(K, T, (K - 1, 0))
-    assert (info["path"], info["N"]) == (("lds", 8192) if K <= 4096 else ("lds", 16384) if short else ("passes", 65536))
+    assert (info["path"], info["N"]) == (("lds", 8192) if K <= 4096 else ("lds", 16384))
     i64 = ext().ols_plan_info(K, T, (K - 1, 0), torch.float64)                               # float64: 8192 points up to 4096 taps; 16 384 would need 272 KB of LDS
     assert (i64["path"], i64["N"]) == (("lds", 8192) if K <= 4096 else ("rocfft", i64["N"]))
     rng = np.random.default_rng(K + T)
@@ -191,16 +192,23 @@ def test_lds16k_ols_vs_float64(C, T, K, monkeypatch):
     y_default = ext().fft_conv_forward(dev(x), kf, (K - 1, 0))
     close(y_default, exp, 4e-6, "default route")
     monkeypatch.setenv("TFX_FFT_LOG2N", "14")
-    assert ext().ols_plan_info(K, T, (K - 1, 0))["path"] == "lds" and ext().ols_plan_info(K, T, (K - 1, 0))["N"] == 16384
-    y16 = ext().fft_conv_forward(dev(x), kf, (K - 1, 0))
-    close(y16, exp, 4e-6, f"C={C} T={T} K={K} 16k")
-    if short and K > 4096:
-        assert torch.equal(y16, y_default)
-    for pad in ((100, 77), (0, K)):
-        if T + pad[0] + pad[1] >= K:
-            close(ext().fft_conv_forward(dev(x), kf, pad), _f64_corr(x, kf, *pad).astype(np.float32), 4e-6, f"pad={pad}")
+    outs = {}
+    for name, r4, wg in (("1024-thread workgroup", "0", "2"), ("radix 4 around 4096", "2", "1")):
+        monkeypatch.setenv("TFX_OLS_LDS16K_R4", r4)
+        monkeypatch.setenv("TFX_OLS_LDS16K", wg)
+        assert ext().ols_plan_info(K, T, (K - 1, 0))["path"] == "lds" and ext().ols_plan_info(K, T, (K - 1, 0))["N"] == 16384
+        outs[name] = ext().fft_conv_forward(dev(x), kf, (K - 1, 0))
+        close(outs[name], exp, 4e-6, f"C={C} T={T} K={K} {name}")
+        for pad in ((100, 77), (0, K)):
+            if T + pad[0] + pad[1] >= K:
+                close(ext().fft_conv_forward(dev(x), kf, pad), _f64_corr(x, kf, *pad).astype(np.float32), 4e-6, f"{name} pad={pad}")
+    if C * T > 100:
+        assert not torch.equal(outs["1024-thread workgroup"], outs["radix 4 around 4096"])       # two different kernels ran
+    if K > 4096:
+        assert torch.equal(y_default, outs["1024-thread workgroup" if short else "radix 4 around 4096"])
     monkeypatch.delenv("TFX_FFT_LOG2N")
     monkeypatch.setenv("TFX_OLS_LDS16K", "0")
+    monkeypatch.setenv("TFX_OLS_LDS16K_R4", "0")
     monkeypatch.setenv("TFX_OLS_LDS8K_MINK", "0")
     assert ext().ols_plan_info(K, T, (K - 1, 0))["path"] == ("rocfft" if short else "passes")
     close(ext().fft_conv_forward(dev(x), kf, (K - 1, 0)), exp, 4e-6, "three passes / rocFFT")
@@ -248,7 +256,9 @@ def test_lds_ols_plan_info_paths():
     assert e.ols_plan_info(2048, 2_880_000, (2047, 0), torch.float64)["path"] == "lds"
     i = e.ols_plan_info(2049, 2_880_000, (2048, 0))                                     # up to 4096 taps: the 8192-point block, any row length
     assert (i["path"], i["N"]) == ("lds", 8192)
-    assert e.ols_plan_info(4097, 2_880_000, (4096, 0))["path"] == "passes"            # long rows: the three-pass pipeline is faster
+    i = e.ols_plan_info(4097, 2_880_000, (4096, 0))                                     # up to 8192 taps: 16 384 points in one launch
+    assert (i["path"], i["N"]) == ("lds", 16384)
+    assert e.ols_plan_info(8193, 2_880_000, (8192, 0))["path"] == "passes"
     i = e.ols_plan_info(8000, 44100, (7999, 0))                                         # short rows: one launch instead of rocFFT
     assert (i["path"], i["N"]) == ("lds", 16384)
     i = e.ols_plan_info(4096, 44100, (4095, 0))

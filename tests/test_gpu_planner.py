@@ -55,8 +55,8 @@ def test_chain_with_iir_gain_golden(golden, policy, monkeypatch):
     high-pass, then FIR-257 | FIR-2049) under the plans: default, one overlap-save pass for the whole chain, cascade
     kernel + merged FIR, and the reference's staging.  The merged 2305-tap FIR runs on the one-launch 8192-point kernel
     (9.6 B/sample), so by the planner's byte model the cascade stays its own 8 B/sample pass by default: folding its
-    impulse response in would push the run past 4096 taps onto the three-pass pipeline (~26 B/sample).  Without that
-    kernel (`auto_fold`) the fold pays and the whole chain is one pass."""
+    impulse response in would push the run past 4096 taps onto the three-pass pipeline (~26 B/sample).  Without the
+    8192- and 16 384-point kernels (`auto_fold`) the fold pays and the whole chain is one pass."""
     from scipy.signal import firwin
     from torchfx_amd import Wave
     from torchfx_amd import filter as F
@@ -64,6 +64,7 @@ def test_chain_with_iir_gain_golden(golden, policy, monkeypatch):
     w = Wave(g["x"], 48000, device=DEV)
     if policy == "auto_fold":
         monkeypatch.setenv("TFX_OLS_LDS8K_MINK", "0")
+        monkeypatch.setenv("TFX_OLS_LDS16K", "0")
     elif policy != "auto":
         w.fuse_spectral = False
         w.fuse_fir = policy == "fir_only"

@@ -458,12 +458,13 @@ def test_default_plan_folds_a_cascade_with_gain_into_the_fir_run(oracle_backend,
     single FIR: the 3-filter IIR run as taps, convolved with both FIRs.  The planner prices the fold in HBM bytes
     (`Wave._ols_bytes_per_sample`): the merged 2305-tap FIR alone runs on the one-launch 8192-point kernel at 9.6 B/sample,
     with the cascade's impulse response folded in it would need the three-pass pipeline (~26 B/sample) -- so by default the
-    cascade stays its own 8 B/sample pass; without the 8192-point kernel the fold pays."""
+    cascade stays its own 8 B/sample pass; without the 8192- and 16 384-point kernels the fold pays."""
     g = golden("chain_gain")
     w = _gain_chain(fx.Wave(g["x"], 48000))
     assert [type(m).__name__ for m in w.plan()] == ["FusedSOSCascade", "FIR"]
     close(w.ys, g["y"], 2e-5)
     monkeypatch.setenv("TFX_OLS_LDS8K_MINK", "0")
+    monkeypatch.setenv("TFX_OLS_LDS16K", "0")
     w = _gain_chain(fx.Wave(g["x"], 48000))
     plan = w.plan()
     assert [type(m).__name__ for m in plan] == ["FIR"] and plan[0].kernel.numel() > 257 + 2049

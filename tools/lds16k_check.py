@@ -1,0 +1,26 @@
+"""16 384-point radix-4 LDS overlap-save (TFX_OLS_LDS16K_R4=2) against a float64 FFT convolution (development)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from scipy.signal import fftconvolve
+from torchfx_amd import torchfx_ext as E
+
+os.environ["TFX_OLS_LDS16K_R4"] = "2"
+os.environ["TFX_FFT_LOG2N"] = "14"
+worst = 0.0
+for C, T, K in [(2, 44100, 5000), (3, 100_003, 8192), (1, 20000, 5), (5, 250_003, 6000), (2, 32_769, 4097), (16, 140_000, 7000), (1, 1, 1)]:
+    rng = np.random.default_rng(K + T)
+    kf = (rng.standard_normal(K) / np.sqrt(K)).astype(np.float32)
+    x = rng.uniform(-1, 1, (C, T)).astype(np.float32)
+    for pad in ((K - 1, 0), (100, 77), (0, K)):
+        if T + pad[0] + pad[1] < K:
+            continue
+        info = E.ols_plan_info(K, T, pad)
+        y = E.fft_conv_forward(torch.from_numpy(x).cuda(), kf, pad).cpu().numpy()
+        xp = np.pad(x.astype(np.float64), ((0, 0), pad))
+        ref = fftconvolve(xp, kf[::-1].astype(np.float64)[None], mode="valid", axes=-1)
+        err = np.abs(y - ref).max() / max(1.0, np.abs(ref).max())
+        worst = max(worst, err)
+        print(C, T, K, pad, info["path"], info["N"], info["S"], f"{err:.2e}", flush=True)
+print("worst", worst)
+assert worst < 4e-6

@@ -449,6 +449,84 @@ ols_lds8192_kernel(const R *__restrict__ x, R *__restrict__ y, const cx<R> *__re
     store_pair<R, LDS8K, 32>(v, y, g, p, j, smem);
 }
 
+// ---- 16 384 points in the same 256-thread workgroup (float32; 4096 < K <= 8192 on long rows) --------------------------------
+// The same construction one level up: a radix-4 step in registers around FOUR 4096-point transforms (thread j holds
+// z[j + 256 t], t < 64: u_r = sum_q z[n + 4096 q] W4^(q r), times W16384^(n r), FFT_4096(u_r) = the bins 4 m + r).
+// W16384^((j + 256 t) r) = W16384^(j r) W64^(t r): three table entries per thread times W256^(4 t r) = twB[16 t + 4 r] from LDS.
+// 128 VGPRs of data, 198 in all: two workgroups per CU instead of four, still well ahead of the three-pass pipeline
+// (64 x 2.88 M: 4097 / 5000 / 6000 / 8192 taps 0.50 / 0.52 / 0.56 / 0.67 ms against 0.84 / 0.85 / 0.89 / 0.91).
+// Spectrum: [r][the pair-interleaved order of the 4096-point kernel over m].
+__device__ __forceinline__ void transform_pair16k_r4(cx<float> (&v)[64], cx<float> *lds, const cx<float> *twB_, const cx<float> *twA_,
+                                                     const v4f *__restrict__ Hq, const v2f *__restrict__ w16kg, int j)
+{
+    const v2f Wc = {0.92387953251128675613f, 0.38268343236508977173f}, Wr = {0.70710678118654752440f, 0.70710678118654752440f};
+    const v2f *twB = (const v2f *)twB_, *twA = (const v2f *)twA_;
+    v2f u[4][16];
+    {
+        const v2f w1 = w16kg[j], w2 = w16kg[256 + j], w3 = w16kg[512 + j];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            v2f a0 = __builtin_bit_cast(v2f, v[t]), a1 = __builtin_bit_cast(v2f, v[t + 16]);
+            v2f a2 = __builtin_bit_cast(v2f, v[t + 32]), a3 = __builtin_bit_cast(v2f, v[t + 48]);
+            pk::pk_dft4<false, false>(a0, a1, a2, a3);
+            u[0][t] = a0;
+            u[1][t] = pk::pk_cmul<false>(a1, t ? pk::pk_cmul<false>(w1, twB[16 * t + 4]) : w1);
+            u[2][t] = pk::pk_cmul<false>(a2, t ? pk::pk_cmul<false>(w2, twB[16 * t + 8]) : w2);
+            u[3][t] = pk::pk_cmul<false>(a3, t ? pk::pk_cmul<false>(w3, twB[16 * t + 12]) : w3);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        pk::fft4096_pk<false>(u[r], (v2f *)lds, twB, twA, j, Wc, Wr);
+        v4f q[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) q[m] = Hq[(8 * r + m) * 256 + j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            u[r][2 * m] = pk::pk_cmul<false>(u[r][2 * m], v2f{q[m].x, q[m].y});
+            u[r][2 * m + 1] = pk::pk_cmul<false>(u[r][2 * m + 1], v2f{q[m].z, q[m].w});
+        }
+        pk::fft4096_pk<true>(u[r], (v2f *)lds, twB, twA, j, Wc, Wr);
+    }
+    {
+        const v2f w1 = w16kg[j], w2 = w16kg[256 + j], w3 = w16kg[512 + j];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            v2f a0 = u[0][t];
+            v2f a1 = pk::pk_cmul<true>(u[1][t], t ? pk::pk_cmul<false>(w1, twB[16 * t + 4]) : w1);
+            v2f a2 = pk::pk_cmul<true>(u[2][t], t ? pk::pk_cmul<false>(w2, twB[16 * t + 8]) : w2);
+            v2f a3 = pk::pk_cmul<true>(u[3][t], t ? pk::pk_cmul<false>(w3, twB[16 * t + 12]) : w3);
+            pk::pk_dft4<true, false>(a0, a1, a2, a3);
+            v[t] = __builtin_bit_cast(cx<float>, a0);
+            v[t + 16] = __builtin_bit_cast(cx<float>, a1);
+            v[t + 32] = __builtin_bit_cast(cx<float>, a2);
+            v[t + 48] = __builtin_bit_cast(cx<float>, a3);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256, 2)          // 198 VGPRs; at three workgroups per CU (168) it spills and runs 5-8 % slower
+ols_lds16k_r4_kernel(const float *__restrict__ x, float *__restrict__ y, const v4f *__restrict__ Hq, const cx<float> *__restrict__ tw256g,
+                     const cx<float> *__restrict__ t4log, const v2f *__restrict__ w16kg, Geom<float> g, int64_t npairs, int64_t per_xcd)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cx<float> *lds = (cx<float> *)smem;
+    cx<float> *twB = lds + LDS_N + LDS_N / 16;
+    cx<float> *twA = twB + 256;
+    const int j = threadIdx.x;
+    twB[j] = tw256g[((j >> 4) * (j & 15)) & 255];
+    twA[j] = t4log[j];
+    const int64_t pair = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= per_xcd || pair >= npairs) return;
+    __syncthreads();
+    cx<float> v[64];
+    const PairAt<float> p(pair, g);
+    fetch_pair<float, 16384, 64>(v, x, g, p, j);
+    transform_pair16k_r4(v, lds, twB, twA, Hq, w16kg, j);
+    store_pair<float, 16384, 64>(v, y, g, p, j, smem);
+}
+
 // ---- second block size: 16 384 points, one 1024-thread workgroup per pair of frames (float32; 2048 < K <= 8192) ----------
 // fftpk16k.h: radix 16 x 16 x 16 x 4, three exchanges per direction through 136 KB of LDS -- ONE workgroup per CU, sixteen
 // wavefronts that run their phases in lockstep.  Measured against the three-pass pipeline on rows long enough for it
@@ -523,12 +601,13 @@ template <typename R> static void *upload(const std::vector<cx<R>> &h)
     return d;
 }
 
-template <typename R> static Plan get_plan(const R *kf, int64_t K, int64_t lead, int N)
+// kind: 0 = 4096 points, 1 = 8192 (radix 2 around 4096), 2 = 16 384 in a 1024-thread workgroup, 3 = 16 384 as radix 4 around 4096
+template <typename R> static Plan get_plan(const R *kf, int64_t K, int64_t lead, int N, int kind)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     const int dev = current_device();
     const size_t nb = (size_t)K * sizeof(R);
-    const char tail[3] = {(char)(sizeof(R) + (N == LDS16K ? 64 : N == LDS8K ? 32 : 0)), (char)lead, (char)dev};
+    const char tail[3] = {(char)(sizeof(R) + 16 * kind), (char)lead, (char)dev};
     if (const std::vector<char> *lk_ = g_last_key[dev]) {       // steady state: one memcmp, no key construction
         if (lk_->size() == nb + 3 && memcmp(lk_->data(), kf, nb) == 0 && memcmp(lk_->data() + nb, tail, 3) == 0) return *g_last[dev];
     }
@@ -553,7 +632,7 @@ template <typename R> static Plan get_plan(const R *kf, int64_t K, int64_t lead,
             return w;
         };
         Plan p;
-        if (N == LDS16K) {
+        if (kind == 2) {
             // spectral ownership of fftpk16k.h: thread r, register s <-> bin (r & 255) + 256 (4 (r >> 8) + s / 4) + 4096 (s % 4);
             // registers (2 m, 2 m + 1) of a thread sit next to each other: one 16-byte load
             for (int r = 0; r < 1024; ++r)
@@ -575,7 +654,14 @@ template <typename R> static Plan get_plan(const R *kf, int64_t K, int64_t lead,
             p.t4lo = nullptr;
         } else {
             std::vector<cx<R>> t256(256), t4(256);
-            if (N == LDS8K) {
+            if (kind == 3) {
+                // [r][...]: bin 4 m + r, m = jj + 256 t, each quarter pair-interleaved like the 4096-point spectrum
+                for (int k = 0; k < LDS16K; ++k) {
+                    const int r = k & 3, m = k >> 2, t = m >> 8, jj = m & 255;
+                    const int at = ((r * 8 + (t >> 1)) * 256 + jj) * 2 + (t & 1);
+                    hs[at].x = (R)(re[k] / LDS16K); hs[at].y = (R)(-im[k] / LDS16K);
+                }
+            } else if (kind == 1) {
                 // [even bins | odd bins]: bin 2 m + h, m = jj + 256 t, each half pair-interleaved like the 4096-point spectrum
                 for (int k = 0; k < LDS8K; ++k) {
                     const int h = k & 1, m = k >> 1, t = m >> 8, jj = m & 255;
@@ -594,8 +680,11 @@ template <typename R> static Plan get_plan(const R *kf, int64_t K, int64_t lead,
                 for (int a2 = 0; a2 < 16; ++a2) t4[16 * t + a2] = W(t * a2, 4096);
             hs.insert(hs.end(), t256.begin(), t256.end());    // one allocation, one copy: spectrum | W256 | W4096 table | W8192^j
             hs.insert(hs.end(), t4.begin(), t4.end());
-            if (N == LDS8K)
+            if (kind == 1)
                 for (int i = 0; i < 256; ++i) hs.push_back(W(i, 8192));
+            if (kind == 3)
+                for (int r = 1; r < 4; ++r)
+                    for (int i = 0; i < 256; ++i) hs.push_back(W(r * i, 16384));
             p.Hs = upload<R>(hs);
             p.tw256 = (char *)p.Hs + (size_t)N * sizeof(cx<R>);
             p.t4lo = (char *)p.tw256 + 256 * sizeof(cx<R>);
@@ -629,8 +718,8 @@ void olslds_clear()
 // taps this path takes: at least half of every block must be valid output -- 4096 points for K <= 1024 (float32; measured
 // equal to the 8192-point block at 1024 taps, faster below) and K < 700 (float64), 8192 points above that up to 4096 taps
 // (float32, 64 x 2.88 M: 2048 taps 0.49 -> 0.40 ms, 4096 taps 0.85 (three passes) -> 0.57; float64, 32 x 2.88 M: 2048 taps
-// 0.60 -> 0.44, 4096 taps 3.0 (rocFFT) -> 0.62), 16 384 points for 4096 < K <= 8192 on rows the three-pass pipeline does
-// not take (float32: float64 would need 272 KB of LDS)
+// 0.60 -> 0.44, 4096 taps 3.0 (rocFFT) -> 0.62), 16 384 points for 4096 < K <= 8192 (float32; TFX_OLS_LDS16K=0 and
+// TFX_OLS_LDS16K_R4=0 hand them back to the three-pass pipeline / rocFFT)
 bool olslds_supported(int64_t K, int dtype, int64_t L, int64_t *N_out)
 {
     if (ldsfft::envi("TFX_OLS_LDS", 1) == 0 || ldsfft::envi("TFX_OLS_NATIVE", 1) == 0) return false;
@@ -644,7 +733,8 @@ bool olslds_supported(int64_t K, int dtype, int64_t L, int64_t *N_out)
     if (can8k && (lg == 13 || K >= min8k)) N = ldsfft::LDS8K;
     else if (K >= 1 && K <= ldsfft::LDS_N / 2 && lg != 14 && lg != 13) N = ldsfft::LDS_N;
     else if (K >= 1 && K <= ldsfft::LDS16K / 2 && dtype == TFX_F32 && (lg == 0 || lg == 14) &&
-             (use16k >= 2 || lg == 14 || (use16k == 1 && L < 65536)))
+             (use16k >= 2 || lg == 14 || (use16k == 1 && (L < 65536 || ldsfft::envi("TFX_OLS_LDS16K_R4", 1) >= 1)) ||
+              ldsfft::envi("TFX_OLS_LDS16K_R4", 1) >= 2))
         N = ldsfft::LDS16K;
     if (!N) return false;
     if (N_out) *N_out = N;
@@ -682,11 +772,35 @@ static void olslds_typed(const R *x, R *y, int64_t C, int64_t Tn, const R *kf_ho
     g.pad_left = pl + lead;
     g.F = ceil_div(g.Tout, g.S);
     g.nframes = C * g.F;
-    const Plan plan = get_plan<R>(kf_host, K, lead, (int)N);
+    // 16 384 points: the 1024-thread workgroup on rows the three-pass pipeline does not reach (few pairs: the sixteen wavefronts
+    // of one pair run side by side), four 4096-point transforms in a 256-thread workgroup on long rows (TFX_OLS_LDS16K_R4: 0 never, 2 always)
+    const int64_t r4 = envi("TFX_OLS_LDS16K_R4", 1);
+    const bool use_r4 = N == LDS16K && sizeof(R) == 4 && (r4 >= 2 || (r4 == 1 && L >= 65536 && envi("TFX_OLS_LDS16K", 1) < 2));
+    const int kind = N == LDS_N ? 0 : N == LDS8K ? 1 : use_r4 ? 3 : 2;
+    const Plan plan = get_plan<R>(kf_host, K, lead, (int)N, kind);
     const int64_t npairs = ceil_div(g.nframes, 2);
     if (g.ep_stat >= 0) g.ep_partial = (double *)scratch("olslds_ep_partial", (size_t)g.nframes * sizeof(double), stream);
     const int dev = current_device();
     if constexpr (sizeof(R) == 4) {
+        if (kind == 3) {
+            static bool attr_r4[TFX_MAX_DEVICES] = {};
+            if (!attr_r4[dev]) {
+                TFX_HIP(hipFuncSetAttribute((const void *)ols_lds16k_r4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<float>()));
+                attr_r4[dev] = true;
+            }
+            const int64_t per_xcd4 = ceil_div(npairs, 8);
+            TFX_CHECK(per_xcd4 * 8 < ((int64_t)1 << 31), "fft_conv_forward: too many frames for one launch");
+            {
+                ProfScope ps("ols_lds16k_r4_kernel", stream);
+                hipLaunchKernelGGL(ols_lds16k_r4_kernel, dim3((unsigned)(per_xcd4 * 8)), dim3(256), lds_bytes<float>(), stream,
+                                   (const float *)x, (float *)y, (const v4f *)plan.Hs, (const cx<float> *)plan.tw256,
+                                   (const cx<float> *)plan.t4lo, (const v2f *)plan.w8k, g, npairs, per_xcd4);
+                TFX_HIP(hipGetLastError());
+            }
+            if (g.ep_stat >= 0)
+                stat_finish(g.ep_partial, ep->per_row ? C : 1, ep->per_row ? g.F : g.nframes, g.ep_stat, ep->stat_out, stream);
+            return;
+        }
         if (N == LDS16K) {
             static int cus_tab[TFX_MAX_DEVICES] = {};
             if (!cus_tab[dev]) {
