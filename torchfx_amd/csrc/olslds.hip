@@ -730,7 +730,9 @@ bool olslds_supported(int64_t K, int dtype, int64_t L, int64_t *N_out)
     // taps from which the 8192-point block pays (0: never): measured equal at 1024 taps in float32, at 512 in float64
     const int64_t min8k = ldsfft::envi("TFX_OLS_LDS8K_MINK", dtype == TFX_F32 ? 1025 : 700);
     const bool can8k = K >= 1 && K <= ldsfft::LDS8K / 2 && min8k > 0 && (lg == 0 || lg == 13);
-    if (can8k && (lg == 13 || K >= min8k)) N = ldsfft::LDS8K;
+    // rows shorter than 65 536 samples are a handful of workgroups that all run at once: the call takes as long as ONE workgroup,
+    // so the smallest block that fits wins there ([2, 44100], 1500 taps: 8 us at 4096 points, 15 us at 8192)
+    if (can8k && (lg == 13 || (K >= min8k && (L >= 65536 || K > ldsfft::LDS_N / 2)))) N = ldsfft::LDS8K;
     else if (K >= 1 && K <= ldsfft::LDS_N / 2 && lg != 14 && lg != 13) N = ldsfft::LDS_N;
     else if (K >= 1 && K <= ldsfft::LDS16K / 2 && dtype == TFX_F32 && (lg == 0 || lg == 14) &&
              (use16k >= 2 || lg == 14 || (use16k == 1 && (L < 65536 || ldsfft::envi("TFX_OLS_LDS16K_R4", 1) >= 1)) ||
