@@ -124,6 +124,18 @@ def make_step(workload: str, x: torch.Tensor):
     if workload == "fftconv":
         k = rev.kernel.reshape(-1)
         return (lambda: E.fft_conv_forward(x, k, (k.numel() - 1, 0))), "cfg4: overlap-save FFT conv, 65536 taps", 65536
+    if workload.startswith("fftconv_k"):                 # other kernel lengths of the FFT mode (not BASELINE configs): fftconv_k4096, ...
+        K = int(workload[len("fftconv_k"):])
+        kk = torch.from_numpy(reverb_ir(K)[::-1].copy())
+        info = E.ols_plan_info(K, x.shape[-1], (K - 1, 0))
+        return (lambda: E.fft_conv_forward(x, kk, (K - 1, 0))), (
+            f"overlap-save FFT conv, {K} taps: path {info['path']}, block {info['N']}, hop {info['S']}"), None
+    if workload == "iir_fir1024":
+        from torchfx_amd import Wave
+        plan = (Wave(x, FS, device=x.device) | f1 | f2 | fir).plan()
+        names = " | ".join(type(m).__name__ + (f"[{m.kernel.numel()} taps]" if getattr(m, "kernel", None) is not None else "") for m in plan)
+        return (lambda: (Wave(x, FS, device=x.device) | f1 | f2 | fir).ys), (
+            f"(Wave(x) | 4xbiquad | FIR-1024).ys, default fusion policy = {names}"), None
     if workload == "chain":
         from torchfx_amd import Wave
         plan, names = plan_chain(x)                       # for the description only; every step plans for itself
@@ -578,7 +590,8 @@ def main() -> None:
         stages = {}
         for key, wl, sec, bound in (("cfg2", "sos", 60.0, "hbm"), ("cfg2_precision_auto", "sos_auto", 60.0, "hbm"),
                                     ("cfg3", "fir", 60.0, "mfma"), ("cfg3_fft_mode", "fir_fft", 60.0, "hbm"),
-                                    ("cfg4", "fftconv", 600.0, "hbm")):
+                                    ("fft_mode_4096_taps", "fftconv_k4096", 60.0, "hbm"), ("fft_mode_8192_taps", "fftconv_k8192", 60.0, "hbm"),
+                                    ("iir_fir1024_pipe", "iir_fir1024", 60.0, "hbm"), ("cfg4", "fftconv", 600.0, "hbm")):
             try:
                 xs = x if sec == seconds else x[:, : int(sec * FS)].contiguous()
                 sstep, sdesc, _ = make_step(wl, xs)
