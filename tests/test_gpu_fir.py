@@ -63,7 +63,10 @@ def test_fir_direct_chunk_sizes_vs_oracle(C, T, K, kc, monkeypatch):
     (700, [300, 5000, 200, 9000]),                 # history longer than a chunk (old history shifts through)
     (129, [20_000, 4_096, 30_000]),                # MFMA Toeplitz kernel (rows >= 4096) / rocFFT path
     (200, [70_000, 66_000, 131_072]),              # LDS-resident overlap-save path, one and two blocks
-    (5000, [140_000, 70_001]),                     # long taps through the native path with history
+    (5000, [140_000, 70_001]),                     # long taps through the native path with history (16 384-point one-launch kernel)
+    (3000, [100_000, 5_000, 2_000, 70_000]),       # 8192-point one-launch kernel, long and short chunks, history longer than a chunk
+    (6000, [20_000, 9_000, 100_000]),              # 16 384 points: the 1024-thread workgroup on short chunks, the radix-4 kernel on long ones
+    (1500, [3_000, 80_000, 1_000]),                # 4096 points on short chunks, 8192 on long ones
 ])
 def test_fir_stream_forward_chunks_equal_one_shot(K, chunks, direct, fir_kernel):
     """tfx_fir_stream_forward: every chunk continues the previous one through a [C, K-1] history buffer the
