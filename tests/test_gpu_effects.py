@@ -157,13 +157,15 @@ def test_epilogue_statistics_and_golden_mix(golden):
         ref = rows.abs().max(dim=1).values if stat == "absmax" else (rows * rows).sum(dim=1)
         assert torch.allclose(ep.stat_value, ref, rtol=1e-12, atol=0), (stat, per_row)
         assert float(y.abs().max()) <= 1.0
-        k = torch.from_numpy((np.hanning(301) / np.hanning(301).sum()).astype(np.float32))
-        ep2 = e.Epilogue(gain=0.5, stat=stat, per_row=per_row)
-        y2 = e.fft_conv_forward(x, k, (300, 0), epilogue=ep2)                  # LDS-resident path: fused into the last pass
-        assert torch.equal(y2, e.gain_forward(e.fft_conv_forward(x, k, (300, 0)), 0.5))
-        rows = y2.double() if per_row else y2.double().reshape(1, -1)
-        ref = rows.abs().max(dim=1).values if stat == "absmax" else (rows * rows).sum(dim=1)
-        assert torch.allclose(ep2.stat_value, ref, rtol=1e-12, atol=0), ("fft", stat, per_row)
+        for taps, block in ((301, 4096), (3001, 8192), (6001, 16384)):         # the three one-launch kernels: fused into their stores
+            assert e.ols_plan_info(taps, x.shape[1], (taps - 1, 0))["N"] == block
+            k = torch.from_numpy((np.hanning(taps) / np.hanning(taps).sum()).astype(np.float32))
+            ep2 = e.Epilogue(gain=0.5, stat=stat, per_row=per_row)
+            y2 = e.fft_conv_forward(x, k, (taps - 1, 0), epilogue=ep2)
+            assert torch.equal(y2, e.gain_forward(e.fft_conv_forward(x, k, (taps - 1, 0)), 0.5))
+            rows = y2.double() if per_row else y2.double().reshape(1, -1)
+            ref = rows.abs().max(dim=1).values if stat == "absmax" else (rows * rows).sum(dim=1)
+            assert torch.allclose(ep2.stat_value, ref, rtol=1e-12, atol=0), ("fft", taps, stat, per_row)
     g = golden("effects")
     w = fx.Wave(g["mix_x"], 48000, device=DEV)
     for m in (F.LoButterworth(4000, order=2), F.HiButterworth(200, order=2), fx.Gain(0.5), F.LoButterworth(6000, order=2),
