@@ -256,8 +256,9 @@ int tfx_chunk_forward(const float *x, int64_t x_pitch, float *y, int64_t C, int6
 int tfx_ols_plan_info(int64_t K, int64_t T, int64_t pad_left, int64_t pad_right,
                       int64_t *N, int64_t *S, int64_t *F, int *native);
 /* The same for a signal of `dtype` (tfx_ols_plan_info answers for float32).  *path = 2: one launch, the
- * whole 4096-point transform in LDS (K <= 2048, float32 / float64; ~4 N/S + 4 bytes of HBM traffic per output
- * sample); 1: the three-pass four-step pipeline (float32, 20 N/S + 4); 0: rocFFT (~95). */
+ * whole transform of a block in LDS and registers (*N = 4096, 8192 or 16384: K <= 8192 in float32, K <= 4096 in
+ * float64; e N/S + e bytes of HBM traffic per output sample, e = element size); 1: the three-pass four-step
+ * pipeline (float32, 20 N/S + 4); 0: rocFFT (~95, float64 ~190). */
 int tfx_ols_plan_info2(int64_t K, int64_t T, int64_t pad_left, int64_t pad_right, int dtype,
                        int64_t *N, int64_t *S, int64_t *F, int *path);
 
