@@ -274,13 +274,16 @@ def test_lds_ols_plan_info_paths():
     assert i["S"] == 4096 - 1024 + 1
 
 
-def test_lds_ols_many_rows_full_config():
-    """cfg-3's shape through the FFT mode (64 x 2.88 M, 1024 taps): channels {0, 31, 63} against float64."""
+@pytest.mark.parametrize("K,block", [(1024, 4096), (3442, 8192), (4096, 8192), (8192, 16384)])
+def test_lds_ols_many_rows_full_config(K, block):
+    """cfg-3's shape through the FFT mode (64 x 2.88 M; 1024 taps = cfg 3's filter, 3442 = the default plan's fold of
+    cfg 2's cascade into it, 4096 / 8192 = the larger one-launch blocks): channels {0, 31, 63} against float64."""
     from scipy.signal import firwin
-    k = firwin(1024, 5000, fs=48000).astype(np.float32)
+    assert ext().ols_plan_info(K, 2_880_000, (K - 1, 0))["N"] == block
+    k = firwin(K, 5000, fs=48000).astype(np.float32)
     g = torch.Generator(device=DEV).manual_seed(5)
     x = torch.rand(64, 2_880_000, generator=g, device=DEV) * 2 - 1
-    y = ext().fft_conv_forward(x, k[::-1].copy(), (1023, 0))
+    y = ext().fft_conv_forward(x, k[::-1].copy(), (K - 1, 0))
     for c in (0, 31, 63):
         xc = x[c].cpu().numpy()
-        close(y[c:c + 1], _f64_corr(xc[None], k[::-1].copy(), 1023, 0).astype(np.float32), 2e-6, f"row {c}")
+        close(y[c:c + 1], _f64_corr(xc[None], k[::-1].copy(), K - 1, 0).astype(np.float32), 2e-6, f"row {c}")

@@ -783,80 +783,45 @@ static void olslds_typed(const R *x, R *y, int64_t C, int64_t Tn, const R *kf_ho
     const int64_t npairs = ceil_div(g.nframes, 2);
     if (g.ep_stat >= 0) g.ep_partial = (double *)scratch("olslds_ep_partial", (size_t)g.nframes * sizeof(double), stream);
     const int dev = current_device();
+    const int64_t per_xcd = ceil_div(npairs, 8);
+    TFX_CHECK(per_xcd * 8 < ((int64_t)1 << 31), "fft_conv_forward: too many frames for one launch");
+    // raise the kernel's dynamic-LDS limit once per device, then launch `grid` workgroups of `threads`
+    auto launch = [&](auto kernel, bool &ready, const char *name, size_t lds, int64_t grid, int threads, auto... args) {
+        if (!ready) {
+            TFX_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ready = true;
+        }
+        ProfScope ps(name, stream);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(threads), lds, stream, args...);
+        TFX_HIP(hipGetLastError());
+    };
+    static bool ready[4][TFX_MAX_DEVICES] = {};            // per kernel kind of this instantiation
+    bool done = false;
     if constexpr (sizeof(R) == 4) {
         if (kind == 3) {
-            static bool attr_r4[TFX_MAX_DEVICES] = {};
-            if (!attr_r4[dev]) {
-                TFX_HIP(hipFuncSetAttribute((const void *)ols_lds16k_r4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<float>()));
-                attr_r4[dev] = true;
-            }
-            const int64_t per_xcd4 = ceil_div(npairs, 8);
-            TFX_CHECK(per_xcd4 * 8 < ((int64_t)1 << 31), "fft_conv_forward: too many frames for one launch");
-            {
-                ProfScope ps("ols_lds16k_r4_kernel", stream);
-                hipLaunchKernelGGL(ols_lds16k_r4_kernel, dim3((unsigned)(per_xcd4 * 8)), dim3(256), lds_bytes<float>(), stream,
-                                   (const float *)x, (float *)y, (const v4f *)plan.Hs, (const cx<float> *)plan.tw256,
-                                   (const cx<float> *)plan.t4lo, (const v2f *)plan.w8k, g, npairs, per_xcd4);
-                TFX_HIP(hipGetLastError());
-            }
-            if (g.ep_stat >= 0)
-                stat_finish(g.ep_partial, ep->per_row ? C : 1, ep->per_row ? g.F : g.nframes, g.ep_stat, ep->stat_out, stream);
-            return;
-        }
-        if (N == LDS16K) {
+            launch(ols_lds16k_r4_kernel, ready[3][dev], "ols_lds16k_r4_kernel", lds_bytes<float>(), per_xcd * 8, 256,
+                   (const float *)x, (float *)y, (const v4f *)plan.Hs, (const cx<float> *)plan.tw256, (const cx<float> *)plan.t4lo,
+                   (const v2f *)plan.w8k, g, npairs, per_xcd);
+            done = true;
+        } else if (kind == 2) {
             static int cus_tab[TFX_MAX_DEVICES] = {};
             if (!cus_tab[dev]) {
-                TFX_HIP(hipFuncSetAttribute((const void *)ols_lds16k_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16k_bytes()));
                 int cus = 0;
                 TFX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
                 cus_tab[dev] = std::max(8, cus / 8 * 8);      // one 1024-thread workgroup per CU
             }
-            const int64_t per_xcd16 = ceil_div(npairs, 8);
-            int64_t grid = std::min<int64_t>(envi("TFX_OLS_LDS16K_GRID", cus_tab[dev]) / 8 * 8, per_xcd16 * 8);
-            if (grid < 8) grid = 8;
-            {
-                ProfScope ps("ols_lds16k_kernel", stream);
-                hipLaunchKernelGGL(ols_lds16k_kernel, dim3((unsigned)grid), dim3(1024), lds16k_bytes(), stream,
-                                   (const float *)x, (float *)y, (const v4f *)plan.Hs, (const v2f *)plan.tw256, g, npairs, per_xcd16);
-                TFX_HIP(hipGetLastError());
-            }
-            if (g.ep_stat >= 0)
-                stat_finish(g.ep_partial, ep->per_row ? C : 1, ep->per_row ? g.F : g.nframes, g.ep_stat, ep->stat_out, stream);
-            return;
+            const int64_t grid = std::max<int64_t>(8, std::min<int64_t>(envi("TFX_OLS_LDS16K_GRID", cus_tab[dev]) / 8 * 8, per_xcd * 8));
+            launch(ols_lds16k_kernel, ready[2][dev], "ols_lds16k_kernel", lds16k_bytes(), grid, 1024,
+                   (const float *)x, (float *)y, (const v4f *)plan.Hs, (const v2f *)plan.tw256, g, npairs, per_xcd);
+            done = true;
         }
     }
-    if (N == LDS8K) {
-        static bool attr8k[TFX_MAX_DEVICES] = {};
-        if (!attr8k[dev]) {
-            TFX_HIP(hipFuncSetAttribute((const void *)ols_lds8192_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<R>()));
-            attr8k[dev] = true;
-        }
-        const int64_t per_xcd8 = ceil_div(npairs, 8);
-        TFX_CHECK(per_xcd8 * 8 < ((int64_t)1 << 31), "fft_conv_forward: too many frames for one launch");
-        {
-            ProfScope ps("ols_lds8192_kernel", stream);
-            hipLaunchKernelGGL(ols_lds8192_kernel<R>, dim3((unsigned)(per_xcd8 * 8)), dim3(256), lds_bytes<R>(), stream,
-                               x, y, (const cx<R> *)plan.Hs, (const cx<R> *)plan.tw256, (const cx<R> *)plan.t4lo,
-                               (const cx<R> *)plan.w8k, g, npairs, per_xcd8);
-            TFX_HIP(hipGetLastError());
-        }
-        if (g.ep_stat >= 0)
-            stat_finish(g.ep_partial, ep->per_row ? C : 1, ep->per_row ? g.F : g.nframes, g.ep_stat, ep->stat_out, stream);
-        return;
-    }
-    static bool attr_tab[TFX_MAX_DEVICES] = {};
-    if (!attr_tab[dev]) {
-        TFX_HIP(hipFuncSetAttribute((const void *)ols_lds4096_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<R>()));
-        attr_tab[dev] = true;
-    }
-    const int64_t per_xcd = ceil_div(npairs, 8);
-    TFX_CHECK(per_xcd * 8 < ((int64_t)1 << 31), "fft_conv_forward: too many frames for one launch");
-    {
-        ProfScope ps("ols_lds4096_kernel", stream);
-        hipLaunchKernelGGL(ols_lds4096_kernel<R>, dim3((unsigned)(per_xcd * 8)), dim3(256), lds_bytes<R>(), stream,
-                           x, y, (const cx<R> *)plan.Hs, (const cx<R> *)plan.tw256, (const cx<R> *)plan.t4lo, g, npairs, per_xcd);
-        TFX_HIP(hipGetLastError());
-    }
+    if (!done && kind == 1)
+        launch(ols_lds8192_kernel<R>, ready[1][dev], "ols_lds8192_kernel", lds_bytes<R>(), per_xcd * 8, 256,
+               x, y, (const cx<R> *)plan.Hs, (const cx<R> *)plan.tw256, (const cx<R> *)plan.t4lo, (const cx<R> *)plan.w8k, g, npairs, per_xcd);
+    else if (!done)
+        launch(ols_lds4096_kernel<R>, ready[0][dev], "ols_lds4096_kernel", lds_bytes<R>(), per_xcd * 8, 256,
+               x, y, (const cx<R> *)plan.Hs, (const cx<R> *)plan.tw256, (const cx<R> *)plan.t4lo, g, npairs, per_xcd);
     if (g.ep_stat >= 0)
         stat_finish(g.ep_partial, ep->per_row ? C : 1, ep->per_row ? g.F : g.nframes, g.ep_stat, ep->stat_out, stream);
 }
