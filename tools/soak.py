@@ -62,10 +62,16 @@ def cases(dev, seconds_long=300.0):
     yield "FIR 1024 through the FFT mode (one launch, transform in LDS)", lambda: E.fft_conv_forward(x_mid, k1024, (1023, 0))
     k4096 = (np.random.default_rng(1).standard_normal(4096) / 4096).astype(np.float32)
     x_short = x_mid[:8, :44100].contiguous()
-    yield "4096 taps on short rows (16 384-point workgroup transform)", lambda: E.fft_conv_forward(x_short, k4096, (4095, 0))
-    yield "4096 taps on long rows (three passes, 256-point rows)", lambda: E.fft_conv_forward(x_mid, k4096, (4095, 0))
+    k8192 = (np.random.default_rng(2).standard_normal(8192) / 8192).astype(np.float32)
+    k12k = (np.random.default_rng(3).standard_normal(12000) / 12000).astype(np.float32)
+    yield "4096 taps on short rows (8192-point one-launch kernel)", lambda: E.fft_conv_forward(x_short, k4096, (4095, 0))
+    yield "4096 taps on long rows (8192-point one-launch kernel)", lambda: E.fft_conv_forward(x_mid, k4096, (4095, 0))
+    yield "8192 taps on short rows (16 384 points, 1024-thread workgroup)", lambda: E.fft_conv_forward(x_short, k8192, (8191, 0))
+    yield "8192 taps on long rows (16 384 points, radix 4 around 4096)", lambda: E.fft_conv_forward(x_mid, k8192, (8191, 0))
+    yield "12000 taps on long rows (three passes, 256-point rows)", lambda: E.fft_conv_forward(x_mid, k12k, (11999, 0))
     x64 = x_mid[:16].double()
     yield "FIR 1024 float64 (LDS)", lambda: E.fft_conv_forward(x64, k1024.astype(np.float64), (1023, 0))
+    yield "4096 taps float64 (8192-point one-launch kernel)", lambda: E.fft_conv_forward(x64, k4096.astype(np.float64), (4095, 0))
     xc = x_mid[:2, :512].contiguous()
     taps = b1024[:256][::-1].copy()
 
