@@ -44,8 +44,16 @@ namespace tfx {
 //   [8 + 4k + {0..3}]             Cmp^(LC * 2^k) row-major, k < 6   (Cmp = [[-a1,-a2],[1,0]])
 //   [32 + 4p + {0..3}]            Cmp^(LC * (p+1)), p < 32: per-lane matrices of the scan's two
 //                                 cross-row steps (p = lane % 16 and p = lane % 32)
+//   [160..163]                    1/Gin, 1/Gout, Gin, Gout: the scale of the section's input / output in the unit-b0 form (else 1)
+// Unit-b0 form (UNIT kernels, float64, K >= 2): every b0 is pulled out of its section, section s computes
+//   y' = v' + (b1/b0) v'[n-1] + (b2/b0) v'[n-2] - a1 y'[n-1] - a2 y'[n-2]
+// on v' = v / Gin, y' = y / Gout (Gin = product of the b0 before it, Gout = Gin b0): step (1a) loses its multiply, the product
+// of all b0 comes back in ONE multiply where the output is rounded and stored -- K - 1 vector instructions per sample less.
+// The carried states enter and leave through the same factors.  Same recursion, same poles; the numerator arithmetic
+// differs from the reference's by float64 round-off (parity at 2e-11 of the output scale like the plain form).
+// Cascades with a zero / tiny / huge b0 keep the plain form (unit_form_ok).
 // ------------------------------------------------------------------------------------------
-__host__ __device__ constexpr int tab_stride(int) { return 32 + 128; }
+__host__ __device__ constexpr int tab_stride(int) { return 32 + 128 + 8; }
 
 struct SosParams {
     const void *x;
@@ -71,6 +79,7 @@ struct SosParams {
     int ep_fused;        // host side only: the kernel applies it (else separate passes follow the launch)
     int fair;            // > 0: waves that share a SIMD alternate their issue priority every 2^fair clocks
     int fair_nw;         // waves per SIMD of this launch (the priority levels that rotate): 2 ... 4
+    int unit;            // host side only: `tab` holds the unit-b0 form (UNIT kernels)
 };
 
 __device__ __forceinline__ void wave_sync()
@@ -134,10 +143,11 @@ template <typename T> struct U16 {               // 16 bytes of T
 // The stream body: one wavefront walks stream `sid` = (row, segment) with `stage` as its private LDS (transposition
 // stage + carry).  Shared by the cascade kernel below and by the fused per-chunk kernel (chunk_iir_fir_kernel), whose
 // output pointer is an LDS buffer.
-template <typename TIn, typename TOut, typename TC, int LC, bool VEC, bool TAPS, bool PF, bool SUMB, bool EPI>
+template <typename TIn, typename TOut, typename TC, int LC, bool VEC, bool TAPS, bool PF, bool SUMB, bool EPI, bool UNIT = false>
 __device__ __forceinline__ void sos_stream_body(const SosParams &p, const int64_t sid, char *const stage, const int lane)
 {
     static_assert(!(TAPS && SUMB), "section taps are not available in sum mode");
+    static_assert(!(UNIT && (TAPS || SUMB)), "the unit-b0 form serves the plain cascade only");
     constexpr int IOB = sizeof(TIn) > sizeof(TOut) ? sizeof(TIn) : sizeof(TOut);
     constexpr int CHUNK_B = LC * IOB + 16;   // per-lane chunk, padded: conflict-free b128 access
     constexpr int STAGE_B = 64 * CHUNK_B;
@@ -195,6 +205,7 @@ __device__ __forceinline__ void sos_stream_body(const SosParams &p, const int64_
         if (start == 0) {
             const double *src = (f < 2) ? p.sx_in : p.sy_in;
             if (src) v = (TC)src[((int64_t)s * st_rows + (SUMB ? b * p.C_in + c : c)) * 2 + (f & 1)];
+            if (UNIT) v *= ((const TC *)p.tab)[(band * K + s) * TS + (f < 2 ? 160 : 161)];      // into the section's scale
         }
         carry[i] = v;
     }
@@ -337,7 +348,7 @@ __device__ __forceinline__ void sos_stream_body(const SosParams &p, const int64_
             for (int n = LC - 1; n >= 0; --n) {
                 const TC x1 = n >= 1 ? d[n - 1] : pv1;
                 const TC x2 = n >= 2 ? d[n - 2] : (n == 1 ? pv1 : pv2);
-                d[n] = fma(b2, x2, fma(b1, x1, b0 * d[n]));
+                d[n] = UNIT ? fma(b2, x2, fma(b1, x1, d[n])) : fma(b2, x2, fma(b1, x1, b0 * d[n]));
             }
             // (1b) the recursion over f from zero start state (lane 0: from the carried true
             //      state), only to get this chunk's END STATE -- 2 flop/sample, nothing stored
@@ -403,8 +414,9 @@ __device__ __forceinline__ void sos_stream_body(const SosParams &p, const int64_
                 capture2(r - 1, r - 2, cy1, cy2, sy1, sy2);
                 if (lane == 0) {
                     const int64_t o = ((int64_t)s * st_rows + (SUMB ? bnd * p.C_in + c : c)) * 2;
-                    if (p.sx_out) { p.sx_out[o] = (double)sx1; p.sx_out[o + 1] = (double)sx2; }
-                    if (p.sy_out) { p.sy_out[o] = (double)sy1; p.sy_out[o + 1] = (double)sy2; }
+                    const TC g_in = UNIT ? tb[162] : (TC)1, g_out = UNIT ? tb[163] : (TC)1;      // back to the true scale
+                    if (p.sx_out) { p.sx_out[o] = (double)(sx1 * g_in); p.sx_out[o + 1] = (double)(sx2 * g_in); }
+                    if (p.sy_out) { p.sy_out[o] = (double)(sy1 * g_out); p.sy_out[o + 1] = (double)(sy2 * g_out); }
                 }
             }
             if constexpr (TAPS) {   // debug / section-by-section parity only
@@ -434,6 +446,11 @@ __device__ __forceinline__ void sos_stream_body(const SosParams &p, const int64_
         if (ts + TILE > out_begin) {
             const int64_t lo64 = out_begin - ts, hi64 = out_end - ts;
             const bool full = (lo64 <= 0) && (hi64 >= TILE);
+            if constexpr (UNIT) {                       // the product of all b0, once, on the way out
+                const TC gt = tab[(K - 1) * TS + 163];
+#pragma unroll
+                for (int n = 0; n < LC; ++n) d[n] *= gt;
+            }
             if constexpr (!EPI) {
 #pragma unroll
                 for (int i = 0; i < NUO; ++i) {
@@ -523,14 +540,14 @@ template <typename TC, int LC> __host__ __device__ inline int sos_carry_bytes(in
     return (((nbl * K * 4 + 2 * LC) * (int)sizeof(TC)) + 15) & ~15;
 }
 
-template <typename TIn, typename TOut, typename TC, int LC, bool VEC, bool TAPS, bool PF, int MINW, bool SUMB = false, bool EPI = false>
+template <typename TIn, typename TOut, typename TC, int LC, bool VEC, bool TAPS, bool PF, int MINW, bool SUMB = false, bool EPI = false, bool UNIT = false>
 __global__ void __launch_bounds__(256, MINW) sos_stream_kernel(const SosParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform -> SGPR addressing
     const int per_wave = sos_stage_bytes<TIn, TOut, TC, LC>() + sos_carry_bytes<TC, LC>(SUMB ? p.nsum : 1, p.K);
-    sos_stream_body<TIn, TOut, TC, LC, VEC, TAPS, PF, SUMB, EPI>(p, (int64_t)blockIdx.x * 4 + wave, smem + wave * per_wave, lane);
+    sos_stream_body<TIn, TOut, TC, LC, VEC, TAPS, PF, SUMB, EPI, UNIT>(p, (int64_t)blockIdx.x * 4 + wave, smem + wave * per_wave, lane);
 }
 
 // Non-finite samples and time segmentation.  In the sequential recursion a NaN / Inf never leaves: once the
@@ -593,6 +610,8 @@ struct SosPlan {
     void *tab_f32_lc16 = nullptr;
     void *tab_f64_lc64 = nullptr;
     void *tab_f32_lc64 = nullptr;
+    void *tab_f64_lc64_unit = nullptr;   // unit-b0 form (fill_tables)
+    int unit_ok = -1;                    // the cascade has a unit-b0 form (lazy)
     std::vector<double> sos;
 };
 
@@ -672,16 +691,39 @@ static int64_t warmup_length(const std::vector<double> &sos, int K)
     return W;
 }
 
+// Whether the cascade can run in the unit-b0 form: every b0 non-zero, not dwarfed by its section's other numerator
+// coefficients (b1 / b0 must stay a sane number) and every partial product of them far inside the float64 range.
+static bool unit_form_ok(const std::vector<double> &sos, int K)
+{
+    if (K < 2) return false;
+    ld g = 1.0L;
+    for (int s = 0; s < K; ++s) {
+        const ld b0 = sos[s * 6], b1 = sos[s * 6 + 1], b2 = sos[s * 6 + 2];
+        g *= b0;
+        if (!(fabsl(b0) > 0) || !(fabsl(b0) * 1e9L >= fmaxl(fabsl(b1), fabsl(b2))) || !(fabsl(g) > 1e-100L && fabsl(g) < 1e100L)) return false;
+    }
+    return true;
+}
+
 template <typename TC>
-static void fill_tables(const std::vector<double> &sos, int K, int LC, std::vector<TC> &out, int &nsteps)
+static void fill_tables(const std::vector<double> &sos, int K, int LC, std::vector<TC> &out, int &nsteps, bool unit = false)
 {
     const int TS = tab_stride(LC);
     out.assign((size_t)K * TS, (TC)0);
     nsteps = 0;
+    ld gin = 1.0L;
     for (int s = 0; s < K; ++s) {
         const double *co = &sos[s * 6];
         TC *tb = &out[(size_t)s * TS];
-        tb[0] = (TC)co[0]; tb[1] = (TC)co[1]; tb[2] = (TC)co[2];
+        if (unit) {
+            tb[0] = (TC)1; tb[1] = (TC)((ld)co[1] / (ld)co[0]); tb[2] = (TC)((ld)co[2] / (ld)co[0]);
+            const ld gout = gin * (ld)co[0];
+            tb[160] = (TC)(1.0L / gin); tb[161] = (TC)(1.0L / gout); tb[162] = (TC)gin; tb[163] = (TC)gout;
+            gin = gout;
+        } else {
+            tb[0] = (TC)co[0]; tb[1] = (TC)co[1]; tb[2] = (TC)co[2];
+            tb[160] = tb[161] = tb[162] = tb[163] = (TC)1;
+        }
         tb[3] = (TC)(-co[4]); tb[4] = (TC)(-co[5]);
         const ld a1 = co[4], a2 = co[5];
         // alpha: response to state (1,0); beta: to (0,1)
@@ -725,7 +767,7 @@ static void fill_tables(const std::vector<double> &sos, int K, int LC, std::vect
 // samples per cascade (a millisecond, once per plan) against the sequential float64 recursion, and the
 // largest difference is scaled by 2.5 (device runs of 4.6e7 samples per cascade measure 0.54 .. 1.02 of twice the
 // replayed error over five orders of magnitude of it, tools/iir_f32_calibrate.py).
-template <typename TC> static void fill_tables(const std::vector<double> &sos, int K, int LC, std::vector<TC> &out, int &nsteps);
+template <typename TC> static void fill_tables(const std::vector<double> &sos, int K, int LC, std::vector<TC> &out, int &nsteps, bool unit);
 
 static double f32_error_bound(const std::vector<double> &sos, int K)
 {
@@ -734,7 +776,7 @@ static double f32_error_bound(const std::vector<double> &sos, int K)
     const int64_t N = 1 << 16;
     std::vector<float> tab;
     int nsteps = 0;
-    fill_tables<float>(sos, K, LC, tab, nsteps);
+    fill_tables<float>(sos, K, LC, tab, nsteps, false);
     for (float v : tab) if (!std::isfinite(v)) return INFINITY;
     // input: uniform in [-1, 1], fixed LCG
     std::vector<float> x((size_t)N);
@@ -827,7 +869,7 @@ static double f32_error_bound(const std::vector<double> &sos, int K)
 
 static void free_plan(SosPlan *pl)
 {
-    void *t[6] = {pl->tab_f64_lc32, pl->tab_f32_lc32, pl->tab_f64_lc16, pl->tab_f32_lc16, pl->tab_f64_lc64, pl->tab_f32_lc64};
+    void *t[7] = {pl->tab_f64_lc32, pl->tab_f32_lc32, pl->tab_f64_lc16, pl->tab_f32_lc16, pl->tab_f64_lc64, pl->tab_f32_lc64, pl->tab_f64_lc64_unit};
     for (void *q : t) if (q) (void)hipFree(q);
     delete pl;
 }
@@ -880,7 +922,7 @@ static SosPlan *get_plan(const double *sos_host, int64_t K, hipStream_t stream, 
 }
 
 template <typename TC>
-static void *ensure_table(SosPlan *pl, void **slot, int LC, int *nsteps, hipStream_t stream)
+static void *ensure_table(SosPlan *pl, void **slot, int LC, int *nsteps, hipStream_t stream, bool unit = false)
 {
     std::lock_guard<std::mutex> lk(g_plan_mu);
     if (!*slot) {
@@ -888,7 +930,7 @@ static void *ensure_table(SosPlan *pl, void **slot, int LC, int *nsteps, hipStre
         for (int b = 0; b < pl->NB; ++b) {
             std::vector<double> one(pl->sos.begin() + (size_t)b * pl->K * 6, pl->sos.begin() + (size_t)(b + 1) * pl->K * 6);
             std::vector<TC> hb;
-            fill_tables<TC>(one, pl->K, LC, hb, *nsteps);
+            fill_tables<TC>(one, pl->K, LC, hb, *nsteps, unit);
             h.insert(h.end(), hb.begin(), hb.end());
         }
         void *d = nullptr;
@@ -969,7 +1011,7 @@ static void plan_segments(SosParams &p, int64_t plan_warm, int TILE, int residen
     p.nseg = (int)nseg; p.seg_len = seg_len; p.warm = warm;
 }
 
-template <typename TIn, typename TOut, typename TC, int LC, bool VEC, bool TAPS, bool PF, int MINW, bool SUMB = false, bool EPI = false>
+template <typename TIn, typename TOut, typename TC, int LC, bool VEC, bool TAPS, bool PF, int MINW, bool SUMB = false, bool EPI = false, bool UNIT = false>
 static void launch_one(SosParams p, int64_t plan_warm, hipStream_t stream)
 {
     constexpr int IOB = sizeof(TIn) > sizeof(TOut) ? sizeof(TIn) : sizeof(TOut);
@@ -978,7 +1020,7 @@ static void launch_one(SosParams p, int64_t plan_warm, hipStream_t stream)
     const int carry_b = (((nbl * p.K * 4 + 2 * LC) * (int)sizeof(TC)) + 15) & ~15;
     const size_t shmem = 4 * (size_t)(STAGE_B + carry_b);
     TFX_CHECK(shmem <= 160 * 1024, "sos_forward: %d band(s) x K=%d need %zu B of LDS (max 163840)", nbl, p.K, shmem);
-    auto kern = sos_stream_kernel<TIn, TOut, TC, LC, VEC, TAPS, PF, MINW, SUMB, EPI>;
+    auto kern = sos_stream_kernel<TIn, TOut, TC, LC, VEC, TAPS, PF, MINW, SUMB, EPI, UNIT>;
     if (!EPI) p.ep_stat = -1;                      // the plain instantiation has no epilogue code
     if (shmem > 64 * 1024)
         TFX_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -1039,6 +1081,13 @@ static void launch_main(const SosParams &p, bool vec, int variant, int64_t nstre
             else launch_one<TIn, TOut, TC, 32, false, false, false, F32 ? 3 : 2>(p, nstreams, stream);
         }
         return;
+    }
+    if constexpr (!F32) {
+        if (p.unit) {          // unit-b0 form of the shipping geometry, plain and with the epilogue (same cascade arithmetic in both)
+            if (p.ep_fused) launch_one<TIn, TOut, TC, 64, true, false, false, 2, false, true, true>(p, nstreams, stream);
+            else launch_one<TIn, TOut, TC, 64, true, false, false, 2, false, false, true>(p, nstreams, stream);
+            return;
+        }
     }
     if (p.ep_fused) {          // epilogue instantiation: same tile geometry as the plain kernel (bit-identical cascade output)
         if (variant >= 4) launch_one<TIn, TOut, TC, 64, true, false, false, F32 ? 3 : 2, false, true>(p, nstreams, stream);
@@ -1161,6 +1210,20 @@ void sos_forward(const void *x, int x_dtype, void *y, int y_dtype, int64_t C_in,
         if (sum_bands) launch_sum<float, float, float>(p, vec, nstreams, stream);
         else launch_main<float, float, float>(p, vec, variant, nstreams, stream);
     } else {
+        // the shipping float32-in / float32-out geometry (LC = 64, aligned rows, no section taps) runs the unit-b0 form when the
+        // cascade has one (TFX_SOS_UNIT_B0=0: plain form)
+        if (LC == 64 && variant == 4 && vec && !p.taps && !sum_bands && x_dtype == TFX_F32 && y_dtype == TFX_F32 && env_int("TFX_SOS_UNIT_B0", 1) != 0) {
+            if (pl->unit_ok < 0) {
+                bool ok = true;
+                for (int b = 0; b < pl->NB && ok; ++b)
+                    ok = unit_form_ok(std::vector<double>(pl->sos.begin() + (size_t)b * pl->K * 6, pl->sos.begin() + (size_t)(b + 1) * pl->K * 6), pl->K);
+                pl->unit_ok = ok ? 1 : 0;
+            }
+            p.unit = pl->unit_ok;
+        }
+        if (p.unit)
+            p.tab = ensure_table<double>(pl, &pl->tab_f64_lc64_unit, 64, &pl->nsteps64, stream, true);
+        else
         p.tab = ensure_table<double>(pl, LC == 64 ? &pl->tab_f64_lc64 : (LC == 32 ? &pl->tab_f64_lc32 : &pl->tab_f64_lc16), LC,
                                      LC == 64 ? &pl->nsteps64 : (LC == 32 ? &pl->nsteps32 : &pl->nsteps16), stream);
         p.nsteps = LC == 64 ? pl->nsteps64 : (LC == 32 ? pl->nsteps32 : pl->nsteps16);
