@@ -1,10 +1,11 @@
 // olslds.hip -- overlap-save convolution in ONE launch: the whole transform lives in LDS.
 //
-// For kernels that fit on chip (K <= 2048 taps: the reference's default FIR mode -- `FIR.forward` with
-// conv_mode "fft", src/torchfx/filter/fir.py:552-579 -> fft_conv1d, _fftconv.py:70-141 -- is exercised at
-// K = 5 ... 1024 by its own tests and benchmarks) the three-pass pipeline of olsnative.hip moves 24-31 B per
+// For kernels that fit on chip (K <= 8192 taps in float32, 4096 in float64: the reference's default FIR mode --
+// `FIR.forward` with conv_mode "fft", src/torchfx/filter/fir.py:552-579 -> fft_conv1d, _fftconv.py:70-141 -- is
+// exercised at K = 5 ... 1024 by its own tests and benchmarks) the three-pass pipeline of olsnative.hip moves 24-31 B per
 // output sample through a workspace although a block of N = 4096 points is 32 KB.  Here one workgroup owns one
-// PAIR of real frames:
+// PAIR of real frames (N = 4096 below; 8192 and 16 384 points are a radix-2 / radix-4 step in registers around two /
+// four of the same 4096-point transforms, further down):
 //
 //     z[n] = frame_a[n] + i frame_b[n]                 gathered straight from the signal (zero fill / history
 //                                                      outside the row: causal padding, ragged tail)
