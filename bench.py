@@ -120,7 +120,7 @@ def make_step(workload: str, x: torch.Tensor):
     if workload == "fir_fft":
         m = fir                                         # F.FIR(firwin(1024, ...)): conv_mode "fft" is the reference's DEFAULT (fir.py:510,552)
         assert m._conv_mode == "fft"
-        return (lambda: m(x)), "cfg3's filter through FIR.forward's default FFT mode: one-launch LDS-resident overlap-save, 1024 taps", None
+        return (lambda: m(x)), "cfg3's filter through FIR.forward's default FFT mode: one-launch LDS-resident overlap-save (8192-point block), 1024 taps", None
     if workload == "fftconv":
         k = rev.kernel.reshape(-1)
         return (lambda: E.fft_conv_forward(x, k, (k.numel() - 1, 0))), "cfg4: overlap-save FFT conv, 65536 taps", 65536
@@ -666,7 +666,7 @@ def main() -> None:
         try:
             from torchfx_amd import torchfx_ext as E
             model = {"sos_stream_kernel<f64>": 8.0 * samples, "sos_stream_kernel<f32>": 8.0 * samples,
-                     "ols_lds4096_kernel": 8.0 * samples}
+                     "ols_lds4096_kernel": 8.0 * samples, "ols_lds8192_kernel": 8.0 * samples, "ols_lds16k_r4_kernel": 8.0 * samples}
             if ols_taps:
                 kk = ols_taps
                 info = E.ols_plan_info(kk, T, (kk - 1, 0))

@@ -138,7 +138,7 @@ def test_lds_ols_reference_shapes_vs_float64(C, T, K, dtype):
     tests/test_fftconv.py:64-122: [2, 44100], K = 5 ... 1024) run on the single-launch LDS kernel -- not rocFFT --
     in float32 and float64, odd frame counts (an unpaired last frame), rows shorter than one block, T < K."""
     info = ext().ols_plan_info(K, T, (K - 1, 0), torch.float32 if dtype == np.float32 else torch.float64)
-    big = K >= (1025 if dtype == np.float32 else 700) and T + K - 1 >= 65536       # short rows: the smallest block that fits
+    big = K >= (640 if dtype == np.float32 else 700) and T + K - 1 >= 65536       # short rows: the smallest block that fits
     assert info["path"] == "lds" and info["N"] == (8192 if big else 4096)
     rng = np.random.default_rng(K * 7 + T)
     kf = (rng.standard_normal(K) / np.sqrt(K)).astype(np.float32).astype(dtype)      # taps are float32 values (fir.py:516)
@@ -219,13 +219,13 @@ def test_lds16k_ols_vs_float64(C, T, K, monkeypatch):
 @pytest.mark.parametrize("C,T,K", [(2, 44100, 1025), (2, 44100, 2048), (3, 100_003, 4096), (1, 9000, 5), (5, 250_003, 3000), (2, 12_289, 2049),
                                    (64, 40_000, 1500), (1, 1, 1), (4, 98_304, 4000), (1, 8193, 4096), (3, 20_481, 4095)])
 def test_lds8k_ols_vs_float64(C, T, K, dtype, monkeypatch):
-    """The 8192-point block of the one-launch kernel (default for 1024 < K <= 4096 in float32 and 700 <= K <= 4096 in float64;
+    """The 8192-point block of the one-launch kernel (default for 640 <= K <= 4096 in float32 and 700 <= K <= 4096 in float64 on rows of 65 536 samples and more;
     TFX_FFT_LOG2N=13 forces it for smaller K): one radix-2 step in registers around two 4096-point transforms.  Against a
     float64 FFT convolution for every padding flavour, and against the 4096-point kernel / the three-pass pipeline / rocFFT on
     the same input."""
     tdt = torch.float32 if dtype == np.float32 else torch.float64
     tol = 4e-6 if dtype == np.float32 else TOL_CONV_F64
-    if K >= (1025 if dtype == np.float32 else 700) and (T + K - 1 >= 65536 or K > 2048):
+    if K >= (640 if dtype == np.float32 else 700) and (T + K - 1 >= 65536 or K > 2048):
         info = ext().ols_plan_info(K, T, (K - 1, 0), tdt)
         assert (info["path"], info["N"]) == ("lds", 8192)            # the default route
     monkeypatch.setenv("TFX_FFT_LOG2N", "13")
@@ -268,13 +268,15 @@ def test_lds_ols_plan_info_paths():
     i = e.ols_plan_info(2049, 2_880_000, (2048, 0), torch.float64)
     assert (i["path"], i["N"]) == ("lds", 8192) and abs(i["bytes_per_sample"] - (8 * 8192 / i["S"] + 8)) < 1e-9
     assert e.ols_plan_info(4097, 2_880_000, (4096, 0), torch.float64)["path"] == "rocfft"
-    i = e.ols_plan_info(1024, 2_880_000, (1023, 0))
-    assert i["S"] == 3072 and i["F"] == 938 and abs(i["bytes_per_sample"] - (4 * 4096 / 3072 + 4)) < 1e-9
+    i = e.ols_plan_info(1024, 2_880_000, (1023, 0))                      # aligned rows: one lead tap, a hop of whole cache lines
+    assert i["N"] == 8192 and i["S"] == 7168 and i["F"] == 402 and abs(i["bytes_per_sample"] - (4 * 8192 / 7168 + 4)) < 1e-9
+    i = e.ols_plan_info(512, 2_880_000, (511, 0))
+    assert i["N"] == 4096 and i["S"] == 3584 and i["F"] == 804 and abs(i["bytes_per_sample"] - (4 * 4096 / 3584 + 4)) < 1e-9
     i = e.ols_plan_info(1024, 2_880_001, (1023, 0))                      # unaligned rows: no lead, odd hop
-    assert i["S"] == 4096 - 1024 + 1
+    assert i["S"] == 8192 - 1024 + 1
 
 
-@pytest.mark.parametrize("K,block", [(1024, 4096), (3442, 8192), (4096, 8192), (8192, 16384)])
+@pytest.mark.parametrize("K,block", [(512, 4096), (1024, 8192), (3442, 8192), (4096, 8192), (8192, 16384)])
 def test_lds_ols_many_rows_full_config(K, block):
     """cfg-3's shape through the FFT mode (64 x 2.88 M; 1024 taps = cfg 3's filter, 3442 = the default plan's fold of
     cfg 2's cascade into it, 4096 / 8192 = the larger one-launch blocks): channels {0, 31, 63} against float64."""

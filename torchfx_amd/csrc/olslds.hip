@@ -177,6 +177,15 @@ constexpr int LDS_N = 4096;
 template <typename R> constexpr size_t lds_bytes() { return (size_t)(LDS_N + LDS_N / 16 + 512) * sizeof(cx<R>); }
 
 // Where a pair of frames lives: rows and offsets of frame a (real part) and frame b (imaginary part)
+// (the 64-bit divisions run on the vector unit: their wave-uniform results go back to scalar registers, or row bases and
+// frame offsets sit in VGPR pairs for the whole transform -- three spilled pairs in the 8192-point kernel, 138 MB of scratch
+// traffic per call beside 1.47 GB of signal)
+__device__ __forceinline__ int64_t uniform64(int64_t v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uint64_t)v);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
 template <typename R> struct PairAt {
     int64_t fa, ca, cb, ra, rb;
     bool has_b;
@@ -184,8 +193,8 @@ template <typename R> struct PairAt {
     {
         fa = 2 * pair;
         has_b = fa + 1 < g.nframes;
-        ca = fa / g.F; ra = fa - ca * g.F;
-        cb = has_b ? (fa + 1) / g.F : ca; rb = has_b ? (fa + 1) - cb * g.F : ra;
+        ca = uniform64(fa / g.F); ra = fa - ca * g.F;
+        cb = has_b ? uniform64((fa + 1) / g.F) : ca; rb = has_b ? (fa + 1) - cb * g.F : ra;
     }
 };
 
@@ -197,9 +206,11 @@ __device__ __forceinline__ void fetch_pair(cx<R> (&v)[VPT], const R *__restrict_
     const int64_t ia0 = p.ra * g.S - g.pad_left, ib0 = p.rb * g.S - g.pad_left;
     const R *xa = x + p.ca * g.Tn, *xb = x + p.cb * g.Tn;
     if (ia0 >= 0 && ia0 + NP <= g.Tn && p.has_b && ib0 >= 0 && ib0 + NP <= g.Tn) {     // interior pair: no checks
-        const R *pa = xa + ia0 + j, *pb = xb + ib0 + j;
+        // wave-uniform bases + a 32-bit lane offset: the loads take the scalar-base form (one VGPR of address for all of
+        // them instead of a 64-bit pointer per 4 KB of reach -- those cost the 8192-point kernel three spilled pairs)
+        const R *pa = xa + ia0, *pb = xb + ib0;
 #pragma unroll
-        for (int t = 0; t < VPT; ++t) v[t] = mk<R>(pa[TPB * t], pb[TPB * t]);
+        for (int t = 0; t < VPT; ++t) v[t] = mk<R>(pa[(unsigned)(j + TPB * t)], pb[(unsigned)(j + TPB * t)]);
     } else {
 #pragma unroll
         for (int t = 0; t < VPT; ++t) {
@@ -226,8 +237,8 @@ __device__ __forceinline__ void store_pair(const cx<R> (&v)[VPT], R *__restrict_
     if (!epi && p.has_b && oa0 + g.S <= g.Tout && ob0 + g.S <= g.Tout) {     // whole hops inside their rows
 #pragma unroll
         for (int k = 0; k < VPT; ++k) {
-            const int n = j + TPB * k;
-            if (n < g.S) { ya[n] = v[k].x; yb[n] = v[k].y; }
+            const unsigned n = (unsigned)(j + TPB * k);
+            if ((int64_t)n < g.S) { ya[n] = v[k].x; yb[n] = v[k].y; }
         }
         return;
     }
@@ -716,9 +727,9 @@ void olslds_clear()
     for (int d = 0; d < TFX_MAX_DEVICES; ++d) { g_last_key[d] = nullptr; g_last[d] = nullptr; }
 }
 
-// taps this path takes: at least half of every block must be valid output -- 4096 points for K <= 1024 (float32; measured
-// equal to the 8192-point block at 1024 taps, faster below) and K < 700 (float64), 8192 points above that up to 4096 taps
-// (float32, 64 x 2.88 M: 2048 taps 0.49 -> 0.40 ms, 4096 taps 0.85 (three passes) -> 0.57; float64, 32 x 2.88 M: 2048 taps
+// taps this path takes: at least half of every block must be valid output -- 4096 points for K < 640 (float32; measured
+// equal to the 8192-point block at 512 taps, faster below) and K < 700 (float64), 8192 points above that up to 4096 taps
+// (float32, 64 x 2.88 M: 1024 taps 0.36 -> 0.34 ms, 2048 taps 0.49 -> 0.39, 4096 taps 0.85 (three passes) -> 0.52; float64, 32 x 2.88 M: 2048 taps
 // 0.60 -> 0.44, 4096 taps 3.0 (rocFFT) -> 0.62), 16 384 points for 4096 < K <= 8192 (float32; TFX_OLS_LDS16K=0 and
 // TFX_OLS_LDS16K_R4=0 hand them back to the three-pass pipeline / rocFFT)
 bool olslds_supported(int64_t K, int dtype, int64_t L, int64_t *N_out)
@@ -728,8 +739,8 @@ bool olslds_supported(int64_t K, int dtype, int64_t L, int64_t *N_out)
     if (lg != 0 && lg != 12 && lg != 13 && lg != 14) return false;         // a forced block size of another path
     int64_t N = 0;
     const int64_t use16k = ldsfft::envi("TFX_OLS_LDS16K", 1);                // 0 never, 1 where the three-pass pipeline does not reach, 2 always
-    // taps from which the 8192-point block pays (0: never): measured equal at 1024 taps in float32, at 512 in float64
-    const int64_t min8k = ldsfft::envi("TFX_OLS_LDS8K_MINK", dtype == TFX_F32 ? 1025 : 700);
+    // taps from which the 8192-point block pays (0: never): measured equal at 512 taps in float32 and in float64
+    const int64_t min8k = ldsfft::envi("TFX_OLS_LDS8K_MINK", dtype == TFX_F32 ? 640 : 700);
     const bool can8k = K >= 1 && K <= ldsfft::LDS8K / 2 && min8k > 0 && (lg == 0 || lg == 13);
     // rows shorter than 65 536 samples are a handful of workgroups that all run at once: the call takes as long as ONE workgroup,
     // so the smallest block that fits wins there ([2, 44100], 1500 taps: 8 us at 4096 points, 15 us at 8192)
