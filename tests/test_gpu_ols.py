@@ -183,7 +183,7 @@ def test_lds16k_ols_vs_float64(C, T, K, monkeypatch):
     three-pass pipeline / rocFFT.  K <= 4096 belongs to the 8192-point kernel by default."""
     short = T + K - 1 < 65536
     info = ext().ols_plan_info(K, T, (K - 1, 0))
-    assert (info["path"], info["N"]) == (("lds", 8192) if K <= 4096 else ("lds", 16384))
+    assert (info["path"], info["N"]) == (("lds", 16384) if (K > 4096 or (K >= 3400 and not short)) else ("lds", 8192))
     i64 = ext().ols_plan_info(K, T, (K - 1, 0), torch.float64)                               # float64: 8192 points up to 4096 taps; 16 384 would need 272 KB of LDS
     assert (i64["path"], i64["N"]) == (("lds", 8192) if K <= 4096 else ("rocfft", i64["N"]))
     rng = np.random.default_rng(K + T)
@@ -205,7 +205,7 @@ def test_lds16k_ols_vs_float64(C, T, K, monkeypatch):
                 close(ext().fft_conv_forward(dev(x), kf, pad), _f64_corr(x, kf, *pad).astype(np.float32), 4e-6, f"{name} pad={pad}")
     if C * T > 100:
         assert not torch.equal(outs["1024-thread workgroup"], outs["radix 4 around 4096"])       # two different kernels ran
-    if K > 4096:
+    if K > 4096 or (K >= 3400 and not short):
         assert torch.equal(y_default, outs["1024-thread workgroup" if short else "radix 4 around 4096"])
     monkeypatch.delenv("TFX_FFT_LOG2N")
     monkeypatch.setenv("TFX_OLS_LDS16K", "0")
@@ -226,8 +226,8 @@ def test_lds8k_ols_vs_float64(C, T, K, dtype, monkeypatch):
     tdt = torch.float32 if dtype == np.float32 else torch.float64
     tol = 4e-6 if dtype == np.float32 else TOL_CONV_F64
     if K >= (640 if dtype == np.float32 else 700) and (T + K - 1 >= 65536 or K > 2048):
-        info = ext().ols_plan_info(K, T, (K - 1, 0), tdt)
-        assert (info["path"], info["N"]) == ("lds", 8192)            # the default route
+        info = ext().ols_plan_info(K, T, (K - 1, 0), tdt)            # the default route: 16 384 points take over at 3400 taps (float32, long rows)
+        assert (info["path"], info["N"]) == ("lds", 16384 if (dtype == np.float32 and K >= 3400 and T + K - 1 >= 65536) else 8192)
     monkeypatch.setenv("TFX_FFT_LOG2N", "13")
     rng = np.random.default_rng(K * 3 + T)
     kf = (rng.standard_normal(K) / np.sqrt(K)).astype(np.float32).astype(dtype)
@@ -259,6 +259,7 @@ def test_lds_ols_plan_info_paths():
     assert (i["path"], i["N"]) == ("lds", 8192)
     i = e.ols_plan_info(4097, 2_880_000, (4096, 0))                                     # up to 8192 taps: 16 384 points in one launch
     assert (i["path"], i["N"]) == ("lds", 16384)
+    assert e.ols_plan_info(3400, 2_880_000, (3399, 0))["N"] == 16384 and e.ols_plan_info(3399, 2_880_000, (3398, 0))["N"] == 8192
     assert e.ols_plan_info(8193, 2_880_000, (8192, 0))["path"] == "passes"
     i = e.ols_plan_info(8000, 44100, (7999, 0))                                         # short rows: one launch instead of rocFFT
     assert (i["path"], i["N"]) == ("lds", 16384)
@@ -276,7 +277,7 @@ def test_lds_ols_plan_info_paths():
     assert i["S"] == 8192 - 1024 + 1
 
 
-@pytest.mark.parametrize("K,block", [(512, 4096), (1024, 8192), (3442, 8192), (4096, 8192), (8192, 16384)])
+@pytest.mark.parametrize("K,block", [(512, 4096), (1024, 8192), (3000, 8192), (3442, 16384), (4096, 16384), (8192, 16384)])
 def test_lds_ols_many_rows_full_config(K, block):
     """cfg-3's shape through the FFT mode (64 x 2.88 M; 1024 taps = cfg 3's filter, 3442 = the default plan's fold of
     cfg 2's cascade into it, 4096 / 8192 = the larger one-launch blocks): channels {0, 31, 63} against float64."""

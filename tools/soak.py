@@ -65,7 +65,9 @@ def cases(dev, seconds_long=300.0):
     k8192 = (np.random.default_rng(2).standard_normal(8192) / 8192).astype(np.float32)
     k12k = (np.random.default_rng(3).standard_normal(12000) / 12000).astype(np.float32)
     yield "4096 taps on short rows (8192-point one-launch kernel)", lambda: E.fft_conv_forward(x_short, k4096, (4095, 0))
-    yield "4096 taps on long rows (8192-point one-launch kernel)", lambda: E.fft_conv_forward(x_mid, k4096, (4095, 0))
+    yield "4096 taps on long rows (16 384 points, radix 4 around 4096)", lambda: E.fft_conv_forward(x_mid, k4096, (4095, 0))
+    k3000 = k4096[:3000].copy()
+    yield "3000 taps on long rows (8192-point one-launch kernel)", lambda: E.fft_conv_forward(x_mid, k3000, (2999, 0))
     yield "8192 taps on short rows (16 384 points, 1024-thread workgroup)", lambda: E.fft_conv_forward(x_short, k8192, (8191, 0))
     yield "8192 taps on long rows (16 384 points, radix 4 around 4096)", lambda: E.fft_conv_forward(x_mid, k8192, (8191, 0))
     yield "12000 taps on long rows (three passes, 256-point rows)", lambda: E.fft_conv_forward(x_mid, k12k, (11999, 0))

@@ -744,7 +744,13 @@ bool olslds_supported(int64_t K, int dtype, int64_t L, int64_t *N_out)
     const bool can8k = K >= 1 && K <= ldsfft::LDS8K / 2 && min8k > 0 && (lg == 0 || lg == 13);
     // rows shorter than 65 536 samples are a handful of workgroups that all run at once: the call takes as long as ONE workgroup,
     // so the smallest block that fits wins there ([2, 44100], 1500 taps: 8 us at 4096 points, 15 us at 8192)
-    if (can8k && (lg == 13 || (K >= min8k && (L >= 65536 || K > ldsfft::LDS_N / 2)))) N = ldsfft::LDS8K;
+    // from ~3300 taps the radix-4 kernel at 16 384 points overtakes it on long rows (4096 taps: 0.47 against 0.53 ms, 3000 taps:
+    // 0.45 against 0.44) although it runs two workgroups per CU instead of four
+    const int64_t min16k = ldsfft::envi("TFX_OLS_LDS16K_MINK", 3400);
+    const bool r4_long = dtype == TFX_F32 && lg == 0 && L >= 65536 && use16k == 1 && ldsfft::envi("TFX_OLS_LDS16K_R4", 1) >= 1 &&
+                         min16k > 0 && K >= min16k && K <= ldsfft::LDS16K / 2;
+    if (r4_long) N = ldsfft::LDS16K;
+    else if (can8k && (lg == 13 || (K >= min8k && (L >= 65536 || K > ldsfft::LDS_N / 2)))) N = ldsfft::LDS8K;
     else if (K >= 1 && K <= ldsfft::LDS_N / 2 && lg != 14 && lg != 13) N = ldsfft::LDS_N;
     else if (K >= 1 && K <= ldsfft::LDS16K / 2 && dtype == TFX_F32 && (lg == 0 || lg == 14) &&
              (use16k >= 2 || lg == 14 || (use16k == 1 && (L < 65536 || ldsfft::envi("TFX_OLS_LDS16K_R4", 1) >= 1)) ||
