@@ -110,7 +110,7 @@ fir_direct_mfma_kernel(const float *__restrict__ x, float *__restrict__ y,
     float *xw = (float *)smem;                              // [XW_PAD]
     float *kp = xw + ((XW_PAD + 3) & ~3);                   // [31 + FIR_KC + 33]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // Tile -> workgroup: workgroups are dealt to the eight XCDs round robin (observed; only speed and traffic depend on it), so
     // XCD b % 8 takes the tiles [xcd * per_xcd, (xcd + 1) * per_xcd) in order: neighbouring tiles of a row, whose windows share
     // K - 1 + 32 samples, are worked on by ONE XCD and the overlap is an L2 hit instead of a second fetch (round 4: PMC read
@@ -118,8 +118,16 @@ fir_direct_mfma_kernel(const float *__restrict__ x, float *__restrict__ y,
     const int64_t ntiles = C * tiles_per_row, per_xcd = (ntiles + 7) / 8;
     const int64_t bid = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if ((int64_t)(blockIdx.x >> 3) >= per_xcd || bid >= ntiles) return;
-    const int64_t c = bid / tiles_per_row;
-    const int64_t n0 = (bid % tiles_per_row) * (int64_t)NOUT;
+    // (64-bit divisions run on the vector unit: the wave-uniform quotient goes back to scalar registers, or row bases and tile
+    // offsets sit in VGPR pairs for the whole tile -- the kernel spilled one register at its 96-VGPR budget: 46 MB of scratch
+    // writes per cfg-3 call in the PMC write traffic)
+    const auto uni64 = [](int64_t v) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uint64_t)v);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uint64_t)v >> 32));
+        return (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    const int64_t c = uni64(bid / tiles_per_row);
+    const int64_t n0 = (bid - c * tiles_per_row) * (int64_t)NOUT;
     const float *xrow = x + c * T;
     float *yrow = y + c * T;
 
@@ -222,14 +230,17 @@ fir_direct_mfma_kernel(const float *__restrict__ x, float *__restrict__ y,
         }
     }
 
-    // D layout: lane holds column j = lane&31, rows i = 8*(r/4) + 4*(lane>>5) + (r&3)
+    // D layout: lane holds column j = lane&31, rows i = 8*(r/4) + 4*(lane>>5) + (r&3).  The lane id is taken afresh (mbcnt):
+    // keeping `li` / `kk` alive through the contraction cost the 96-VGPR kernel its one spilled register.
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int li_e = lane_e & 31, kk_e = lane_e >> 5;
 #pragma unroll
     for (int t = 0; t < NJ; ++t) {
         const int64_t nb = n0 + wave * WOUT + t * 1024;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int i = 8 * (r >> 2) + 4 * kk + (r & 3);
-            const int64_t n = nb + 32 * i + li;
+            const int i = 8 * (r >> 2) + 4 * kk_e + (r & 3);
+            const int64_t n = nb + 32 * i + li_e;
             if ((DBG & 1) ? (acc[t][r] == 1234.5f) : (n < T)) yrow[n] = acc[t][r];
         }
     }
