@@ -109,6 +109,35 @@ def test_fft_conv_random_geometry_vs_float64(seed):
     close(y, exp.astype(np.float32), TOL_CONV_F32, f"C={C} T={T} K={K} pad=({pl},{pr})")
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_one_launch_kernels_random_geometry_vs_float64(seed):
+    """The tap range of the one-launch kernels (1 ... 8192) with random rows, paddings (aligned rows take `lead` zero taps and a
+    hop of whole cache lines), row counts that leave an unpaired last frame, both dtypes: whatever block (4096 / 8192 / 16 384
+    points, either 16 384-point kernel) or fallback the dispatch picks, against a float64 correlation computed with SciPy."""
+    from scipy.signal import fftconvolve
+    rng = np.random.default_rng(9100 + seed)
+    dtype = np.float64 if seed % 4 == 3 else np.float32
+    C = int(rng.integers(1, 8))
+    K = int(np.exp(rng.uniform(0, np.log(8192.0))))
+    K = int(rng.choice([K, K, 639, 640, 699, 700, 1024, 2048, 2049, 3399, 3400, 4096, 4097, 8192])) if seed % 3 == 0 else K
+    T = int(rng.integers(max(1, K // 2), 300_000))
+    if seed % 2:
+        T = (T + 31) // 32 * 32                                    # rows of whole cache lines: the aligned geometry
+    pl = int(rng.choice([K - 1, 0, int(rng.integers(0, K + 40))]))
+    pr = int(rng.choice([0, 0, int(rng.integers(0, 50))]))
+    if T + pl + pr < K:
+        pl = K - T
+    x = rnd((C, T), seed, dtype)
+    kf = (rng.standard_normal(K) / np.sqrt(K)).astype(np.float32).astype(dtype)
+    info = ext().ols_plan_info(K, T, (pl, pr), torch.float32 if dtype == np.float32 else torch.float64)
+    y = ext().fft_conv_forward(dev(x), kf, (pl, pr))
+    xp = np.pad(x.astype(np.float64), ((0, 0), (pl, pr)))
+    exp = fftconvolve(xp, kf[::-1].astype(np.float64)[None], mode="valid", axes=-1)
+    assert y.shape == exp.shape == (C, T + pl + pr - K + 1)
+    close(y, exp.astype(dtype), 4e-6 if dtype == np.float32 else TOL_CONV_F64,
+          f"C={C} T={T} K={K} pad=({pl},{pr}) {dtype.__name__} path={info['path']} N={info['N']}")
+
+
 def test_fft_conv_kernel_longer_than_the_native_limit():
     """600 001 taps is beyond the hand-written path (K <= 2^19): the rocFFT path takes over."""
     from scipy.signal import fftconvolve
