@@ -171,6 +171,8 @@ template <typename R> struct Geom {
     R ep_gain;
     int ep_scale, ep_clamp, ep_stat;
     double *ep_partial;   // [nframes]: one partial per frame
+    int nt;               // TFX_OLS_LDS_NT (default 2): 2 = the output is stored with the nontemporal hint (written once: 2-3 % on every
+                          // block size; the same hint on the signal loads, whose overlap the XCD's L2 serves, changes nothing)
 };
 
 constexpr int LDS_N = 4096;
@@ -235,6 +237,14 @@ __device__ __forceinline__ void store_pair(const cx<R> (&v)[VPT], R *__restrict_
     R *ya = y + p.ca * g.Tout + oa0, *yb = y + p.cb * g.Tout + ob0;
     const bool epi = g.ep_scale | g.ep_clamp | (g.ep_stat >= 0);
     if (!epi && p.has_b && oa0 + g.S <= g.Tout && ob0 + g.S <= g.Tout) {     // whole hops inside their rows
+        if (g.nt & 2) {                                        // the output is written once: streaming stores
+#pragma unroll
+            for (int k = 0; k < VPT; ++k) {
+                const unsigned n = (unsigned)(j + TPB * k);
+                if ((int64_t)n < g.S) { __builtin_nontemporal_store(v[k].x, ya + n); __builtin_nontemporal_store(v[k].y, yb + n); }
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < VPT; ++k) {
             const unsigned n = (unsigned)(j + TPB * k);
@@ -786,6 +796,7 @@ static void olslds_typed(const R *x, R *y, int64_t C, int64_t Tn, const R *kf_ho
     g.hist = hist; g.H = hist ? H : 0;
     g.ep_gain = ep ? (R)ep->gain : (R)1; g.ep_scale = ep ? ep->scale : 0; g.ep_clamp = ep ? ep->clamp : 0;
     g.ep_stat = ep ? ep->stat_mode : -1; g.ep_partial = nullptr;
+    g.nt = (int)envi("TFX_OLS_LDS_NT", 2);
     int64_t lead = 0, N = 0;
     TFX_CHECK(olslds_supported(K, sizeof(R) == 4 ? TFX_F32 : TFX_F64, Tn + pl + pr, &N), "olslds_forward: %lld taps are not for this path", (long long)K);
     olslds_geometry(K, Tn, pl, pr, (int)sizeof(R), N, &lead, &g.S);

@@ -85,6 +85,9 @@ struct OlsGeom {
     double *ep_partial;   // [nframes][N2 / 32]: one partial per (frame, column block); row c owns F * N2/32 consecutive ones
     int N2;            // row length (N = 256 * N2)
     int P2;            // row pitch of the workspace T in elements (N2 + pad: breaks the power-of-two stride)
+    int nt;            // nontemporal hints (TFX_OLS_NT, default 3): 1 = signal loads of pass A, 2 = signal stores of pass C -- the signal
+                       // is read once and written once; chain step 7.98 -> 7.87 ms.  (The same hint on the workspace loads of
+                       // passes B and C, their last use, changes nothing.)
 };
 
 constexpr int OLS_N1 = 256;
@@ -218,6 +221,14 @@ ols_col_fwd16_kernel(const float *__restrict__ x, cpx *__restrict__ T, const cpx
         for (int i = 0; i < NBF; ++i)
 #pragma unroll
             for (int t = 0; t < 16; ++t) v[i][t] = make_float2((float)t, (float)col);
+    } else if (inner && (g.nt & 1)) {          // the signal is read once: streaming loads
+#pragma unroll
+        for (int i = 0; i < NBF; ++i)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int64_t n = (int64_t)(q + QS * i + 16 * t) * g.N2 + n2;
+                v[i][t] = make_float2(__builtin_nontemporal_load(xa + ia0 + n), __builtin_nontemporal_load(xb + ib0 + n));
+            }
     } else if (inner) {
 #pragma unroll
         for (int i = 0; i < NBF; ++i)
@@ -325,8 +336,13 @@ ols_col_inv16_kernel(const cpx *__restrict__ T, float *__restrict__ y, const cpx
                         if (wb) acc_b = red_comb_rt(g.ep_stat, acc_b, red_elem_rt(g.ep_stat, (double)o.y));
                     }
                 }
-                if (wa) ya[oa] = o.x;
-                if (wb) yb[ob] = o.y;
+                if (g.nt & 2) {            // the output is written once and not read back here: streaming stores
+                    if (wa) __builtin_nontemporal_store(o.x, ya + oa);
+                    if (wb) __builtin_nontemporal_store(o.y, yb + ob);
+                } else {
+                    if (wa) ya[oa] = o.x;
+                    if (wb) yb[ob] = o.y;
+                }
             }
         }
     if (g.ep_stat >= 0) {                  // one partial per (frame, column block), threads combined in a fixed order
@@ -1276,7 +1292,7 @@ static NativePlan *get_native_plan(const float *kf, int64_t K, int64_t N, int64_
         OlsGeom g{};
         g.Tn = K; g.Tout = K; g.F = 1; g.S = N; g.pad_left = lead; g.out_shift = 0; g.nframes = 1;
         g.hist = nullptr; g.H = 0; g.ep_gain = 1.0f; g.ep_scale = 0; g.ep_clamp = 0; g.ep_stat = -1; g.ep_partial = nullptr;
-        g.N2 = N2; g.P2 = N2;
+        g.N2 = N2; g.P2 = N2; g.nt = 0;
         hipLaunchKernelGGL(colf_tab[1][0], dim3((unsigned)(N2 / OLS_CB)), dim3(512), OLS_SHM_COL, stream,
                            (const float *)pl->taps_dev, pl->Hp, pl->tw256, g, (int64_t)0);
         TFX_HIP(hipGetLastError());
@@ -1381,6 +1397,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     g.F = ceil_div(g.Tout + g.out_shift, g.S);
     g.nframes = C * g.F; g.N2 = plan->N2;
     g.P2 = g.N2 + (int)envi("TFX_OLS_PITCH_PAD", 0);
+    g.nt = (int)envi("TFX_OLS_NT", 3);
     const int64_t npairs = ceil_div(g.nframes, 2);
     if (g.ep_stat >= 0)                   // every (frame, column block) slot is written by exactly one workgroup
         g.ep_partial = (double *)scratch("olsn_ep_partial", (size_t)(g.nframes * (g.N2 / OLS_CB)) * sizeof(double), stream);
