@@ -200,6 +200,33 @@ int tfx_fft_conv_forward_ep(const void *x, void *y, int dtype, int64_t C, int64_
                             const void *kernel_host, int64_t K, int64_t pad_left, int64_t pad_right,
                             const tfx_epilogue *epilogue, tfx_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * tfx_sos_fft_conv_forward -- a zero-state SOS cascade followed by an FFT-mode FIR as ONE overlap-save
+ * pipeline, in the reference's own arithmetic.  Replaces two consecutive steps of Wave._materialize
+ *           src/torchfx/wave.py:207-239
+ * namely  parallel_iir_forward(x, sos, None, None)   src/torchfx/_ops.py:119-176  (float64 DF1 recursion,
+ *           src/torchfx/_csrc/cpu/iir_cpu.cpp:132-147; fresh FusedSOSCascade: zero state, src/torchfx/filter/fused.py:62-64),
+ * the downcast to the signal's float32             src/torchfx/filter/iir.py:84-184,
+ * and    fft_conv1d(., kernel, padding=(l, r))      src/torchfx/filter/_fftconv.py:70-141.
+ * The recursion runs in float64 registers inside the forward column pass of the three-pass transform (one
+ * thread per 4096-sample row, exact warm-up from zero state), so it costs no pass over the signal of its own.
+ *   x DEVICE float32 [C,T]; sos_host HOST float64 [K,6]; kernel_host HOST float32 [taps] FLIPPED;
+ *   y DEVICE float32 [C, T+pad_left+pad_right-taps+1];  y_sections: optional DEVICE float64 [K,C,T], every
+ *   section's output ("IIR compared section-by-section"), or NULL;  force_block != 0: take the 2^20-point
+ *   block even when the row is shorter than one block (fixture-sized parity tests).
+ * tfx_sos_fft_conv_supported answers 1 when the geometry is served (T and T+l+r-taps+1 multiples of 32,
+ * K <= 8 sections whose memory fades within 4096 samples, taps that select the 2^20-point block), else 0:
+ * callers stage the two steps (tfx_sos_forward, tfx_fft_conv_forward) then.
+ * ------------------------------------------------------------------------- */
+int tfx_sos_fft_conv_supported(int64_t T, const double *sos_host, int64_t K, int64_t taps,
+                               int64_t pad_left, int64_t pad_right, int force_block);
+int tfx_sos_fft_conv_forward(const float *x, float *y, int64_t C, int64_t T,
+                             const double *sos_host, int64_t K,
+                             const float *kernel_host, int64_t taps,
+                             int64_t pad_left, int64_t pad_right,
+                             double *y_sections, int force_block,
+                             const tfx_epilogue *epilogue, tfx_stream_t stream);
+
 /* the apply half of Normalize on a statistic left by an epilogue (or by tfx_stat_forward's raw form) */
 int tfx_normalize_apply(const void *x, void *y, int dtype, int64_t C, int64_t T, int mode, int per_row,
                         double peak, const double *stat_dev, tfx_stream_t stream);

@@ -1,0 +1,120 @@
+"""GPU parity -- the SOS cascade inside the forward column pass of the three-pass overlap-save pipeline
+(`tfx_sos_fft_conv_forward`, `ols_col_fwd16_sos_kernel`): `iir-cascade | FIR` in the reference's own arithmetic
+(float64 DF1 recursion, one rounding to float32, float32 overlap-save) without a pass of the recursion's own.
+
+The cascade is compared SECTION BY SECTION with the reference's float64 section outputs (`iir_cfg2_sections.npz`,
+written by oracle/make_golden.py from the real reference) through the optional `y_sections` tap, the result with the
+oracle's staged chain (iir_cpu.cpp -> float32 -> _fftconv.py) and with the staged HIP path.
+Tolerances and helpers: tests/gpu_common.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests.gpu_common import *  # noqa: F401,F403
+
+pytestmark = pytest.mark.gpu
+
+CFG2_SOS = None
+
+
+def cfg2_sos():
+    import scipy.signal as sg
+    global CFG2_SOS
+    if CFG2_SOS is None:
+        from torchfx_amd import filter as F
+        f1 = F.LoButterworth(2000, order=6, fs=48000)
+        f2 = F.ParametricEQ(frequency=1000, q=2.0, gain=3.0, fs=48000)
+        f1.compute_coefficients()
+        f2.compute_coefficients()
+        CFG2_SOS = np.vstack([f1._sos.numpy(), f2._sos.numpy()])
+    return CFG2_SOS
+
+
+def taps(K, seed=3):
+    k = np.random.default_rng(seed).standard_normal(K) * np.exp(-np.arange(K) / max(8.0, K / 8.0))
+    return (k / np.abs(k).sum()).astype(np.float32)
+
+
+def test_supported_predicate():
+    E = ext()
+    sos = cfg2_sos()
+    assert E.sos_fft_conv_supported(28_800_000, sos, 66559, (66558, 0))
+    assert not E.sos_fft_conv_supported(28_800_001, sos, 66559, (66558, 0))          # rows must be whole 128-byte lines
+    assert not E.sos_fft_conv_supported(2_880_000, sos, 1024, (1023, 0))              # one-launch LDS territory
+    assert E.sos_fft_conv_supported(8192, sos, 513, (512, 0), force_block=True)
+    import scipy.signal as sg
+    slow = sg.butter(2, 20 / 24000, "highpass", output="sos")                          # memory far longer than a row
+    assert not E.sos_fft_conv_supported(28_800_000, slow, 66559, (66558, 0))
+    nine = np.vstack([sos, sos, sos[:1]])
+    assert not E.sos_fft_conv_supported(28_800_000, nine, 66559, (66558, 0))          # more than 8 sections
+
+
+def test_cfg2_sections_golden_through_the_fused_pass(golden):
+    """north_star: "IIR compared section-by-section" -- on the kernel that runs the recursion inside pass A."""
+    g = golden("iir_cfg2_sections")
+    k = taps(513)
+    y, sec = ext().sos_fft_conv_forward(dev(g["x"]), g["sos"], torch.from_numpy(k[::-1].copy()), (512, 0),
+                                        return_sections=True, force_block=True)
+    assert sec.dtype == torch.float64 and tuple(sec.shape) == g["y_sections"].shape
+    for s in range(g["sos"].shape[0]):
+        close(sec[s], g["y_sections"][s], TOL_IIR_F64OUT, f"section {s} (fused pass A)")
+    ref = O.fft_conv1d(g["y"], k[::-1].copy(), (512, 0))          # the reference's own float32 cascade output, then its FFT convolution
+    close(y, ref, TOL_CONV_F32, "chain")
+    y2 = ext().sos_fft_conv_forward(dev(g["x"]), g["sos"], torch.from_numpy(k[::-1].copy()), (512, 0), force_block=True)
+    assert torch.equal(y, y2)                                     # the tap instantiation computes the same samples
+
+
+@pytest.mark.parametrize("C,T,K", [(1, 1 << 20, 8193), (3, 2_500_000 // 32 * 32, 66559), (2, 1_100_000 // 32 * 32, 20000)])
+def test_multi_frame_against_oracle_and_staged(C, T, K):
+    """Several frames per row, an odd number of frames (a pair without a second frame), frames that start in the left
+    padding and end beyond the row."""
+    sos = cfg2_sos()
+    x = rnd((C, T), 11)
+    k = taps(K)
+    kf = torch.from_numpy(k[::-1].copy())
+    y = ext().sos_fft_conv_forward(dev(x), sos, kf, (K - 1, 0), force_block=True)
+    assert tuple(y.shape) == (C, T)
+    # staged HIP path: cascade kernel (float64 arithmetic, float32 out) then the overlap-save pipeline
+    ys, _, _ = ext().sos_forward(dev(x), None, torch.from_numpy(sos), None, None)
+    ys = ext().fft_conv_forward(ys, kf, (K - 1, 0))
+    close(y, ys.cpu().numpy(), 2e-6, "fused vs staged HIP")
+    # oracle on the first row (seconds of CPU)
+    ref = O.chain_forward(x[:1], sos, [k[::-1].copy()])
+    close(y[:1], ref, TOL_CONV_F32, "fused vs oracle")
+
+
+def test_sections_on_a_multi_frame_row():
+    """Section taps over rows longer than a frame: every sample of every section against the oracle's float64 recursion
+    (rows of frames that overlap by K - 1 samples are written by both frames -- same values to float64 round-off)."""
+    sos = cfg2_sos()
+    T = (1 << 20) + 300_000 // 32 * 32
+    x = rnd((2, T), 5)
+    k = taps(66559)
+    y, sec = ext().sos_fft_conv_forward(dev(x), sos, torch.from_numpy(k[::-1].copy()), (66558, 0), return_sections=True,
+                                        force_block=True)
+    _, _, _, ref = O.sos_forward(x.astype(np.float64), sos, sections=True)
+    for s in range(sos.shape[0]):
+        close(sec[s], ref[s], TOL_IIR_F64OUT, f"section {s}")
+
+
+def test_epilogue_rides_along():
+    sos = cfg2_sos()
+    T = 1_200_000 // 32 * 32
+    x = rnd((2, T), 7)
+    k = taps(30000)
+    kf = torch.from_numpy(k[::-1].copy())
+    E = ext()
+    ep = E.Epilogue(gain=0.5, clamp=True, stat="absmax", per_row=True)
+    y = E.sos_fft_conv_forward(dev(x), sos, kf, (29999, 0), force_block=True, epilogue=ep)
+    y0 = E.sos_fft_conv_forward(dev(x), sos, kf, (29999, 0), force_block=True)
+    exp = torch.clamp(y0 * 0.5, -1.0, 1.0)
+    assert torch.equal(y, exp)
+    close(ep.stat_value, exp.abs().amax(dim=1).double().cpu().numpy(), 1e-12, "statistic")
+
+
+def test_refuses_what_it_does_not_serve():
+    sos = cfg2_sos()
+    x = dev(rnd((1, 8191), 1))
+    with pytest.raises(RuntimeError, match="unsupported here"):
+        ext().sos_fft_conv_forward(x, sos, torch.from_numpy(taps(65)), (64, 0), force_block=True)

@@ -33,6 +33,10 @@ void fir_clear();
 void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, const void *kernel_host,
                       int64_t K, int64_t pad_left, int64_t pad_right, hipStream_t stream, const void *hist = nullptr,
                       int64_t H = 0, const Epilogue *ep = nullptr);
+bool sos_fft_conv_supported(int64_t T, const double *sos_host, int64_t Ksos, int64_t K, int64_t pad_left, int64_t pad_right, int force);
+void sos_fft_conv_forward(const float *x, float *y, int64_t C, int64_t T, const double *sos_host, int64_t Ksos,
+                          const float *kernel_host, int64_t K, int64_t pad_left, int64_t pad_right, double *sections, int force,
+                          const Epilogue *ep, hipStream_t stream);
 void normalize_apply_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, int mode, int per_row, double peak,
                              const double *stat, hipStream_t stream);
 void fftconv_clear();
@@ -220,6 +224,27 @@ int tfx_fft_conv_forward_ep(const void *x, void *y, int dtype, int64_t C, int64_
     TFX_API_BEGIN
     const Epilogue ep = to_epilogue(epilogue);
     fft_conv_forward(x, y, dtype, C, T, kernel_host, K, pad_left, pad_right, (hipStream_t)stream, nullptr, 0, &ep);
+    TFX_API_END
+}
+
+int tfx_sos_fft_conv_supported(int64_t T, const double *sos_host, int64_t K, int64_t taps, int64_t pad_left, int64_t pad_right,
+                               int force_block)
+{
+    try {
+        return (sos_host && sos_fft_conv_supported(T, sos_host, K, taps, pad_left, pad_right, force_block)) ? 1 : 0;
+    } catch (...) {
+        return 0;
+    }
+}
+
+int tfx_sos_fft_conv_forward(const float *x, float *y, int64_t C, int64_t T, const double *sos_host, int64_t K,
+                             const float *kernel_host, int64_t taps, int64_t pad_left, int64_t pad_right,
+                             double *y_sections, int force_block, const tfx_epilogue *epilogue, tfx_stream_t stream)
+{
+    TFX_API_BEGIN
+    const Epilogue ep = to_epilogue(epilogue);
+    sos_fft_conv_forward(x, y, C, T, sos_host, K, kernel_host, taps, pad_left, pad_right, y_sections, force_block,
+                         epilogue ? &ep : nullptr, (hipStream_t)stream);
     TFX_API_END
 }
 

@@ -79,6 +79,15 @@ template <typename V> __device__ __forceinline__ void stg16_stream(void *p, cons
     __builtin_nontemporal_store(__builtin_bit_cast(tfx_u32x4, v), (tfx_u32x4 *)p);
 }
 
+// olsnative.hip: a planner-built (zero-state) SOS cascade that runs inside the forward column pass of the three-pass
+// overlap-save pipeline (ols_col_fwd16_sos_kernel)
+struct SosFuseHost {
+    const double *sos;      // host [K, 6] rows b0 b1 b2 a0 a1 a2 (a0 ignored, iir_cpu.cpp:86)
+    int64_t K;
+    int64_t warm;           // samples after which the cascade has forgotten its past to float64 round-off (sos_plan_info)
+    double *sections;       // optional DEVICE [K, C, T] float64: every section's output, or null
+};
+
 // fir.hip: device copy of a host tap vector, cached by content and device (uploaded, blocking, the first time a filter is seen)
 const void *cached_taps(const void *host, size_t bytes, size_t padded);
 

@@ -296,6 +296,32 @@ std::tuple<Tensor, Tensor> fft_conv_ep_op(const Tensor &x_in, const Tensor &kern
     return {y, stat};
 }
 
+// zero-state SOS cascade | FFT-mode FIR as one overlap-save pipeline (tfx_sos_fft_conv_forward): y, the statistic of the
+// epilogue and -- on request -- every section's float64 output [K, C, T]
+std::tuple<Tensor, Tensor, Tensor> sos_fft_conv_op(const Tensor &x_in, const Tensor &sos_cpu, const Tensor &kernel, int64_t pad_left,
+                                                   int64_t pad_right, bool sections, bool force_block, double gain, bool clamp,
+                                                   int64_t stat_mode, bool per_row)
+{
+    TORCH_CHECK(x_in.dim() == 2, "sos_fft_conv_forward: x must be [C, T], got ", x_in.sizes());
+    need_device(x_in, "x");
+    TORCH_CHECK(x_in.scalar_type() == at::kFloat, "sos_fft_conv_forward: float32 signals only, got ", x_in.scalar_type());
+    const Tensor x = x_in.contiguous();
+    const Tensor sos = host_f64(sos_cpu, 6, "sos_fft_conv_forward");
+    TORCH_CHECK(sos.dim() == 2, "sos_fft_conv_forward: sos must be [K, 6]");
+    const Tensor k = taps_host(kernel, x);
+    const int64_t C = x.size(0), T = x.size(1), K = sos.size(0), taps = k.numel();
+    const int64_t tout = T + pad_left + pad_right - taps + 1;
+    Tensor y = at::empty({C, tout > 0 ? tout : 0}, x.options()), stat;
+    Tensor sec = sections ? at::empty({K, C, T}, x.options().dtype(at::kDouble)) : at::empty({0}, x.options().dtype(at::kDouble));
+    const tfx_epilogue ep = make_epilogue(gain, clamp, stat_mode, per_row, stat, x, C);
+    c10::hip::HIPGuard guard(x.get_device());
+    check_rc(tfx_sos_fft_conv_forward(x.data_ptr<float>(), y.data_ptr<float>(), C, T, sos.data_ptr<double>(), K, k.data_ptr<float>(), taps,
+                                      pad_left, pad_right, sections ? sec.data_ptr<double>() : nullptr, force_block ? 1 : 0, &ep,
+                                      stream_of(x)),
+             "sos_fft_conv_forward");
+    return {y, stat, sec};
+}
+
 // the apply half of Normalize on a statistic an epilogue left on the device
 Tensor normalize_apply_op(const Tensor &x, const Tensor &stat, double peak, int64_t mode, bool per_row)
 {
@@ -561,6 +587,8 @@ TORCH_LIBRARY(torchfx_hip, m)
           "bool per_row, *, ScalarType? out_dtype=None, int precision=-1) -> (Tensor, Tensor, Tensor, Tensor)");
     m.def("fft_conv_forward_ep(Tensor x, Tensor kernel, int pad_left, int pad_right, float gain, bool clamp, int stat_mode, "
           "bool per_row) -> (Tensor, Tensor)");
+    m.def("sos_fft_conv_forward(Tensor x, Tensor sos_cpu, Tensor kernel, int pad_left, int pad_right, bool sections=False, "
+          "bool force_block=False, float gain=1.0, bool clamp=False, int stat_mode=-1, bool per_row=False) -> (Tensor, Tensor, Tensor)");
     m.def("normalize_apply(Tensor x, Tensor stat, float peak, int mode, bool per_row) -> Tensor");
     m.def("sum_forward(Tensor[] tensors) -> Tensor");
     m.def("gain_forward(Tensor x, float gain, bool clamp) -> Tensor");
@@ -586,6 +614,7 @@ TORCH_LIBRARY_IMPL(torchfx_hip, CUDA, m)          // "CUDA" is the dispatch key 
     m.impl("chunk_forward", chunk_op);
     m.impl("sos_forward_ep", sos_ep_op);
     m.impl("fft_conv_forward_ep", fft_conv_ep_op);
+    m.impl("sos_fft_conv_forward", sos_fft_conv_op);
     m.impl("normalize_apply", normalize_apply_op);
     m.impl("sum_forward", sum_op);
     m.impl("gain_forward", gain_op);
@@ -624,7 +653,7 @@ TORCH_LIBRARY_IMPL(torchfx_hip, CPU, m)
 {
     for (const char *name : {"sos_forward", "sos_forward_sections", "sos_bank_forward", "sos_bank_sum_forward", "biquad_forward",
                              "delay_line_forward", "fir_direct_forward", "fft_conv_forward", "fir_stream_forward", "chunk_forward", "sos_forward_ep",
-                             "fft_conv_forward_ep", "normalize_apply", "sum_forward", "gain_forward", "quantile_abs", "stat_forward",
+                             "fft_conv_forward_ep", "sos_fft_conv_forward", "normalize_apply", "sum_forward", "gain_forward", "quantile_abs", "stat_forward",
                              "normalize_forward", "deinterleave_forward", "deinterleave_into", "interleave_forward"})
         m.impl(name, torch::CppFunction::makeFromBoxedFunction<&no_cpu_boxed>());
 }

@@ -28,7 +28,10 @@ namespace tfx {
 // olsnative.hip: hand-written LDS FFT passes for the long-kernel float32 case
 bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out);
 void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const float *kf_host, int64_t K,
-                       int64_t pl, int64_t pr, int64_t N, hipStream_t stream, const float *hist, int64_t H, const Epilogue *ep);
+                       int64_t pl, int64_t pr, int64_t N, hipStream_t stream, const float *hist, int64_t H, const Epilogue *ep,
+                       const SosFuseHost *sosf = nullptr);
+bool olsnative_sos_supported(int64_t Ksos, int64_t warm, int64_t K, int64_t Tn, int64_t pl, int64_t pr, int force, int64_t *N_out);
+void sos_plan_info(const double *sos_host, int64_t K, int *precision, int64_t *warmup, double *err_bound);
 
 // olslds.hip: one launch, the whole 4096-point transform in LDS (K <= 2048 taps, float32 and float64, rows of any length)
 bool olslds_supported(int64_t K, int dtype, int64_t L, int64_t *N_out);
@@ -350,6 +353,43 @@ void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, c
         fft_conv_typed<double, double2>((const double *)x, (double *)y, dtype, C, T, kernel_host, K, pad_left, pad_right, stream,
                                         (const double *)hist, H);
     if (ep && ep->any()) epilogue_as_passes(y, dtype, C, L - K + 1, *ep, stream);     // rocFFT path: separate passes
+}
+
+// `iir-cascade | FIR` as ONE overlap-save pipeline in the reference's arithmetic: the zero-state float64 cascade
+// (_ops.py:119-176 with state None -> iir_cpu.cpp:64-159), its result rounded to float32 (iir.py:84-184, the downcast), then
+// fft_conv1d (_fftconv.py:70-141) -- the cascade runs inside the forward column pass (olsnative.hip), no pass of its own.
+bool sos_fft_conv_supported(int64_t T, const double *sos_host, int64_t Ksos, int64_t K, int64_t pad_left, int64_t pad_right, int force)
+{
+    if (Ksos < 1 || T <= 0 || K < 1) return false;
+    int prec = 0;
+    int64_t warm = -1;
+    double eb = 0.0;
+    sos_plan_info(sos_host, Ksos, &prec, &warm, &eb);
+    int64_t N = 0;
+    return olsnative_sos_supported(Ksos, warm, K, T, pad_left, pad_right, force, &N);
+}
+
+void sos_fft_conv_forward(const float *x, float *y, int64_t C, int64_t T, const double *sos_host, int64_t Ksos,
+                          const float *kernel_host, int64_t K, int64_t pad_left, int64_t pad_right, double *sections, int force,
+                          const Epilogue *ep, hipStream_t stream)
+{
+    TFX_CHECK(!ep || ep->stat_mode < 0 || ep->stat_out, "sos_fft_conv_forward: statistic requested without an output buffer");
+    TFX_CHECK(K >= 1 && pad_left >= 0 && pad_right >= 0 && Ksos >= 1, "sos_fft_conv_forward: bad sizes");
+    const int64_t L = T + pad_left + pad_right;
+    TFX_CHECK(L >= K, "Input should be at least as large as the kernel size %lld, but it is only %lld samples long.",
+              (long long)K, (long long)L);
+    if (C == 0) return;
+    TFX_CHECK(C > 0 && T > 0, "sos_fft_conv_forward: bad shape");
+    TFX_CHECK(x && y && kernel_host && sos_host, "sos_fft_conv_forward: null pointer");
+    int prec = 0;
+    int64_t warm = -1, N = 0;
+    double eb = 0.0;
+    sos_plan_info(sos_host, Ksos, &prec, &warm, &eb);
+    TFX_CHECK(olsnative_sos_supported(Ksos, warm, K, T, pad_left, pad_right, force, &N),
+              "sos_fft_conv_forward: unsupported here (float32 rows of a multiple of 32 samples, at most 8 sections whose memory "
+              "fades within 4096 samples, taps that take the 2^20-point block) -- ask tfx_sos_fft_conv_supported first");
+    const SosFuseHost sf{sos_host, Ksos, warm, sections};
+    olsnative_forward(x, y, C, T, kernel_host, K, pad_left, pad_right, N, stream, nullptr, 0, (ep && ep->any()) ? ep : nullptr, &sf);
 }
 
 }  // namespace tfx

@@ -366,6 +366,131 @@ ols_col_inv16_kernel(const cpx *__restrict__ T, float *__restrict__ y, const cpx
 }
 
 // ---------------------------------------------------------------------------------------------
+// Pass A with the SOS cascade in front of it (N2 = 4096): `iir-cascade | FIR...` in the reference's own arithmetic --
+// float64 DF1 recursion (src/torchfx/_csrc/cpu/iir_cpu.cpp:132-147), one rounding to float32 (filter/iir.py: the downcast
+// of _sos_cascade_forward), float32 overlap-save (filter/_fftconv.py:123-140) -- without the recursion's own 8 B/sample pass.
+//
+// A frame is 256 rows of 4096 consecutive samples and the column transform wants 32 adjacent columns of ALL rows at once,
+// so no workgroup ever holds a long run of consecutive samples -- but it holds 512 SHORT runs that each continue where
+// the previous column block stopped.  One workgroup therefore owns a frame PAIR and walks its 128 column blocks in time
+// order; thread (frame, row) is the recursion of that row: it carries the 2K+2 float64 state values of its row in
+// registers from block to block and runs the plain sequential DF1 recursion over its 32 samples -- no scan, no matrices,
+// 5 fused multiply-adds per sample and section.  A row starts `warm` samples early from zero state (the planner's
+// max|A^W| < 2^-60 of sos.hip: the state at the row's first sample is the true one to float64 round-off); those
+// warm-up blocks are read and filtered but not transformed.  Per block: coalesced 16-byte loads of the 512 lines
+// (prefetched one block ahead) -> LDS stage [512][36] -> each thread takes its line, filters it and puts the rounded
+// float32 samples back IN PLACE -> the stage is the column transform's input z = a + i b -> radix-16 x 16 transform through
+// the same LDS bytes -> workspace.  Samples outside [0, T) enter the recursion as zeros and leave it as zeros (the
+// reference filters T samples and the FIR pads afterwards).
+// ---------------------------------------------------------------------------------------------
+constexpr int SOSF_MAXK = 8;
+constexpr int SOSF_LS = 36;                      // floats per line of the stage: conflict-free ds_read_b128 / ds_write_b128 per lane
+constexpr size_t OLS_SHM_SOSF = (size_t)512 * SOSF_LS * sizeof(float) + 256 * sizeof(cpx);
+struct SosFuse {                                 // by value in the kernel arguments: the coefficients are scalar operands
+    double co[SOSF_MAXK][5];                     // b0, b1, b2, -a1, -a2 of each section
+    double *sections;                            // optional [K, C, T] float64: every section's output (parity tests), or null
+    int warm_blocks;                             // warm-up of a row in 32-sample blocks
+};
+
+template <int KS, bool TAPS>
+__global__ void __launch_bounds__(512, 2)
+ols_col_fwd16_sos_kernel(const float *__restrict__ x, cpx *__restrict__ T, const cpx *__restrict__ tw256g,
+                         OlsGeom g, int64_t frame0, SosFuse sf)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *S = (float *)smem;                          // [512][SOSF_LS]: line (frame, row)
+    cpx *lds = (cpx *)smem;                            // the transform's [256][32] exchange lives in the same bytes
+    cpx *tw256 = (cpx *)(smem + (size_t)512 * SOSF_LS * sizeof(float));
+    const int tid = threadIdx.x;
+    if (tid < 256) tw256[tid] = tw256g[tid];
+    const int64_t pair = blockIdx.x;
+    const int64_t fa = frame0 + 2 * pair, fb = fa + 1;
+    const int64_t ca = fa / g.F, ia0 = (fa % g.F) * g.S - g.pad_left;
+    const bool has_b = fb < g.nframes;
+    const int64_t cb_ = has_b ? fb / g.F : 0, ib0 = has_b ? (fb % g.F) * g.S - g.pad_left : 0;
+    const float *xa = x + ca * g.Tn, *xb = x + cb_ * g.Tn;
+    const int64_t back = (int64_t)OLS_CB * sf.warm_blocks;
+
+    // recursion side: this thread is line `tid` = (frame tid >> 8, row tid & 255)
+    const bool mine_b = tid >= 256;
+    int64_t tl = (mine_b ? ib0 : ia0) + (int64_t)(tid & 255) * g.N2 - back;        // time of the block's first sample
+    const int64_t chan_l = mine_b ? cb_ : ca;
+    const bool lane_on = !mine_b || has_b;
+    double h1[KS + 1], h2[KS + 1];             // h[0]: input history; h[s + 1]: output history of section s (iir_cpu.cpp:125-130)
+#pragma unroll
+    for (int s = 0; s <= KS; ++s) { h1[s] = 0.0; h2[s] = 0.0; }
+
+    // loader side: line (tid >> 3) + 64 i, 16-byte part tid & 7;  i < 4: frame a, i >= 4: frame b
+    const int lrow = tid >> 3, lpart = tid & 7;
+    int64_t ta = ia0 + (int64_t)lrow * g.N2 - back + 4 * lpart;
+    int64_t tb = ib0 + (int64_t)lrow * g.N2 - back + 4 * lpart;
+    const int64_t rstep = (int64_t)64 * g.N2;
+    float4 P[8];
+    auto fetch = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool isb = i >= 4;
+            const int64_t t = (isb ? tb : ta) + (int64_t)(i & 3) * rstep;
+            const float *src = (isb ? xb : xa) + t;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t >= 0 && t < g.Tn && (!isb || has_b)) {          // lines never straddle the row's ends (aligned frames, T % 32 == 0)
+                v = (g.nt & 1) ? ldg16_stream<float4>(src) : *(const float4 *)src;
+            }
+            P[i] = v;
+        }
+        ta += OLS_CB; tb += OLS_CB;
+    };
+    fetch();
+    cpx *Tp = T + pair * ((int64_t)OLS_N1 * g.P2);
+    const int col = tid & 31, q = tid >> 5;
+    for (int blk = -sf.warm_blocks; blk < g.N2 / OLS_CB; ++blk) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *(float4 *)&S[(lrow + 64 * i) * SOSF_LS + 4 * lpart] = P[i];
+        if (blk + 1 < g.N2 / OLS_CB) fetch();              // in flight while this block is filtered and transformed
+        __syncthreads();
+        float u[OLS_CB];
+#pragma unroll
+        for (int j = 0; j < OLS_CB / 4; ++j) {
+            const float4 w4 = *(const float4 *)&S[tid * SOSF_LS + 4 * j];
+            u[4 * j] = w4.x; u[4 * j + 1] = w4.y; u[4 * j + 2] = w4.z; u[4 * j + 3] = w4.w;
+        }
+        const bool live = lane_on && tl >= 0 && tl < g.Tn;     // the whole block is inside the row or outside it
+#pragma unroll
+        for (int n = 0; n < OLS_CB; ++n) {
+            double v = (double)u[n];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                double yn = sf.co[s][0] * v;
+                yn = __builtin_fma(sf.co[s][1], h1[s], yn);
+                yn = __builtin_fma(sf.co[s][2], h2[s], yn);
+                yn = __builtin_fma(sf.co[s][3], h1[s + 1], yn);
+                yn = __builtin_fma(sf.co[s][4], h2[s + 1], yn);
+                h2[s] = h1[s]; h1[s] = v;
+                v = yn;
+                if (TAPS) { if (live && blk >= 0) sf.sections[((int64_t)s * (g.nframes / g.F) + chan_l) * g.Tn + tl + n] = yn; }
+            }
+            h2[KS] = h1[KS]; h1[KS] = v;
+            u[n] = live ? (float)v : 0.0f;
+        }
+        tl += OLS_CB;
+        if (blk < 0) { __syncthreads(); continue; }           // warm-up block: every line was read, the stage may be refilled
+#pragma unroll
+        for (int j = 0; j < OLS_CB / 4; ++j)
+            *(float4 *)&S[tid * SOSF_LS + 4 * j] = make_float4(u[4 * j], u[4 * j + 1], u[4 * j + 2], u[4 * j + 3]);
+        __syncthreads();
+        cpx v[1][16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[0][t] = make_float2(S[(q + 16 * t) * SOSF_LS + col], S[(256 + q + 16 * t) * SOSF_LS + col]);
+        __syncthreads();                                      // the exchange overwrites the stage
+        col_stages16<false, 1, true>(v, lds, tw256, col, q);
+        const int n2 = blk * OLS_CB + col;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) Tp[(int64_t)(q + 16 * k) * g.P2 + n2] = v[0][DFT16_AT(k)];
+        __syncthreads();                                      // exchange read: the stage may be refilled
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Row pass B: one wavefront per row of N2 = 4^L2 points; lane owns butterflies j = lane + 64 i.
 // ---------------------------------------------------------------------------------------------
 template <int L2, bool INV>
@@ -1112,6 +1237,12 @@ static const coli_t coli_tab[2][5] = {
     {ols_col_inv16_kernel<1, 0>, ols_col_inv16_kernel<1, 1>, ols_col_inv16_kernel<1, 2>, ols_col_inv16_kernel<1, 3>, ols_col_inv16_kernel<1, 4>}};
 static const row_t row_tab[8] = {ols_row4096_kernel<0, 0>, ols_row4096_kernel<1, 0>, ols_row4096_kernel<0, 1>, ols_row4096_kernel<1, 1>,
                                  ols_row4096_kernel<0, 2>, ols_row4096_kernel<1, 2>, ols_row4096_kernel<0, 3>, ols_row4096_kernel<1, 3>};
+typedef void (*colsos_t)(const float *, cpx *, const cpx *, OlsGeom, int64_t, SosFuse);
+static const colsos_t colsos_tab[2][SOSF_MAXK] = {
+    {ols_col_fwd16_sos_kernel<1, false>, ols_col_fwd16_sos_kernel<2, false>, ols_col_fwd16_sos_kernel<3, false>, ols_col_fwd16_sos_kernel<4, false>,
+     ols_col_fwd16_sos_kernel<5, false>, ols_col_fwd16_sos_kernel<6, false>, ols_col_fwd16_sos_kernel<7, false>, ols_col_fwd16_sos_kernel<8, false>},
+    {ols_col_fwd16_sos_kernel<1, true>, ols_col_fwd16_sos_kernel<2, true>, ols_col_fwd16_sos_kernel<3, true>, ols_col_fwd16_sos_kernel<4, true>,
+     ols_col_fwd16_sos_kernel<5, true>, ols_col_fwd16_sos_kernel<6, true>, ols_col_fwd16_sos_kernel<7, true>, ols_col_fwd16_sos_kernel<8, true>}};
 constexpr int MAXL = 8;
 struct Lanes {                      // internal streams and fork/join events of one device
     hipStream_t stream[MAXL] = {};
@@ -1138,6 +1269,9 @@ static void ols_set_attributes(int dev)
             TFX_HIP(hipFuncSetAttribute((const void *)colf_tab[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, (int)OLS_SHM_COL));
             TFX_HIP(hipFuncSetAttribute((const void *)coli_tab[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, (int)OLS_SHM_COL));
         }
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < SOSF_MAXK; ++b)
+            TFX_HIP(hipFuncSetAttribute((const void *)colsos_tab[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, (int)OLS_SHM_SOSF));
     attr_tab[dev] = true;
 }
 static void ols_make_lanes(int dev, int nlanes)           // lanes are created when first used
@@ -1348,8 +1482,25 @@ bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out)
     return true;
 }
 
+// The cascade-in-pass-A form (ols_col_fwd16_sos_kernel): 4096-point rows, aligned frames, a cascade of at most SOSF_MAXK
+// sections whose warm-up fits a row.  `force`: take the 2^20-point block even for rows shorter than one block (tests at
+// fixture size; a one-frame launch).
+bool olsnative_sos_supported(int64_t Ksos, int64_t warm, int64_t K, int64_t Tn, int64_t pl, int64_t pr, int force, int64_t *N_out)
+{
+    if (envi("TFX_OLS_SOS", 1) == 0) return false;
+    if (Ksos < 1 || Ksos > SOSF_MAXK || warm < 0 || warm > envi("TFX_OLS_SOS_MAXWARM", 4096)) return false;
+    const int64_t L = Tn + pl + pr, N = (int64_t)1 << 20;
+    if (L < K || Tn % 32 != 0 || (L - K + 1) % 32 != 0 || envi("TFX_OLS_ALIGN", 1) == 0) return false;
+    int64_t n = 0;
+    if (force) { if (N < 2 * (K + 32)) return false; }
+    else if (!olsnative_supported(K, L, &n) || n != N) return false;
+    if (N_out) *N_out = N;
+    return true;
+}
+
 void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const float *kf_host, int64_t K,
-                       int64_t pl, int64_t pr, int64_t N, hipStream_t stream, const float *hist, int64_t H, const Epilogue *ep)
+                       int64_t pl, int64_t pr, int64_t N, hipStream_t stream, const float *hist, int64_t H, const Epilogue *ep,
+                       const SosFuseHost *sosf)
 {
     HostTrace tr;
     // g_np_mu guards the plan cache, the one-time function attributes and the creation of the internal streams (the three
@@ -1407,15 +1558,18 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     // B and C find the slab pass A / B just wrote in the cache instead of in HBM and the whole step gains 8-11 % despite
     // the smaller launches -- cfg 4: 9.4-9.5 ms at 3 x 1 GB, 8.4-8.5 ms at 2 x 64 MB; 48 MB x 3 is as good, 4 lanes or
     // >= 128 MB slabs are not (profiles/r03_experiments.txt).  Default: 64 MB slabs on two lanes.
-    int nlanes = (int)envi("TFX_OLS_STREAMS", 2);
+    // Cascade in pass A: one workgroup per frame pair lives for a whole frame (204 column blocks), so a launch needs
+    // hundreds of pairs to fill the chip -- slabs of 1 GB on three lanes; the long-lived recursion workgroups of one
+    // lane share the chip with the bandwidth-bound passes B and C of the others.
+    int nlanes = (int)(sosf ? envi("TFX_OLS_SOS_STREAMS", 3) : envi("TFX_OLS_STREAMS", 2));
     if (nlanes < 1) nlanes = 1;
     if (nlanes > MAXL) nlanes = MAXL;
     const int64_t pair_bytes = (int64_t)OLS_N1 * g.P2 * (int64_t)sizeof(cpx);
-    int64_t slab = envi("TFX_OLS_PAIRS_PER_SLAB", 0);
+    int64_t slab = sosf ? envi("TFX_OLS_SOS_PAIRS", 0) : envi("TFX_OLS_PAIRS_PER_SLAB", 0);
     if (slab <= 0) {
         // The workspace lives outside PyTorch's caching allocator and is kept between calls (scratch(), released by
         // tfx_clear_caches); TFX_OLS_SLAB_MB bounds a lane's share, never more than 1/8 of the free memory over all lanes.
-        int64_t slab_mb = envi("TFX_OLS_SLAB_MB", 64);
+        int64_t slab_mb = sosf ? envi("TFX_OLS_SOS_SLAB_MB", 1024) : envi("TFX_OLS_SLAB_MB", 64);
         {
             // the cap follows the memory free when the device is first used (and again after tfx_clear_caches), not at every call:
             // a driver query per step costs tens of microseconds, is not allowed while a stream is capturing, and would make the
@@ -1455,6 +1609,17 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     ols_set_attributes(dev);
     tr.mark("function attributes");
     const int ncb = g.N2 / OLS_CB;
+    SosFuse sosk{};
+    if (sosf) {
+        TFX_CHECK(g.N2 == 4096 && align && !hist && sosf->K >= 1 && sosf->K <= SOSF_MAXK && sosf->warm >= 0,
+                  "olsnative_forward: the cascade cannot run inside the column pass here (olsnative_sos_supported)");
+        for (int64_t s = 0; s < sosf->K; ++s) {
+            const double *co = sosf->sos + 6 * s;                 // b0 b1 b2 a0 a1 a2; a0 is not used (iir_cpu.cpp:86)
+            sosk.co[s][0] = co[0]; sosk.co[s][1] = co[1]; sosk.co[s][2] = co[2]; sosk.co[s][3] = -co[4]; sosk.co[s][4] = -co[5];
+        }
+        sosk.sections = sosf->sections;
+        sosk.warm_blocks = (int)ceil_div(sosf->warm, OLS_CB);
+    }
     // Internal streams (TFX_OLS_STREAMS, default 2), slabs rotate over them: while one slab drains the tail of a pass
     // (the last, partially filled round of workgroups) the other slab's pass fills the idle CUs.
     // Fork/join with events on the caller's stream; each lane has its own workspace.
@@ -1483,7 +1648,12 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
         const int ln = nlanes > 1 ? (int)(slab_idx % nlanes) : 0;
         hipStream_t stream = nlanes > 1 ? lane_stream[ln] : user_stream;   // shadows the parameter
         cpx *T = Tlane[ln];
-        {
+        if (sosf) {
+            ProfScope ps("ols_col_fwd16_sos_kernel", stream);
+            hipLaunchKernelGGL(colsos_tab[sosf->sections ? 1 : 0][sosf->K - 1], dim3((unsigned)np), dim3(512), OLS_SHM_SOSF, stream,
+                               x, T, plan->tw256, g, 2 * p0, sosk);
+            TFX_HIP(hipGetLastError());
+        } else {
             ProfScope ps("ols_col_fwd16_kernel", stream);
             hipLaunchKernelGGL(colf, dim3((unsigned)(np * ncb)), dim3(512 / nbf), shm_col, stream,
                                x, T, plan->tw256, g, 2 * p0);

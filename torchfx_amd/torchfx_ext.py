@@ -33,7 +33,7 @@ from torchfx_amd import native
 
 __all__ = [
     "biquad_forward", "sos_forward", "sos_bank_forward", "sos_bank_sum_forward", "delay_line_forward",
-    "fir_direct_forward", "fft_conv_forward", "fir_stream_forward", "chunk_forward", "chunk_supported", "normalize_apply", "Epilogue", "sum_forward", "gain_forward", "quantile_abs", "stat_forward", "normalize_forward",
+    "fir_direct_forward", "fft_conv_forward", "sos_fft_conv_forward", "sos_fft_conv_supported", "fir_stream_forward", "chunk_forward", "chunk_supported", "normalize_apply", "Epilogue", "sum_forward", "gain_forward", "quantile_abs", "stat_forward", "normalize_forward",
     "deinterleave_forward", "interleave_forward", "sos_plan_info", "ols_plan_info", "prewarm",
 ]
 
@@ -166,6 +166,31 @@ def fft_conv_forward(x: Tensor, kernel, padding: tuple[int, int] = (0, 0), epilo
             epilogue.stat_mode, epilogue.per_row)
         return y
     return native.ops().fft_conv_forward(x, _kernel_host(kernel, x.dtype), int(padding[0]), int(padding[1]))
+
+
+def sos_fft_conv_supported(T: int, sos, taps: int, padding: tuple[int, int] = (0, 0), force_block: bool = False) -> bool:
+    """Whether :func:`sos_fft_conv_forward` serves float32 rows of ``T`` samples with this cascade and tap count
+    (``tfx_sos_fft_conv_supported``; host-only, no device needed)."""
+    s = np.ascontiguousarray(_coeff(sos).detach().cpu().numpy(), dtype=np.float64).reshape(-1, 6)
+    return bool(L.load().tfx_sos_fft_conv_supported(
+        ctypes.c_int64(int(T)), s.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.c_int64(s.shape[0]),
+        ctypes.c_int64(int(taps)), ctypes.c_int64(int(padding[0])), ctypes.c_int64(int(padding[1])), ctypes.c_int(int(force_block))))
+
+
+def sos_fft_conv_forward(x: Tensor, sos, kernel, padding: tuple[int, int] = (0, 0), *, return_sections: bool = False,
+                         force_block: bool = False, epilogue: Epilogue | None = None):
+    """A zero-state SOS cascade followed by ``fft_conv1d`` as ONE overlap-save pipeline in the reference's arithmetic:
+    float64 DF1 recursion (``_ops.py:119-176`` with ``state=None`` -> ``iir_cpu.cpp:64-159``), the downcast to float32
+    (``iir.py:84-184``), float32 overlap-save (``_fftconv.py:70-141``).  The recursion runs inside the forward column
+    pass of the transform.  ``x [C,T]`` float32; returns ``y [C, T+l+r-K+1]`` (+ the float64 output of every section
+    ``[K,C,T]`` with ``return_sections``).  Raises when :func:`sos_fft_conv_supported` says no."""
+    ep = epilogue if epilogue is not None else Epilogue()
+    y, stat, sec = native.ops().sos_fft_conv_forward(
+        x, _coeff(sos), _kernel_host(kernel, x.dtype), int(padding[0]), int(padding[1]), bool(return_sections),
+        bool(force_block), ep.gain, ep.clamp, ep.stat_mode, ep.per_row)
+    if epilogue is not None:
+        epilogue.stat_value = stat
+    return (y, sec) if return_sections else y
 
 
 def normalize_apply(x: Tensor, stat: Tensor, peak: float, mode: int = 0, per_row: bool = False) -> Tensor:
