@@ -53,3 +53,9 @@ if "check" in what:
     ys, _, _ = E.sos_forward(x, None, sos, None, None)
     ys = E.fft_conv_forward(ys, k, (K - 1, 0))
     print("max |fused - staged| =", float((y - ys).abs().max()), " max|y| =", float(ys.abs().max()))
+if "sweep" in what:
+    for streams in (2, 3, 4):
+        for pairs in (32, 64, 128, 256, 480):
+            os.environ["TFX_OLS_SOS_STREAMS"] = str(streams)
+            os.environ["TFX_OLS_SOS_PAIRS"] = str(pairs)
+            timed(lambda: E.sos_fft_conv_forward(x, sos, k, (K - 1, 0)), f"fused streams={streams} pairs={pairs}")

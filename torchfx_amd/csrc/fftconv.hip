@@ -17,6 +17,8 @@
 
 #include <rocfft/rocfft.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include <map>
@@ -32,6 +34,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
                        const SosFuseHost *sosf = nullptr);
 bool olsnative_sos_supported(int64_t Ksos, int64_t warm, int64_t K, int64_t Tn, int64_t pl, int64_t pr, int force, int64_t *N_out);
 void sos_plan_info(const double *sos_host, int64_t K, int *precision, int64_t *warmup, double *err_bound);
+int64_t sos_warmup_bits(const double *sos_host, int64_t K, int bits);
 
 // olslds.hip: one launch, the whole 4096-point transform in LDS (K <= 2048 taps, float32 and float64, rows of any length)
 bool olslds_supported(int64_t K, int dtype, int64_t L, int64_t *N_out);
@@ -358,15 +361,30 @@ void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, c
 // `iir-cascade | FIR` as ONE overlap-save pipeline in the reference's arithmetic: the zero-state float64 cascade
 // (_ops.py:119-176 with state None -> iir_cpu.cpp:64-159), its result rounded to float32 (iir.py:84-184, the downcast), then
 // fft_conv1d (_fftconv.py:70-141) -- the cascade runs inside the forward column pass (olsnative.hip), no pass of its own.
+// Warm-up of a row's recursion inside the column pass: the state a row starts from is the true one to 2^-bits of the
+// state's scale (TFX_OLS_SOS_HALO_BITS, default 48 -- 3.6e-15, the round-off a float64 recursion gathers over a 4096-sample
+// row anyway; the stand-alone cascade kernel uses 60).  Cached by coefficient content: the analysis is a few dozen
+// long-double matrix products.
+static int64_t fused_warmup(const double *sos_host, int64_t Ksos)
+{
+    static std::mutex mu;
+    static std::map<std::vector<double>, int64_t> memo;
+    const char *e = getenv("TFX_OLS_SOS_HALO_BITS");
+    const int bits = (e && *e) ? std::max(20, std::min(60, atoi(e))) : 48;
+    std::vector<double> key(sos_host, sos_host + 6 * Ksos);
+    key.push_back((double)bits);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = memo.find(key);
+    if (it != memo.end()) return it->second;
+    if (memo.size() > 256) memo.clear();
+    return memo[key] = sos_warmup_bits(sos_host, Ksos, bits);
+}
+
 bool sos_fft_conv_supported(int64_t T, const double *sos_host, int64_t Ksos, int64_t K, int64_t pad_left, int64_t pad_right, int force)
 {
     if (Ksos < 1 || T <= 0 || K < 1) return false;
-    int prec = 0;
-    int64_t warm = -1;
-    double eb = 0.0;
-    sos_plan_info(sos_host, Ksos, &prec, &warm, &eb);
     int64_t N = 0;
-    return olsnative_sos_supported(Ksos, warm, K, T, pad_left, pad_right, force, &N);
+    return Ksos <= 8 && olsnative_sos_supported(Ksos, fused_warmup(sos_host, Ksos), K, T, pad_left, pad_right, force, &N);
 }
 
 void sos_fft_conv_forward(const float *x, float *y, int64_t C, int64_t T, const double *sos_host, int64_t Ksos,
@@ -381,10 +399,8 @@ void sos_fft_conv_forward(const float *x, float *y, int64_t C, int64_t T, const 
     if (C == 0) return;
     TFX_CHECK(C > 0 && T > 0, "sos_fft_conv_forward: bad shape");
     TFX_CHECK(x && y && kernel_host && sos_host, "sos_fft_conv_forward: null pointer");
-    int prec = 0;
-    int64_t warm = -1, N = 0;
-    double eb = 0.0;
-    sos_plan_info(sos_host, Ksos, &prec, &warm, &eb);
+    int64_t N = 0;
+    const int64_t warm = Ksos <= 8 ? fused_warmup(sos_host, Ksos) : -1;
     TFX_CHECK(olsnative_sos_supported(Ksos, warm, K, T, pad_left, pad_right, force, &N),
               "sos_fft_conv_forward: unsupported here (float32 rows of a multiple of 32 samples, at most 8 sections whose memory "
               "fades within 4096 samples, taps that take the 2^20-point block) -- ask tfx_sos_fft_conv_supported first");

@@ -128,7 +128,7 @@ __device__ __forceinline__ void dft16(cpx (&v)[16])
 // ---------------------------------------------------------------------------------------------
 // PK: the butterflies in packed arithmetic (fftpk.h: a 16-point DFT in 80 vector instructions instead of ~160, a twiddle
 // product in 2 instead of 4); the exchange and its addresses are the same.  TFX_OLS_PK=0 selects the compiler-scheduled form.
-template <bool INV, int NBF, bool PK>
+template <bool INV, int NBF, bool PK, bool LEAN = false>
 __device__ __forceinline__ void col_stages16(cpx (&v)[NBF][16], cpx *lds, const cpx *tw256, int col, int q)
 {
     constexpr int QS = 16 / NBF;               // butterfly j = q + QS * i
@@ -154,11 +154,22 @@ __device__ __forceinline__ void col_stages16(cpx (&v)[NBF][16], cpx *lds, const 
             v2f d[16], w[16];
 #pragma unroll
             for (int t = 0; t < 16; ++t) d[t] = L[(j + 16 * t) * OLS_CB + col];
+            if (LEAN) {                                  // twiddles in four batches: 24 registers less at the peak
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) if (4 * b + t > 0) w[t] = TW[((4 * b + t) * j) & 255];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) if (4 * b + t > 0) d[4 * b + t] = pk::pk_cmul<INV>(d[4 * b + t], w[t]);
+                }
+            } else {
 #pragma unroll
             for (int t = 1; t < 16; ++t) w[t] = TW[(t * j) & 255];
             __builtin_amdgcn_sched_barrier(0);       // all reads are issued before the first product (asm consumers: the scheduler would sink them)
 #pragma unroll
             for (int t = 1; t < 16; ++t) d[t] = pk::pk_cmul<INV>(d[t], w[t]);
+            }
             pk::pk_dft16<INV>(d, Wc, Wr);          // natural-order output row j + 16 k sits at d[PK_DFT16_AT(k)]
 #pragma unroll
             for (int t = 0; t < 16; ++t) v[i][t] = __builtin_bit_cast(cpx, d[t]);
@@ -384,16 +395,19 @@ ols_col_inv16_kernel(const cpx *__restrict__ T, float *__restrict__ y, const cpx
 // reference filters T samples and the FIR pads afterwards).
 // ---------------------------------------------------------------------------------------------
 constexpr int SOSF_MAXK = 8;
+constexpr int SOSF_K4W = 4;                      // up to this many sections the kernel fits 128 registers: two workgroups per CU
+constexpr int SOSF_CH = 16;                      // samples per unrolled stretch of the recursion (bounds the live ranges)
 constexpr int SOSF_LS = 36;                      // floats per line of the stage: conflict-free ds_read_b128 / ds_write_b128 per lane
 constexpr size_t OLS_SHM_SOSF = (size_t)512 * SOSF_LS * sizeof(float) + 256 * sizeof(cpx);
 struct SosFuse {                                 // by value in the kernel arguments: the coefficients are scalar operands
-    double co[SOSF_MAXK][5];                     // b0, b1, b2, -a1, -a2 of each section
+    double co[SOSF_MAXK][5];                     // b0, b1, b2, -a1, -a2 of each section; unit-b0 form: b0_0 ... b0_s, b1 / b0, b2 / b0, -a1, -a2
     double *sections;                            // optional [K, C, T] float64: every section's output (parity tests), or null
     int warm_blocks;                             // warm-up of a row in 32-sample blocks
+    int prio;                                    // the transform / memory phases issue ahead of the recursion (TFX_OLS_SOS_PRIO)
 };
 
-template <int KS, bool TAPS>
-__global__ void __launch_bounds__(512, 2)
+template <int KS, bool TAPS, bool UNIT>
+__global__ void __launch_bounds__(512, ((KS <= SOSF_K4W && !TAPS) ? 4 : 2))
 ols_col_fwd16_sos_kernel(const float *__restrict__ x, cpx *__restrict__ T, const cpx *__restrict__ tw256g,
                          OlsGeom g, int64_t frame0, SosFuse sf)
 {
@@ -409,31 +423,37 @@ ols_col_fwd16_sos_kernel(const float *__restrict__ x, cpx *__restrict__ T, const
     const bool has_b = fb < g.nframes;
     const int64_t cb_ = has_b ? fb / g.F : 0, ib0 = has_b ? (fb % g.F) * g.S - g.pad_left : 0;
     const float *xa = x + ca * g.Tn, *xb = x + cb_ * g.Tn;
-    const int64_t back = (int64_t)OLS_CB * sf.warm_blocks;
+    const int nblk = g.N2 / OLS_CB;
+    // Wave-uniform clock of the walk: `ta` / `tb` = time (sample index in its row) of row 0's first sample of the block being
+    // FETCHED; a line is row r of a frame, r * N2 samples later.  Lines are whole 128-byte lines of the signal or lie entirely
+    // outside [0, T) (aligned frames, T % 32 == 0), so validity is one comparison of the row offset with two scalars.
+    int64_t ta = ia0 - (int64_t)OLS_CB * sf.warm_blocks, tb = ib0 - (int64_t)OLS_CB * sf.warm_blocks;
+    auto bound = [](int64_t v) { return (int)(v < -(int64_t)0x40000000 ? -(int64_t)0x40000000 : (v > (int64_t)0x40000000 ? (int64_t)0x40000000 : v)); };
 
     // recursion side: this thread is line `tid` = (frame tid >> 8, row tid & 255)
     const bool mine_b = tid >= 256;
-    int64_t tl = (mine_b ? ib0 : ia0) + (int64_t)(tid & 255) * g.N2 - back;        // time of the block's first sample
-    const int64_t chan_l = mine_b ? cb_ : ca;
-    const bool lane_on = !mine_b || has_b;
+    const int rel_l = (tid & 255) * g.N2;
     double h1[KS + 1], h2[KS + 1];             // h[0]: input history; h[s + 1]: output history of section s (iir_cpu.cpp:125-130)
 #pragma unroll
     for (int s = 0; s <= KS; ++s) { h1[s] = 0.0; h2[s] = 0.0; }
 
     // loader side: line (tid >> 3) + 64 i, 16-byte part tid & 7;  i < 4: frame a, i >= 4: frame b
     const int lrow = tid >> 3, lpart = tid & 7;
-    int64_t ta = ia0 + (int64_t)lrow * g.N2 - back + 4 * lpart;
-    int64_t tb = ib0 + (int64_t)lrow * g.N2 - back + 4 * lpart;
-    const int64_t rstep = (int64_t)64 * g.N2;
+    const int rel_f = lrow * g.N2 + 4 * lpart;
+    const int rstep = 64 * g.N2;
     float4 P[8];
     auto fetch = [&]() {
+        const float *pa = xa + ta, *pb = xb + tb;            // may point outside the row: dereferenced only where valid
+        const int lo_a = bound(-ta), hi_a = bound(g.Tn - ta), lo_b = bound(-tb), hi_b = has_b ? bound(g.Tn - tb) : lo_b;
+        int rel = rel_f;
+        asm volatile("" : "+v"(rel));                        // offsets are recomputed per block, not kept in sixteen registers
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const bool isb = i >= 4;
-            const int64_t t = (isb ? tb : ta) + (int64_t)(i & 3) * rstep;
-            const float *src = (isb ? xb : xa) + t;
+            const int r = rel + (i & 3) * rstep;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t >= 0 && t < g.Tn && (!isb || has_b)) {          // lines never straddle the row's ends (aligned frames, T % 32 == 0)
+            if (r >= (isb ? lo_b : lo_a) && r < (isb ? hi_b : hi_a)) {
+                const float *src = (isb ? pb : pa) + r;
                 v = (g.nt & 1) ? ldg16_stream<float4>(src) : *(const float4 *)src;
             }
             P[i] = v;
@@ -443,49 +463,69 @@ ols_col_fwd16_sos_kernel(const float *__restrict__ x, cpx *__restrict__ T, const
     fetch();
     cpx *Tp = T + pair * ((int64_t)OLS_N1 * g.P2);
     const int col = tid & 31, q = tid >> 5;
-    for (int blk = -sf.warm_blocks; blk < g.N2 / OLS_CB; ++blk) {
+    for (int blk = -sf.warm_blocks; blk < nblk; ++blk) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) *(float4 *)&S[(lrow + 64 * i) * SOSF_LS + 4 * lpart] = P[i];
-        if (blk + 1 < g.N2 / OLS_CB) fetch();              // in flight while this block is filtered and transformed
+        // the block being filtered is the one fetched last: its clock is one block behind ta / tb
+        const int64_t tcur = (mine_b ? tb : ta) - OLS_CB;
+        const bool live = (!mine_b || has_b) && rel_l >= bound(-tcur) && rel_l < bound(g.Tn - tcur);
+        if (blk + 1 < nblk) fetch();                       // in flight while this block is filtered and transformed
         __syncthreads();
-        float u[OLS_CB];
+        // The recursion is a long stream of independent float64 operations, the transform a short chain of LDS round trips and
+        // barriers: with two workgroups per CU the arbiter (oldest first) lets one workgroup's recursion starve the other's
+        // transform.  sf.prio: the transform and the memory phases issue ahead of the recursion.
+        if (sf.prio) __builtin_amdgcn_s_setprio(0);
+#pragma unroll 1
+        for (int j = 0; j < OLS_CB / SOSF_CH; ++j) {
+            float u[SOSF_CH];
 #pragma unroll
-        for (int j = 0; j < OLS_CB / 4; ++j) {
-            const float4 w4 = *(const float4 *)&S[tid * SOSF_LS + 4 * j];
-            u[4 * j] = w4.x; u[4 * j + 1] = w4.y; u[4 * j + 2] = w4.z; u[4 * j + 3] = w4.w;
-        }
-        const bool live = lane_on && tl >= 0 && tl < g.Tn;     // the whole block is inside the row or outside it
-#pragma unroll
-        for (int n = 0; n < OLS_CB; ++n) {
-            double v = (double)u[n];
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                double yn = sf.co[s][0] * v;
-                yn = __builtin_fma(sf.co[s][1], h1[s], yn);
-                yn = __builtin_fma(sf.co[s][2], h2[s], yn);
-                yn = __builtin_fma(sf.co[s][3], h1[s + 1], yn);
-                yn = __builtin_fma(sf.co[s][4], h2[s + 1], yn);
-                h2[s] = h1[s]; h1[s] = v;
-                v = yn;
-                if (TAPS) { if (live && blk >= 0) sf.sections[((int64_t)s * (g.nframes / g.F) + chan_l) * g.Tn + tl + n] = yn; }
+            for (int i = 0; i < SOSF_CH / 4; ++i) {
+                const float4 w4 = *(const float4 *)&S[tid * SOSF_LS + SOSF_CH * j + 4 * i];
+                u[4 * i] = w4.x; u[4 * i + 1] = w4.y; u[4 * i + 2] = w4.z; u[4 * i + 3] = w4.w;
             }
-            h2[KS] = h1[KS]; h1[KS] = v;
-            u[n] = live ? (float)v : 0.0f;
-        }
-        tl += OLS_CB;
-        if (blk < 0) { __syncthreads(); continue; }           // warm-up block: every line was read, the stage may be refilled
 #pragma unroll
-        for (int j = 0; j < OLS_CB / 4; ++j)
-            *(float4 *)&S[tid * SOSF_LS + 4 * j] = make_float4(u[4 * j], u[4 * j + 1], u[4 * j + 2], u[4 * j + 3]);
+            for (int n = 0; n < SOSF_CH; ++n) {
+                double v = (double)u[n];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    // UNIT: every b0 is pulled out of its section (the recursion is scale-invariant): 4 instead of 5 operations,
+                    // the product of all b0 comes back in one multiply where the sample is rounded
+                    double yn = UNIT ? __builtin_fma(sf.co[s][1], h1[s], v) : __builtin_fma(sf.co[s][1], h1[s], sf.co[s][0] * v);
+                    yn = __builtin_fma(sf.co[s][2], h2[s], yn);
+                    yn = __builtin_fma(sf.co[s][3], h1[s + 1], yn);
+                    yn = __builtin_fma(sf.co[s][4], h2[s + 1], yn);
+                    h2[s] = h1[s]; h1[s] = v;
+                    v = yn;
+                    if (TAPS) {
+                        if (live && blk >= 0)
+                            sf.sections[((int64_t)s * (g.nframes / g.F) + (mine_b ? cb_ : ca)) * g.Tn + tcur + rel_l + SOSF_CH * j + n] =
+                                UNIT ? yn * sf.co[s][0] : yn;
+                    }
+                }
+                h2[KS] = h1[KS]; h1[KS] = v;
+                if (UNIT) v *= sf.co[KS - 1][0];
+                u[n] = live ? (float)v : 0.0f;
+            }
+            if (blk >= 0) {
+#pragma unroll
+                for (int i = 0; i < SOSF_CH / 4; ++i)
+                    *(float4 *)&S[tid * SOSF_LS + SOSF_CH * j + 4 * i] = make_float4(u[4 * i], u[4 * i + 1], u[4 * i + 2], u[4 * i + 3]);
+            }
+        }
+        if (sf.prio) __builtin_amdgcn_s_setprio(3);
+        if (blk < 0) { __syncthreads(); continue; }           // warm-up block: every line was read, the stage may be refilled
         __syncthreads();
         cpx v[1][16];
 #pragma unroll
         for (int t = 0; t < 16; ++t) v[0][t] = make_float2(S[(q + 16 * t) * SOSF_LS + col], S[(256 + q + 16 * t) * SOSF_LS + col]);
         __syncthreads();                                      // the exchange overwrites the stage
-        col_stages16<false, 1, true>(v, lds, tw256, col, q);
-        const int n2 = blk * OLS_CB + col;
+        col_stages16<false, 1, true, true>(v, lds, tw256, col, q);
+        char *Tb = (char *)(Tp + blk * OLS_CB);               // wave-uniform base, 32-bit lane offsets (a pair's workspace is 8 MB)
+        unsigned off = (unsigned)(q * g.P2 + col) * (unsigned)sizeof(cpx);
+        asm volatile("" : "+v"(off));
+        const unsigned ostep = 16u * (unsigned)g.P2 * (unsigned)sizeof(cpx);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) Tp[(int64_t)(q + 16 * k) * g.P2 + n2] = v[0][DFT16_AT(k)];
+        for (int k = 0; k < 16; ++k) { *(cpx *)(Tb + off) = v[0][DFT16_AT(k)]; off += ostep; }
         __syncthreads();                                      // exchange read: the stage may be refilled
     }
 }
@@ -1238,11 +1278,10 @@ static const coli_t coli_tab[2][5] = {
 static const row_t row_tab[8] = {ols_row4096_kernel<0, 0>, ols_row4096_kernel<1, 0>, ols_row4096_kernel<0, 1>, ols_row4096_kernel<1, 1>,
                                  ols_row4096_kernel<0, 2>, ols_row4096_kernel<1, 2>, ols_row4096_kernel<0, 3>, ols_row4096_kernel<1, 3>};
 typedef void (*colsos_t)(const float *, cpx *, const cpx *, OlsGeom, int64_t, SosFuse);
-static const colsos_t colsos_tab[2][SOSF_MAXK] = {
-    {ols_col_fwd16_sos_kernel<1, false>, ols_col_fwd16_sos_kernel<2, false>, ols_col_fwd16_sos_kernel<3, false>, ols_col_fwd16_sos_kernel<4, false>,
-     ols_col_fwd16_sos_kernel<5, false>, ols_col_fwd16_sos_kernel<6, false>, ols_col_fwd16_sos_kernel<7, false>, ols_col_fwd16_sos_kernel<8, false>},
-    {ols_col_fwd16_sos_kernel<1, true>, ols_col_fwd16_sos_kernel<2, true>, ols_col_fwd16_sos_kernel<3, true>, ols_col_fwd16_sos_kernel<4, true>,
-     ols_col_fwd16_sos_kernel<5, true>, ols_col_fwd16_sos_kernel<6, true>, ols_col_fwd16_sos_kernel<7, true>, ols_col_fwd16_sos_kernel<8, true>}};
+#define TFX_SOSF_ROW(TAPS_, UNIT_) {ols_col_fwd16_sos_kernel<1, TAPS_, UNIT_>, ols_col_fwd16_sos_kernel<2, TAPS_, UNIT_>, ols_col_fwd16_sos_kernel<3, TAPS_, UNIT_>, \
+                                    ols_col_fwd16_sos_kernel<4, TAPS_, UNIT_>, ols_col_fwd16_sos_kernel<5, TAPS_, UNIT_>, ols_col_fwd16_sos_kernel<6, TAPS_, UNIT_>, \
+                                    ols_col_fwd16_sos_kernel<7, TAPS_, UNIT_>, ols_col_fwd16_sos_kernel<8, TAPS_, UNIT_>}
+static const colsos_t colsos_tab[4][SOSF_MAXK] = {TFX_SOSF_ROW(false, false), TFX_SOSF_ROW(true, false), TFX_SOSF_ROW(false, true), TFX_SOSF_ROW(true, true)};
 constexpr int MAXL = 8;
 struct Lanes {                      // internal streams and fork/join events of one device
     hipStream_t stream[MAXL] = {};
@@ -1269,7 +1308,7 @@ static void ols_set_attributes(int dev)
             TFX_HIP(hipFuncSetAttribute((const void *)colf_tab[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, (int)OLS_SHM_COL));
             TFX_HIP(hipFuncSetAttribute((const void *)coli_tab[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, (int)OLS_SHM_COL));
         }
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
         for (int b = 0; b < SOSF_MAXK; ++b)
             TFX_HIP(hipFuncSetAttribute((const void *)colsos_tab[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, (int)OLS_SHM_SOSF));
     attr_tab[dev] = true;
@@ -1485,6 +1524,8 @@ bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out)
 // The cascade-in-pass-A form (ols_col_fwd16_sos_kernel): 4096-point rows, aligned frames, a cascade of at most SOSF_MAXK
 // sections whose warm-up fits a row.  `force`: take the 2^20-point block even for rows shorter than one block (tests at
 // fixture size; a one-frame launch).
+bool sos_unit_rows(const double *sos_host, int64_t K, double (*rows)[5]);     // sos.hip
+
 bool olsnative_sos_supported(int64_t Ksos, int64_t warm, int64_t K, int64_t Tn, int64_t pl, int64_t pr, int force, int64_t *N_out)
 {
     if (envi("TFX_OLS_SOS", 1) == 0) return false;
@@ -1558,9 +1599,8 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     // B and C find the slab pass A / B just wrote in the cache instead of in HBM and the whole step gains 8-11 % despite
     // the smaller launches -- cfg 4: 9.4-9.5 ms at 3 x 1 GB, 8.4-8.5 ms at 2 x 64 MB; 48 MB x 3 is as good, 4 lanes or
     // >= 128 MB slabs are not (profiles/r03_experiments.txt).  Default: 64 MB slabs on two lanes.
-    // Cascade in pass A: one workgroup per frame pair lives for a whole frame (204 column blocks), so a launch needs
-    // hundreds of pairs to fill the chip -- slabs of 1 GB on three lanes; the long-lived recursion workgroups of one
-    // lane share the chip with the bandwidth-bound passes B and C of the others.
+    // Cascade in pass A: one workgroup per frame pair lives for a whole frame (~190 column blocks), so a launch needs
+    // hundreds of pairs to fill the chip -- slabs of 320 pairs (2.5 GB) on three lanes (profiles/r05_experiments.txt).
     int nlanes = (int)(sosf ? envi("TFX_OLS_SOS_STREAMS", 3) : envi("TFX_OLS_STREAMS", 2));
     if (nlanes < 1) nlanes = 1;
     if (nlanes > MAXL) nlanes = MAXL;
@@ -1569,7 +1609,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     if (slab <= 0) {
         // The workspace lives outside PyTorch's caching allocator and is kept between calls (scratch(), released by
         // tfx_clear_caches); TFX_OLS_SLAB_MB bounds a lane's share, never more than 1/8 of the free memory over all lanes.
-        int64_t slab_mb = sosf ? envi("TFX_OLS_SOS_SLAB_MB", 1024) : envi("TFX_OLS_SLAB_MB", 64);
+        int64_t slab_mb = sosf ? envi("TFX_OLS_SOS_SLAB_MB", 2560) : envi("TFX_OLS_SLAB_MB", 64);
         {
             // the cap follows the memory free when the device is first used (and again after tfx_clear_caches), not at every call:
             // a driver query per step costs tens of microseconds, is not allowed while a stream is capturing, and would make the
@@ -1610,15 +1650,19 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     tr.mark("function attributes");
     const int ncb = g.N2 / OLS_CB;
     SosFuse sosk{};
+    bool sos_unit = false;
     if (sosf) {
         TFX_CHECK(g.N2 == 4096 && align && !hist && sosf->K >= 1 && sosf->K <= SOSF_MAXK && sosf->warm >= 0,
                   "olsnative_forward: the cascade cannot run inside the column pass here (olsnative_sos_supported)");
-        for (int64_t s = 0; s < sosf->K; ++s) {
+        sos_unit = envi("TFX_OLS_SOS_UNIT_B0", 1) != 0 && sos_unit_rows(sosf->sos, sosf->K, sosk.co);
+        for (int64_t s = 0; s < sosf->K && !sos_unit; ++s) {
             const double *co = sosf->sos + 6 * s;                 // b0 b1 b2 a0 a1 a2; a0 is not used (iir_cpu.cpp:86)
             sosk.co[s][0] = co[0]; sosk.co[s][1] = co[1]; sosk.co[s][2] = co[2]; sosk.co[s][3] = -co[4]; sosk.co[s][4] = -co[5];
         }
         sosk.sections = sosf->sections;
-        sosk.warm_blocks = (int)ceil_div(sosf->warm, OLS_CB);
+        sosk.prio = (int)envi("TFX_OLS_SOS_PRIO", 1);
+        const int64_t warm_dev = envi("TFX_OLS_SOS_WARM", -1);            // development: probe builds of the experiments log (wrong results)
+        sosk.warm_blocks = (int)ceil_div(warm_dev >= 0 ? warm_dev : sosf->warm, OLS_CB);
     }
     // Internal streams (TFX_OLS_STREAMS, default 2), slabs rotate over them: while one slab drains the tail of a pass
     // (the last, partially filled round of workgroups) the other slab's pass fills the idle CUs.
@@ -1643,14 +1687,19 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     }
     tr.mark("lanes, workspaces, fork");
     int64_t slab_idx = 0;
-    for (int64_t p0 = 0; p0 < npairs; p0 += slab, ++slab_idx) {
-        const int64_t np = (npairs - p0 < slab) ? (npairs - p0) : slab;
+    // Cascade in pass A: the lanes would otherwise march in step (all in pass A', then all in B, then all in C) -- the first
+    // slab of lane i is cut to (i + 1) / nlanes of a slab so that the three kinds of pass meet on the chip
+    const int64_t sos_sub = sosf ? envi("TFX_OLS_SOS_SUB_PAIRS", 0) : 0;
+    const int stagger = sosf ? (int)envi("TFX_OLS_SOS_STAGGER", 0) : 0;
+    for (int64_t p0 = 0, step_pairs = slab; p0 < npairs; p0 += step_pairs, ++slab_idx) {
+        step_pairs = (stagger && nlanes > 1 && slab_idx < nlanes) ? std::max<int64_t>(1, slab * (slab_idx + 1) / nlanes) : slab;
+        const int64_t np = (npairs - p0 < step_pairs) ? (npairs - p0) : step_pairs;
         const int ln = nlanes > 1 ? (int)(slab_idx % nlanes) : 0;
         hipStream_t stream = nlanes > 1 ? lane_stream[ln] : user_stream;   // shadows the parameter
         cpx *T = Tlane[ln];
         if (sosf) {
             ProfScope ps("ols_col_fwd16_sos_kernel", stream);
-            hipLaunchKernelGGL(colsos_tab[sosf->sections ? 1 : 0][sosf->K - 1], dim3((unsigned)np), dim3(512), OLS_SHM_SOSF, stream,
+            hipLaunchKernelGGL(colsos_tab[(sosf->sections ? 1 : 0) + (sos_unit ? 2 : 0)][sosf->K - 1], dim3((unsigned)np), dim3(512), OLS_SHM_SOSF, stream,
                                x, T, plan->tw256, g, 2 * p0, sosk);
             TFX_HIP(hipGetLastError());
         } else {
@@ -1658,6 +1707,27 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
             hipLaunchKernelGGL(colf, dim3((unsigned)(np * ncb)), dim3(512 / nbf), shm_col, stream,
                                x, T, plan->tw256, g, 2 * p0);
             TFX_HIP(hipGetLastError());
+        }
+        if (sosf && probe == 0 && sos_sub > 0 && sos_sub < np) {
+            // behind the one wide launch of the recursion pass, passes B and C walk the slab in cache-sized pieces so that pass C
+            // finds what pass B just wrote in the Infinity Cache (the regime of the plain pipeline's 64 MB slabs).  Measured
+            // slower (10.4-10.5 against 9.7-10.2 ms, profiles/r05_experiments.txt): off by default (TFX_OLS_SOS_SUB_PAIRS)
+            for (int64_t q0 = 0; q0 < np; q0 += sos_sub) {
+                const int64_t nq = std::min(sos_sub, np - q0);
+                cpx *Tq = T + q0 * ((int64_t)OLS_N1 * g.P2);
+                {
+                    ProfScope ps("ols_row4096_kernel", stream);
+                    hipLaunchKernelGGL(row_tab[2 * (xch < 0 || xch > 3 ? 3 : xch)], dim3((unsigned)(nq * OLS_N1)), dim3(256), (size_t)(4096 + 256 + 512) * sizeof(cpx), stream,
+                                       Tq, plan->Hp, plan->tw256, plan->t4lo, plan->t4hi, plan->tlo, plan->thi, plan->tu, N - 1, g.P2, nq);
+                    TFX_HIP(hipGetLastError());
+                }
+                {
+                    ProfScope ps("ols_col_inv16_kernel", stream);
+                    hipLaunchKernelGGL(coli, dim3((unsigned)(nq * ncb)), dim3(512 / nbf), shm_col, stream, Tq, y, plan->tw256, g, 2 * (p0 + q0));
+                    TFX_HIP(hipGetLastError());
+                }
+            }
+            continue;
         }
         {
             const int64_t nrows = np * OLS_N1;

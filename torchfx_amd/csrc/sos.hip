@@ -655,7 +655,7 @@ static ld maxabs(const std::vector<ld> &a)
 }
 
 // smallest W (with margin) such that max|A^W| < tol; -1 if not reached within 2^26 samples
-static int64_t warmup_length(const std::vector<double> &sos, int K)
+static int64_t warmup_length(const std::vector<double> &sos, int K, int bits = 60)
 {
     // O(K^3) long-double matrix squarings: beyond ~100 sections the analysis would cost seconds of host
     // time, so such cascades run as one sequential segment per row (exact, just less parallel)
@@ -668,7 +668,7 @@ static int64_t warmup_length(const std::vector<double> &sos, int K)
         cascade_step(sos, K, w);
         for (int i = 0; i < D; ++i) A[(size_t)i * D + j] = w[i];
     }
-    const ld tol = ldexpl(1.0L, -60);
+    const ld tol = ldexpl(1.0L, -bits);
     std::vector<std::vector<ld>> pw;   // A^(2^i)
     pw.push_back(A);
     int m = 0;
@@ -1390,6 +1390,31 @@ void chunk_forward(const float *x, int64_t x_pitch, float *y, int64_t C, int64_t
         else hipLaunchKernelGGL((chunk_iir_fir_kernel<double, false>), dim3((unsigned)C), dim3(threads), shmem, stream, q);
     }
     TFX_HIP(hipGetLastError());
+}
+
+// olsnative.hip (cascade inside the forward column pass): the warm-up for max|A^W| < 2^-bits and the unit-b0 form of a
+// cascade -- rows [G_s = b0_0 ... b0_s, b1 / b0, b2 / b0, -a1, -a2] (quotients in long double) -- or false when the cascade
+// has no such form (unit_form_ok)
+int64_t sos_warmup_bits(const double *sos_host, int64_t K, int bits)
+{
+    const std::vector<double> sos(sos_host, sos_host + 6 * K);
+    return warmup_length(sos, (int)K, bits);
+}
+bool sos_unit_rows(const double *sos_host, int64_t K, double (*rows)[5])
+{
+    const std::vector<double> sos(sos_host, sos_host + 6 * K);
+    if (!unit_form_ok(sos, (int)K)) return false;
+    ld g = 1.0L;
+    for (int64_t s = 0; s < K; ++s) {
+        const ld b0 = sos[s * 6];
+        g *= b0;
+        rows[s][0] = (double)g;
+        rows[s][1] = (double)((ld)sos[s * 6 + 1] / b0);
+        rows[s][2] = (double)((ld)sos[s * 6 + 2] / b0);
+        rows[s][3] = -sos[s * 6 + 4];
+        rows[s][4] = -sos[s * 6 + 5];
+    }
+    return true;
 }
 
 void sos_plan_info(const double *sos_host, int64_t K, int *precision, int64_t *warmup, double *err_bound)
