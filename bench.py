@@ -69,7 +69,7 @@ def build_filters():
     return f1, f2, fir, rev
 
 
-def plan_chain(x: torch.Tensor, fuse_fir: bool | None = None, fuse_spectral: bool | None = None):
+def plan_chain(x: torch.Tensor, fuse_fir: bool | None = None, fuse_spectral: bool | None = None, fuse_recursive: bool | None = None):
     """The product's execution plan for  x | f1 | f2 | fir | rev  (None = the Wave's default policy)."""
     from torchfx_amd import Wave
 
@@ -79,12 +79,17 @@ def plan_chain(x: torch.Tensor, fuse_fir: bool | None = None, fuse_spectral: boo
         w.fuse_fir = fuse_fir
     if fuse_spectral is not None:
         w.fuse_spectral = fuse_spectral
+    if fuse_recursive is not None:
+        w.fuse_recursive = fuse_recursive
     plan = (w | f1 | f2 | fir | rev).plan()
     names = []
     for m in plan:
         taps = getattr(m, "kernel", None)
-        names.append(f"{type(m).__name__}[{m._sos.shape[0]} sections]" if hasattr(m, "_sos") and taps is None
-                     else f"{type(m).__name__}[{taps.numel()} taps, {m._conv_mode}]")
+        if type(m).__name__ == "CascadeFIR":
+            names.append(f"CascadeFIR[{m._sos.shape[0]} sections, float64 recursion inside the column pass | {m.fir.kernel.numel()} taps, fft]")
+        else:
+            names.append(f"{type(m).__name__}[{m._sos.shape[0]} sections]" if hasattr(m, "_sos") and taps is None
+                         else f"{type(m).__name__}[{taps.numel()} taps, {m._conv_mode}]")
     return plan, " | ".join(names)
 
 
@@ -98,7 +103,7 @@ def run_plan(plan, x: torch.Tensor) -> torch.Tensor:
 
 
 def _ols_taps(plan) -> int:
-    return max(int(m.kernel.numel()) for m in plan if hasattr(m, "kernel"))
+    return max(int((m.fir if hasattr(m, "fir") else m).kernel.numel()) for m in plan if hasattr(m, "kernel") or hasattr(m, "fir"))
 
 
 def make_step(workload: str, x: torch.Tensor):
@@ -142,10 +147,16 @@ def make_step(workload: str, x: torch.Tensor):
         return (lambda: (Wave(x, FS, device=x.device) | f1 | f2 | fir | rev).ys), (
             f"cfg5/GPU: (Wave(x) | 4xbiquad | FIR-1024 | FFT-conv-65536).ys, default fusion policy = {names}"), _ols_taps(plan)
     if workload == "chain_iir_kernel":
-        plan, names = plan_chain(x, fuse_fir=True, fuse_spectral=False)
-        return (lambda: run_plan(plan, x)), f"chain with the IIR as its own float64 recursive pass = {names}", _ols_taps(plan)
+        plan, names = plan_chain(x, fuse_fir=True, fuse_spectral=False, fuse_recursive=False)
+        return (lambda: run_plan(plan, x)), f"chain with the IIR as its own float64 recursive pass (round 1-4 staging of the like-for-like plan) = {names}", _ols_taps(plan)
+    if workload == "chain_fold":
+        plan, names = plan_chain(x, fuse_fir=True, fuse_spectral=True)
+        est = getattr(plan[0], "fold_error_estimate", None)
+        make_step.fold_error_estimate = est
+        return (lambda: run_plan(plan, x)), (f"chain with the spectral fold (opt-in, TORCHFX_AMD_FUSE_SPECTRAL=1): the cascade joins the FIR run as its "
+                                            f"impulse response, IIR part in float32 FFT arithmetic = {names}"), _ols_taps(plan)
     if workload == "chain_reference_staging":
-        plan, names = plan_chain(x, fuse_fir=False, fuse_spectral=False)
+        plan, names = plan_chain(x, fuse_fir=False, fuse_spectral=False, fuse_recursive=False)
         return (lambda: run_plan(plan, x)), f"chain staged as the reference stages it (TORCHFX_AMD_FUSION=reference) = {names}", _ols_taps(plan)
     raise SystemExit(f"unknown workload {workload}")
 
@@ -455,7 +466,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="chain",
-                    choices=["chain", "sos", "fir", "fir_fft", "fftconv", "chain_iir_kernel", "chain_reference_staging"])
+                    choices=["chain", "sos", "fir", "fir_fft", "fftconv", "chain_iir_kernel", "chain_fold", "chain_reference_staging"])
     ap.add_argument("--channels", type=int, default=64, help="channels PER GPU (weak scaling)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--total-channels", type=int, default=512, help="fixed batch of --scaling strong (cfg 5)")
@@ -554,15 +565,16 @@ def main() -> None:
     # single stream gives the clean per-kernel numbers
     prof_serial = None
     if extras and chainlike:
-        old_env = os.environ.get("TFX_OLS_STREAMS")
-        os.environ["TFX_OLS_STREAMS"] = "1"
+        old_env = {k: os.environ.get(k) for k in ("TFX_OLS_STREAMS", "TFX_OLS_SOS_STREAMS")}
+        os.environ["TFX_OLS_STREAMS"] = os.environ["TFX_OLS_SOS_STREAMS"] = "1"
         try:
             _, prof_serial, _ = timed_region(step, 2, 1, sync, lib)
         finally:
-            if old_env is None:
-                os.environ.pop("TFX_OLS_STREAMS", None)
-            else:
-                os.environ["TFX_OLS_STREAMS"] = old_env
+            for k, v in old_env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
 
     variants = None
     if extras and args.workload == "chain":
@@ -570,14 +582,17 @@ def main() -> None:
         # recursive pass (round-1 default) and staged exactly like the reference
         variants = {}
         head = out[:, : 4 * FS].clone()
-        for vname in ("chain_iir_kernel", "chain_reference_staging"):
+        for vname in ("chain_fold", "chain_iir_kernel", "chain_reference_staging"):
             try:
                 vstep, vdesc, _ = make_step(vname, x)
-                vms, vgroups, _, vout = batch_timed(vstep, sync, lib, 3, 3)
-                variants[vname] = {"what": vdesc, "ms_per_step": round(vms, 4), "ms_per_step_groups_of_3": vgroups,
+                vel, _, vout = timed_region(vstep, args.steps, 2, sync, lib, profile=False)     # the same region as the headline
+                vms = vel / args.steps * 1e3
+                variants[vname] = {"what": vdesc, "ms_per_step": round(vms, 4), "steps": args.steps,
                                    "Msamples_per_s": round(C * T / vms / 1e3, 1),
                                    "frac_of_8TBps_at_8B_per_sample": round(8.0 * C * T / (vms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                    "max_abs_diff_vs_default_chain_first_4s": float((vout[:, : 4 * FS] - head).abs().max())}
+                if vname == "chain_fold":
+                    variants[vname]["fold_error_estimate"] = getattr(make_step, "fold_error_estimate", None)
                 del vout, vstep
             except Exception as e:
                 variants[vname] = {"error": repr(e)}
@@ -655,6 +670,11 @@ def main() -> None:
             dist.all_reduce(tg, op=dist.ReduceOp.MAX)
             gather_ms = float(tg.item())
 
+    if world > 1 and seen != world:
+        raise SystemExit(f"bench.py: the process group sees {seen} ranks, --gpus says {world}: no line printed")
+    uuids = [d.get("uuid", "") for d in devices]
+    if world > 1 and not share and len(set(uuids)) != world:
+        raise SystemExit(f"bench.py: {world} ranks drive {len(set(uuids))} distinct devices ({sorted(set(uuids))}): no line printed")
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         samples = C * T
@@ -674,6 +694,10 @@ def main() -> None:
                 pairs = (frames + 1) // 2
                 n = info["N"]
                 model["ols_col_fwd16_kernel"] = frames * n * 4.0 + pairs * n * 8.0
+                # the recursion's column pass also reads every row's warm-up (61 of 128 blocks for the cfg-2 cascade at 2^-48)
+                _f = build_filters()
+                wb = -(-max(0, E.sos_fft_conv_warmup(torch.cat([_f[0]._sos, _f[1]._sos]))) // 32)
+                model["ols_col_fwd16_sos_kernel"] = frames * n * 4.0 * (1.0 + min(wb, 128) / 128.0) + pairs * n * 8.0
                 model["ols_col_inv16_kernel"] = pairs * n * 8.0 + 4.0 * samples
                 for nm in ("ols_row_kernel", "ols_row1024_kernel", "ols_row4096_kernel"):
                     model[nm] = pairs * n * 16.0
@@ -733,9 +757,13 @@ def main() -> None:
             roof["frac_is"] = "dominant kernel: algorithmic work of one launch / its average duration (HIP events)"
         roof["step_achieved"] = round(step_ach, 2)
         roof["step_frac"] = round(step_ach / roof["peak"], 4)
+        if args.workload == "chain" and "ols_col_fwd16_sos_kernel" in kernels:
+            # the default plan IS the reference's arithmetic: float64 recursion (inside the forward column pass), float32 overlap-save
+            roof["step_frac_reference_arithmetic"] = roof["step_frac"]
+        if variants and "ms_per_step" in variants.get("chain_fold", {}):
+            roof["step_frac_spectral_fold"] = variants["chain_fold"]["frac_of_8TBps_at_8B_per_sample"]
         if variants and "ms_per_step" in variants.get("chain_iir_kernel", {}):
-            # like-for-like arithmetic with the reference: float64 recursion for the IIR part, then one overlap-save pass
-            roof["step_frac_reference_arithmetic"] = variants["chain_iir_kernel"]["frac_of_8TBps_at_8B_per_sample"]
+            roof["step_frac_iir_as_its_own_pass"] = variants["chain_iir_kernel"]["frac_of_8TBps_at_8B_per_sample"]
         if variants and "ms_per_step" in variants.get("chain_reference_staging", {}):
             roof["step_frac_reference_staging"] = variants["chain_reference_staging"]["frac_of_8TBps_at_8B_per_sample"]
         if dom and prof_serial and dom in prof_serial:
@@ -775,15 +803,19 @@ def main() -> None:
             if kn in kernels:
                 a = alg_gb / (kernels[kn]["ms_per_step"] * 1e-3)
                 roof["iir_kernel"] = {"name": kn, "achieved": round(a, 1), "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4)}
-        dtype = {"chain": "f32 (overlap-save FFT arithmetic for the whole fused chain; f32 I/O)",
+        dtype = {"chain": "f64 (IIR) + f32 (FFT); f32 I/O", "chain_fold": "f32 (overlap-save FFT arithmetic for the whole folded chain); f32 I/O",
                  "chain_iir_kernel": "f64 (IIR) + f32 (FFT); f32 I/O", "chain_reference_staging": "f64 (IIR) + f32 (FFT); f32 I/O",
                  "sos": "f64; f32 I/O", "fir": "f32", "fir_fft": "f32", "fftconv": "f32"}[args.workload]
         if args.workload == "chain" and "sos_stream_kernel<f64>" in kernels:
             dtype = "f64 (IIR) + f32 (FFT); f32 I/O"
         iir_knob = os.environ.get("TORCHFX_AMD_IIR_PRECISION", "f64")
-        if args.workload == "chain" and not any(n.startswith("sos_stream_kernel") for n in kernels):
-            iir_how = ("folded into the f32 overlap-save pass (fuse_spectral: the cascade's 2418-tap impulse response joins the FIR run; "
-                       f"no recursive kernel runs; roofline.step_frac_reference_arithmetic = the chain with the IIR as its own {iir_knob} pass)")
+        if "ols_col_fwd16_sos_kernel" in kernels:
+            iir_how = ("float64 DF1 recursion (iir_cpu.cpp:132-147) in registers inside the overlap-save pipeline's forward column pass "
+                       "(ols_col_fwd16_sos_kernel: one thread per 4096-sample row, warm-up to 2^-48 from zero state), rounded once to float32; "
+                       "every section's output readable through y_sections (tests/test_gpu_sos_ols.py)")
+        elif args.workload.startswith("chain") and not any(n.startswith("sos_stream_kernel") for n in kernels):
+            iir_how = ("folded into the f32 overlap-save pass (fuse_spectral, opt-in: the cascade's impulse response joins the FIR run; "
+                       "no recursive kernel runs)")
         elif args.workload in ("fir", "fir_fft", "fftconv"):
             iir_how = "n/a (no IIR stage)"
         else:
@@ -813,6 +845,7 @@ def main() -> None:
         }
         line["ranks_seen"] = seen                         # all-reduce of ones on the process group (RCCL at N > 1)
         line["devices"] = devices
+        line["distinct_device_uuids"] = len(set(uuids))
         if args.workload == "chain":
             line["end_to_end"] = {
                 "what": "(Wave(x) | f1 | f2 | fir | rev).ys from Python: pipe operators + plan lookup + kernels",

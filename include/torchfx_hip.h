@@ -220,6 +220,8 @@ int tfx_fft_conv_forward_ep(const void *x, void *y, int dtype, int64_t C, int64_
  * ------------------------------------------------------------------------- */
 int tfx_sos_fft_conv_supported(int64_t T, const double *sos_host, int64_t K, int64_t taps,
                                int64_t pad_left, int64_t pad_right, int force_block);
+/* samples a row's recursion starts early from zero state inside the column pass (-1: more than 8 sections / no decay) */
+int64_t tfx_sos_fft_conv_warmup(const double *sos_host, int64_t K);
 int tfx_sos_fft_conv_forward(const float *x, float *y, int64_t C, int64_t T,
                              const double *sos_host, int64_t K,
                              const float *kernel_host, int64_t taps,

@@ -152,11 +152,13 @@ def _staged_oracle_window(xrow, sos, kf, kr, lo, hi):
     return w[:, lo - a:]                                             # exact for lo - a >= need, or a == 0
 
 
-@pytest.mark.parametrize("workload", ["chain", "chain_iir_kernel"])
+@pytest.mark.parametrize("workload", ["chain", "chain_fold", "chain_iir_kernel"])
 def test_cfg5_chain_per_gpu_64ch_600s(workload):
-    """The bench workload at the per-GPU size of cfg 5 (64 ch x 600 s), default plan (the whole chain as one
-    overlap-save pass) and the plan with the IIR as its own float64 pass, against the STAGED oracle (sos ->
-    FIR fft -> IR fft, as the reference runs it) on channels {0, 40, 63}: first 15 s and last 15 s."""
+    """The bench workload at the per-GPU size of cfg 5 (64 ch x 600 s) -- default plan (float64 recursion inside the
+    overlap-save pipeline's column pass), the opt-in spectral fold (the whole chain as one float32 overlap-save pass) and
+    the plan with the IIR as its own float64 pass -- against the STAGED oracle (sos -> FIR fft -> IR fft, as the
+    reference runs it) on channels {0, 40, 63}: first 15 s and last 15 s; for the default plan also every section's
+    output of the kernel that ran (north_star: "IIR compared section-by-section")."""
     from scipy.signal import firwin
     import bench
     C, T = 64, 600 * FS
@@ -176,8 +178,20 @@ def test_cfg5_chain_per_gpu_64ch_600s(workload):
         tail = _staged_oracle_window(xrow, sos, kf, kr, T - n, T)
         assert np.abs(y[c, T - n:].cpu().numpy() - tail[0]).max() <= 1e-5 * scale, (desc, c, "tail")
     # mid-signal: 15 s around the first slab / internal-stream seam that falls inside a row
-    taps = max(int(m.kernel.numel()) for m in bench.plan_chain(x[:1], *({"chain": (None, None), "chain_iir_kernel": (True, False)}[workload]))[0]
-               if hasattr(m, "kernel"))
+    flags = {"chain": {}, "chain_fold": dict(fuse_fir=True, fuse_spectral=True),
+             "chain_iir_kernel": dict(fuse_fir=True, fuse_spectral=False, fuse_recursive=False)}[workload]
+    plan = bench.plan_chain(x[:1], **flags)[0]
+    taps = bench._ols_taps(plan)
+    if workload == "chain":
+        assert [type(m).__name__ for m in plan] == ["CascadeFIR"]
+        y2, sec = plan[0](x[62:64].contiguous(), return_sections=True)          # the same kernel, taps on: two rows
+        assert torch.equal(y2, y[62:64])
+        for c in (0, 1):
+            _, _, _, rs = O.sos_forward(x[62 + c:63 + c, :n].cpu().numpy().astype(np.float64), sos, sections=True)
+            for k in range(sos.shape[0]):
+                d = float(np.abs(sec[k, c, :n].cpu().numpy() - rs[k, 0]).max())
+                assert d <= 2e-11 * max(1.0, float(np.abs(rs[k]).max())), ("section", k, c, d)
+        del sec, y2
     c, mid = _slab_seam(taps, T)
     lo, hi = mid - n // 2, mid + n // 2
     assert 0 < c < C and 0 < lo and hi < T

@@ -44,9 +44,15 @@ def test_cfg5_small_chain_golden_staged_and_fused(golden):
     close(wf.ys, g["yc"], TOL_CONV_F32, "fused chain (merged FIR)")
     wd = (Wave(g["xc"], 48000, device=DEV) | F.LoButterworth(2000, order=6) | F.ParametricEQ(frequency=1000, q=2.0, gain=3.0)
           | F.FIR(firwin(1024, 5000, fs=48000)) | F.FIR(irs))
-    assert (wd.fuse_fir, wd.fuse_spectral) == (True, True)      # default policy: the whole LTI run is one overlap-save pass
-    assert [type(m).__name__ for m in wd.plan()] == ["FIR"]
-    close(wd.ys, g["yc"], TOL_CONV_F32, "default plan (IIR folded into the merged FIR)")
+    # default policy: FIR run merged, the cascade in the reference's float64 arithmetic (rows this short: its own launch)
+    assert (wd.fuse_fir, wd.fuse_spectral, wd.fuse_recursive) == (True, False, True)
+    assert [type(m).__name__ for m in wd.plan()] == ["FusedSOSCascade", "FIR"]
+    close(wd.ys, g["yc"], TOL_CONV_F32, "default plan")
+    wo = Wave(g["xc"], 48000, device=DEV)
+    wo.fuse_spectral = True                                      # opt-in: the whole LTI run as one overlap-save pass
+    wo = (wo | F.LoButterworth(2000, order=6) | F.ParametricEQ(frequency=1000, q=2.0, gain=3.0)
+          | F.FIR(firwin(1024, 5000, fs=48000)) | F.FIR(irs))
+    assert [type(m).__name__ for m in wo.plan()] == ["FIR"]
 
 
 @pytest.mark.parametrize("policy", ["auto", "auto_fold", "fir_only", "reference"])
@@ -65,6 +71,7 @@ def test_chain_with_iir_gain_golden(golden, policy, monkeypatch):
     if policy == "auto_fold":
         monkeypatch.setenv("TFX_OLS_LDS8K_MINK", "0")
         monkeypatch.setenv("TFX_OLS_LDS16K", "0")
+        w.fuse_spectral = True
     elif policy != "auto":
         w.fuse_spectral = False
         w.fuse_fir = policy == "fir_only"
@@ -103,6 +110,7 @@ def test_spectral_fold_targeted_cases(case):
 
     def pipe(xs):
         w = Wave(xs, 48000, device=DEV)
+        w.fuse_spectral = True                                     # the fold is opt-in since round 5; its bound decides here
         for m in members:
             w = w | m
         return w | fir
@@ -123,6 +131,102 @@ def test_spectral_fold_targeted_cases(case):
         b = (Wave(x[:, 150_000:], 48000, device=DEV) | members[0]).ys
         yi = torch.cat([a, b], dim=1)
         close(fir(yi), ref, 1e-5, "chunked " + case)
+
+
+def _raw_sos_class():
+    from torchfx_amd import filter as F
+
+    class RawSOS(F.IIR):
+        """An IIR step around given SOS rows (the fixtures' ill-conditioned designs)."""
+
+        def __init__(self, sos, fs=48000):
+            super().__init__(fs)
+            self._set_sos(sos)
+
+        def compute_coefficients(self):
+            pass
+    return RawSOS
+
+
+def _RawSOS(sos):
+    return _raw_sos_class()(sos)
+
+
+HARD = ["hicheby1_20", "hibutter_20_o5", "lobutter_40_o8", "ellip_o12", "notch_q30", "butter_o20"]
+
+
+@pytest.mark.parametrize("taps", [513, 65536])
+def test_fold_error_bound_on_the_hard_cascades(golden, taps):
+    """every cascade of iir_hard.npz (pole radius up to 0.999, order up to 20) in front of FIR-513 and
+    FIR-65536 through the plan WITH the spectral fold switched on: within 1e-5 of the staged oracle on the device.  Every
+    fold that is taken carries its host-side error estimate (`wave._fold_error_estimate`, limit 2e-6; these cascades
+    measure 2e-10 ... 3e-8: the float32 FFT's error is relative to the output scale, whatever the poles); the ones that
+    are refused here are refused by the impulse-response length guard (notch, Q = 30: 387 028 samples of memory) or by
+    the byte model (a 513-tap FIR does not pay for a 66 574-tap impulse response) and run staged, in the reference's
+    float64 arithmetic.  `test_fold_bound_refuses` checks the bound's own refusal path."""
+    from torchfx_amd import Wave, wave as W
+    from torchfx_amd import filter as F
+    g = golden("iir_hard")
+    T = 400_000 if taps == 513 else 1_200_000
+    x = rnd((2, T), 31)
+    k = (np.random.default_rng(9).standard_normal(taps) * np.exp(-np.arange(taps) / (taps / 8.0)))
+    k = (k / np.abs(k).sum()).astype(np.float32)
+    fir = F.FIR(k)
+    refused, folded = [], []
+    for name in HARD:
+        sos = g[name + "_sos"]
+        half = max(1, sos.shape[0] // 2)
+        if sos.shape[0] < 2:
+            sos = np.vstack([sos, [[1.0, 0, 0, 1, 0, 0]]])
+            half = 1
+        casc = [_RawSOS(sos[:half]), _RawSOS(sos[half:])]         # two IIR steps -> the planner builds (and may fold) the cascade
+        w = Wave(x, 48000, device=DEV)
+        w.fuse_spectral = True
+        w = w | casc[0] | casc[1] | fir
+        plan = w.plan()
+        names = [type(m).__name__ for m in plan]
+        (folded if names == ["FIR"] else refused).append((name, names))
+        if names == ["FIR"]:
+            assert plan[0].fold_error_estimate <= W.FOLD_ERROR_LIMIT
+        ref = O.chain_forward(x[:1], sos, [fir.kernel.numpy().reshape(-1)])
+        scale = max(1.0, float(np.abs(ref).max()))
+        err = float(np.abs(w.ys[:1].cpu().numpy() - ref).max())
+        assert err <= 1e-5 * scale, (name, taps, names, err, scale)
+    assert refused, f"the bound refused nothing at {taps} taps: {folded}"
+
+
+def test_default_plan_runs_the_recursion_inside_the_overlap_save_pass():
+    """`fuse_recursive` (default): planner-built cascade | long FFT FIR on float32 rows of a multiple of 32 samples =
+    ONE CascadeFIR step (tfx_sos_fft_conv_forward); its section taps are the float64 recursion's, its result the staged
+    chain's.  Rows the kernel does not serve keep the two launches."""
+    from torchfx_amd import Wave
+    from torchfx_amd import filter as F
+    T = (1 << 20) + 320_000
+    x = rnd((2, T), 3)
+    f1, f2 = F.LoButterworth(2000, order=6, fs=48000), F.ParametricEQ(frequency=1000, q=2.0, gain=3.0, fs=48000)
+    rev = F.FIR(reverb_ir(65536))
+    fir = F.DesignableFIR(cutoff=5000, num_taps=1024, fs=48000)
+    w = Wave(x, 48000, device=DEV) | f1 | f2 | fir | rev
+    # at this length the pipeline takes the 2^18-point block: two launches
+    assert [type(m).__name__ for m in w.plan()] == ["FusedSOSCascade", "FIR"]
+    xl = rnd((1, 4_200_000 // 32 * 32), 4)
+    wl = Wave(xl, 48000, device=DEV) | f1 | f2 | fir | rev
+    plan = wl.plan()
+    assert [type(m).__name__ for m in plan] == ["CascadeFIR"] and plan[0].fir.kernel.numel() == 1024 + 65536 - 1
+    y = wl.ys
+    sos = np.vstack([f1._sos.numpy(), f2._sos.numpy()])
+    ref = O.chain_forward(xl, sos, [fir.kernel.numpy().reshape(-1), rev.kernel.numpy().reshape(-1)])
+    close(y, ref, TOL_CONV_F32, "default plan, recursion inside pass A")
+    y2, sec = plan[0](dev(xl), return_sections=True)
+    assert torch.equal(y2, y)
+    _, _, _, rs = O.sos_forward(xl.astype(np.float64), sos, sections=True)
+    for s in range(4):
+        close(sec[s], rs[s], TOL_IIR_F64OUT, f"section {s}")
+    # odd length: staged, same numbers to the FIR tolerance
+    xo = xl[:, :-7].copy()
+    wo = Wave(xo, 48000, device=DEV) | f1 | f2 | fir | rev
+    assert [type(m).__name__ for m in wo.plan()] == ["FusedSOSCascade", "FIR"]
+    close(wo.ys, ref[:, :-7], TOL_CONV_F32, "staged at an odd length")
 
 
 def test_module_shapes_dtype_and_state_rules(golden):

@@ -165,15 +165,23 @@ def test_fused_cascade_validation():
 
 
 def test_fusion_policy_defaults(monkeypatch):
-    """auto (default): FIR-run merge and spectral folding on, gain folding opt-in; reference: all off;
+    """auto (default): FIR-run merge and the recursion-inside-the-overlap-save fusion on (both keep the reference's
+    arithmetic), spectral folding (float32 FFT arithmetic for the IIR part) and gain folding opt-in; reference: all off;
     the per-feature variables override either way."""
-    for k in ("TORCHFX_AMD_FUSION", "TORCHFX_AMD_FUSE_FIR", "TORCHFX_AMD_FUSE_SPECTRAL", "TORCHFX_AMD_FUSE_GAIN"):
+    for k in ("TORCHFX_AMD_FUSION", "TORCHFX_AMD_FUSE_FIR", "TORCHFX_AMD_FUSE_SPECTRAL", "TORCHFX_AMD_FUSE_GAIN",
+              "TORCHFX_AMD_FUSE_RECURSIVE"):
         monkeypatch.delenv(k, raising=False)
     w = fx.Wave(torch.zeros(1, 8), 48000)
-    assert (w.fuse_fir, w.fuse_spectral, w.fuse_gain) == (True, True, False)
+    assert (w.fuse_fir, w.fuse_spectral, w.fuse_gain, w.fuse_recursive) == (True, False, False, True)
+    monkeypatch.setenv("TORCHFX_AMD_FUSE_SPECTRAL", "1")
+    assert fx.Wave(torch.zeros(1, 8), 48000).fuse_spectral is True
+    monkeypatch.delenv("TORCHFX_AMD_FUSE_SPECTRAL")
+    monkeypatch.setenv("TORCHFX_AMD_FUSE_RECURSIVE", "0")
+    assert fx.Wave(torch.zeros(1, 8), 48000).fuse_recursive is False
+    monkeypatch.delenv("TORCHFX_AMD_FUSE_RECURSIVE")
     monkeypatch.setenv("TORCHFX_AMD_FUSION", "reference")
     w = fx.Wave(torch.zeros(1, 8), 48000)
-    assert (w.fuse_fir, w.fuse_spectral, w.fuse_gain) == (False, False, False)
+    assert (w.fuse_fir, w.fuse_spectral, w.fuse_gain, w.fuse_recursive) == (False, False, False, False)
     chain = w | F.LoButterworth(2000, order=2) | F.HiButterworth(100, order=2) | F.FIR([0.5, 0.5]) | F.FIR([1.0, -1.0])
     assert [type(m).__name__ for m in chain.plan()] == ["FusedSOSCascade", "FIR", "FIR"]     # wave.py:207-239 staging
     monkeypatch.setenv("TORCHFX_AMD_FUSE_FIR", "1")
@@ -446,6 +454,61 @@ def test_spectral_fusion_matches_staged(oracle_backend, golden):
     assert [type(m).__name__ for m in w.plan()] == ["FusedSOSCascade", "FIR"]
 
 
+def test_fold_bound_refuses(oracle_backend, golden, monkeypatch):
+    """The spectral fold's error bound: the estimate is measured per (cascade, FIR) pair and the fold is dropped when it
+    exceeds the limit -- the cascade then runs in float64 (its own launch, or inside the column pass)."""
+    from torchfx_amd import wave as W
+    g = golden("chain")
+    from scipy.signal import firwin
+    irs = np.random.default_rng(1).standard_normal(4097) * np.exp(-np.arange(4097) / 500.0)
+
+    def pipe():
+        w = fx.Wave(g["xc"], 48000)
+        w.fuse_fir = w.fuse_spectral = True
+        return (w | F.LoButterworth(2000, order=6) | F.ParametricEQ(frequency=1000, q=2.0, gain=3.0)
+                | F.FIR(firwin(1024, 5000, fs=48000)) | F.FIR(irs / np.abs(irs).sum()))
+    W.plan_cache_clear()
+    p = pipe().plan()
+    assert [type(m).__name__ for m in p] == ["FIR"] and 0.0 < p[0].fold_error_estimate <= W.FOLD_ERROR_LIMIT
+    est = p[0].fold_error_estimate
+    W.plan_cache_clear()
+    monkeypatch.setattr(W, "FOLD_ERROR_LIMIT", est / 4)
+    p = pipe().plan()
+    assert [type(m).__name__ for m in p] == ["FusedSOSCascade", "FIR"]
+    assert p[0].fold_refused == pytest.approx(est)
+    close(pipe().ys, g["yc"], 2e-5)
+
+
+def test_default_plan_of_the_headline_chain_is_one_cascade_fir_step():
+    """BASELINE cfg 5's chain at its real row length: planner-built cascade | merged 66 559-tap FIR = one CascadeFIR
+    (the float64 recursion inside the overlap-save pipeline's column pass); the planning queries are host-only."""
+    from torchfx_amd import wave as W
+    from scipy.signal import firwin
+    W.plan_cache_clear()
+    ir = np.random.default_rng(0).standard_normal(65536) * np.exp(-np.arange(65536) / 8000.0)
+    members = (F.LoButterworth(2000, order=6, fs=48000), F.ParametricEQ(frequency=1000, q=2.0, gain=3.0, fs=48000),
+               F.FIR(firwin(1024, 5000, fs=48000)), F.FIR(ir / np.abs(ir).sum()))
+    x = torch.empty((1, 28_800_064), dtype=torch.float32, device="meta")
+
+    def plan(length=28_800_000, **flags):
+        w = fx.Wave.__new__(fx.Wave)
+        w._ys, w.fs, w._device, w.metadata, w._pipeline = x[:, :length], 48000, "meta", {}, list(members)
+        w.fuse_fir, w.fuse_spectral, w.fuse_gain, w.fuse_epilogue, w.fuse_recursive = True, False, False, True, True
+        for k, v in flags.items():
+            setattr(w, k, v)
+        return w.plan()
+    p = plan()
+    assert [type(m).__name__ for m in p] == ["CascadeFIR"] and p[0].fir.kernel.numel() == 66559 and p[0]._sos.shape == (4, 6)
+    assert [type(m).__name__ for m in plan(fuse_recursive=False)] == ["FusedSOSCascade", "FIR"]
+    assert [type(m).__name__ for m in plan(fuse_spectral=True)] == ["FIR"]             # the fold wins when both are on
+    assert [type(m).__name__ for m in plan(length=28_800_001)] == ["FusedSOSCascade", "FIR"]   # not whole 128-byte lines
+    assert [type(m).__name__ for m in plan(length=2_880_000)] == ["FusedSOSCascade", "FIR"]    # 2^18-point blocks there
+    g = fx.effect.Gain(0.5)
+    members = members + (g,)
+    p = plan()
+    assert type(p[0]).__name__ == "Epilogued" and type(p[0].producer).__name__ == "CascadeFIR"
+
+
 def _gain_chain(wave):
     from scipy.signal import firwin
     irg = np.random.default_rng(2).standard_normal(2049) * np.exp(-np.arange(2049) / 300.0)
@@ -453,14 +516,16 @@ def _gain_chain(wave):
             | F.HiButterworth(80, order=2) | F.FIR(firwin(257, 6000, fs=48000)) | F.FIR(8.0 * irg / np.abs(irg).sum()))
 
 
-def test_default_plan_folds_a_cascade_with_gain_into_the_fir_run(oracle_backend, golden, monkeypatch):
+def test_spectral_plan_folds_a_cascade_with_gain_into_the_fir_run(oracle_backend, golden, monkeypatch):
     """Reference output of the staged chain (tests/golden/chain_gain.npz) vs the folded plan, which is a
     single FIR: the 3-filter IIR run as taps, convolved with both FIRs.  The planner prices the fold in HBM bytes
     (`Wave._ols_bytes_per_sample`): the merged 2305-tap FIR alone runs on the one-launch 8192-point kernel at 9.6 B/sample,
     with the cascade's impulse response folded in it would need the three-pass pipeline (~26 B/sample) -- so by default the
     cascade stays its own 8 B/sample pass; without the 8192- and 16 384-point kernels the fold pays."""
     g = golden("chain_gain")
+    monkeypatch.setenv("TORCHFX_AMD_FUSE_SPECTRAL", "1")           # the fold is opt-in since round 5
     w = _gain_chain(fx.Wave(g["x"], 48000))
+    assert w.fuse_spectral
     assert [type(m).__name__ for m in w.plan()] == ["FusedSOSCascade", "FIR"]
     close(w.ys, g["y"], 2e-5)
     monkeypatch.setenv("TFX_OLS_LDS8K_MINK", "0")
@@ -468,6 +533,7 @@ def test_default_plan_folds_a_cascade_with_gain_into_the_fir_run(oracle_backend,
     w = _gain_chain(fx.Wave(g["x"], 48000))
     plan = w.plan()
     assert [type(m).__name__ for m in plan] == ["FIR"] and plan[0].kernel.numel() > 257 + 2049
+    assert 0.0 < plan[0].fold_error_estimate <= fx.wave.FOLD_ERROR_LIMIT        # measured on the host, printed by bench.py
     oracle_backend.calls.clear()
     close(w.ys, g["y"], 2e-5)
     assert [c[0] for c in oracle_backend.calls] == ["fft_conv_forward"]
@@ -586,6 +652,7 @@ def test_plan_cache_hits_and_invalidates():
 
     def plan(members=(f1, f2, fir, rev), length=100_000):
         w = fx.Wave(x[:, :length], 48000)
+        w.fuse_spectral = True                                        # the fold: the plan that derives the most (opt-in)
         for m in members:
             w = w | m
         return w.plan()
@@ -662,7 +729,8 @@ def test_user_held_cascade_and_stateful_fir_stay_staged(oracle_backend):
     held = F.FusedSOSCascade(f1, f2)
     x = torch.from_numpy(np.random.default_rng(1).standard_normal((2, 40_000))).float()
     w = fx.Wave(x, 48000)
-    assert w.fuse_spectral and w.fuse_fir and w.fuse_epilogue          # the default policy
+    assert w.fuse_recursive and w.fuse_fir and w.fuse_epilogue and not w.fuse_spectral      # the default policy
+    w.fuse_spectral = True                                              # ... and with the fold switched on as well
     plan = (w | held | fir).plan()
     assert plan[0] is held and [type(m).__name__ for m in plan] == ["FusedSOSCascade", "FIR"]
     # chunked == one shot through the default plan (state carried on the user's object)

@@ -59,3 +59,41 @@ if "sweep" in what:
             os.environ["TFX_OLS_SOS_STREAMS"] = str(streams)
             os.environ["TFX_OLS_SOS_PAIRS"] = str(pairs)
             timed(lambda: E.sos_fft_conv_forward(x, sos, k, (K - 1, 0)), f"fused streams={streams} pairs={pairs}")
+if "sustained" in what:
+    def burst(fn, n, name):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        print(f"{name:28s} {n:3d} steps back to back: {(time.perf_counter() - t0) * 1e3 / n:7.3f} ms / step", flush=True)
+    def staged2():
+        y, _, _ = E.sos_forward(x, None, sos, None, None)
+        return E.fft_conv_forward(y, k, (K - 1, 0))
+    for n in (5, 20, 60):
+        burst(lambda: E.sos_fft_conv_forward(x, sos, k, (K - 1, 0)), n, "cascade in pass A")
+        burst(staged2, n, "cascade kernel + OLS")
+        burst(lambda: E.fft_conv_forward(x, k, (K - 1, 0)), n, "OLS alone")
+if "wavepath" in what:
+    from scipy.signal import firwin
+    from torchfx_amd import Wave
+    fir = F.FIR(firwin(1024, 5000, fs=48000))
+    rev = F.FIR((lambda ir: (ir / np.abs(ir).sum()).astype(np.float32))(np.random.default_rng(0).standard_normal(65536) * np.exp(-np.arange(65536) / 8000.0)))
+    def burst2(fn, n, name):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+        torch.cuda.synchronize()
+        print(f"{name:44s} {n:3d} steps back to back: {(time.perf_counter() - t0) * 1e3 / n:7.3f} ms / step", flush=True)
+    plan = (Wave(x, 48000, device=x.device) | f1 | f2 | fir | rev).plan()
+    print([type(m).__name__ for m in plan])
+    kk = plan[0].fir.kernel.reshape(-1)
+    for rep in range(2):
+        burst2(lambda: (Wave(x, 48000, device=x.device) | f1 | f2 | fir | rev).ys, 20, "Wave(...).ys")
+        burst2(lambda: plan[0](x), 20, "plan[0](x)")
+        burst2(lambda: E.sos_fft_conv_forward(x, sos, kk, (kk.numel() - 1, 0)), 20, "op, the plan's merged taps")
+        burst2(lambda: E.sos_fft_conv_forward(x, sos, k, (K - 1, 0)), 20, "op, the tool's 66559 taps")
+    xn = torch.randn((C, T), device="cuda"); xn.mul_(1.0 / float(xn.abs().max()))
+    burst2(lambda: E.sos_fft_conv_forward(xn, sos, k, (K - 1, 0)), 20, "op, normal-distributed input")
+    burst2(lambda: E.sos_fft_conv_forward(x, sos, k, (K - 1, 0)), 20, "op, uniform input")

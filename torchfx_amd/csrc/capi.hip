@@ -34,6 +34,7 @@ void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, c
                       int64_t K, int64_t pad_left, int64_t pad_right, hipStream_t stream, const void *hist = nullptr,
                       int64_t H = 0, const Epilogue *ep = nullptr);
 bool sos_fft_conv_supported(int64_t T, const double *sos_host, int64_t Ksos, int64_t K, int64_t pad_left, int64_t pad_right, int force);
+int64_t sos_fft_conv_warmup(const double *sos_host, int64_t Ksos);
 void sos_fft_conv_forward(const float *x, float *y, int64_t C, int64_t T, const double *sos_host, int64_t Ksos,
                           const float *kernel_host, int64_t K, int64_t pad_left, int64_t pad_right, double *sections, int force,
                           const Epilogue *ep, hipStream_t stream);
@@ -234,6 +235,15 @@ int tfx_sos_fft_conv_supported(int64_t T, const double *sos_host, int64_t K, int
         return (sos_host && sos_fft_conv_supported(T, sos_host, K, taps, pad_left, pad_right, force_block)) ? 1 : 0;
     } catch (...) {
         return 0;
+    }
+}
+
+int64_t tfx_sos_fft_conv_warmup(const double *sos_host, int64_t K)
+{
+    try {
+        return sos_host ? sos_fft_conv_warmup(sos_host, K) : -1;
+    } catch (...) {
+        return -1;
     }
 }
 

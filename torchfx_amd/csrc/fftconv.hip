@@ -380,6 +380,8 @@ static int64_t fused_warmup(const double *sos_host, int64_t Ksos)
     return memo[key] = sos_warmup_bits(sos_host, Ksos, bits);
 }
 
+int64_t sos_fft_conv_warmup(const double *sos_host, int64_t Ksos) { return (Ksos >= 1 && Ksos <= 8) ? fused_warmup(sos_host, Ksos) : -1; }
+
 bool sos_fft_conv_supported(int64_t T, const double *sos_host, int64_t Ksos, int64_t K, int64_t pad_left, int64_t pad_right, int force)
 {
     if (Ksos < 1 || T <= 0 || K < 1) return false;

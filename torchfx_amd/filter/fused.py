@@ -87,3 +87,49 @@ class FusedSOSCascade(nn.Module):
     @torch.no_grad()
     def forward(self, x: Tensor, epilogue=None) -> Tensor:
         return self._stream(x, epilogue)
+
+
+class CascadeFIR(nn.Module):
+    """Planner product (``Wave.plan()``, ``fuse_recursive``): a FRESH SOS cascade followed by an FFT-mode FIR, run as ONE
+    overlap-save pipeline in the reference's own arithmetic -- float64 DF1 recursion from zero state
+    (``_ops.py:119-176`` -> ``iir_cpu.cpp:64-159``), the downcast to the signal's float32 (``iir.py:84-184``), then
+    ``fft_conv1d`` (``fir.py:552-555`` -> ``_fftconv.py:70-141``) -- where the recursion runs inside the transform's forward
+    column pass (``tfx_sos_fft_conv_forward``) instead of as a pass over the signal of its own.  Stateless like the
+    ``FusedSOSCascade`` the reference builds per materialisation (``wave.py:221-233``: its state is dropped with it).
+
+    Rows the kernel does not serve (another dtype, a length that is not a multiple of 32, a misaligned view, a host tensor)
+    run the two steps staged -- same arithmetic, two launches."""
+
+    def __init__(self, table: CascadeTable, fir: nn.Module) -> None:
+        super().__init__()
+        self._table, self.fir = table, fir
+        self._planner_built = True
+
+    @property
+    def _sos(self) -> Tensor:
+        return self._table.sos
+
+    @property
+    def fs(self) -> int | None:
+        return self._table.fs
+
+    @torch.no_grad()
+    def forward(self, x: Tensor, epilogue=None, return_sections: bool = False):
+        from torchfx_amd import torchfx_ext
+
+        if x.ndim not in (1, 2, 3):
+            raise ValueError("Input must be of shape [T], [C, T], or [B, C, T]")
+        taps = self.fir.kernel.reshape(-1)
+        k = int(taps.numel())
+        rows = x.reshape(-1, x.shape[-1])
+        if (x.is_cuda and x.dtype == torch.float32 and rows.is_contiguous() and rows.data_ptr() % 16 == 0
+                and torchfx_ext.sos_fft_conv_supported(int(rows.shape[-1]), self._table.sos, k, (k - 1, 0))):
+            out = torchfx_ext.sos_fft_conv_forward(rows, self._table.sos, taps, (k - 1, 0), return_sections=return_sections,
+                                                   epilogue=epilogue)
+            if return_sections:
+                return out[0].reshape(x.shape), out[1]
+            return out.reshape(x.shape)
+        if return_sections:
+            raise RuntimeError("CascadeFIR: section taps come from the fused pass only (float32 rows of a multiple of 32 samples)")
+        y = CascadeStream(self._table)(x)                  # fresh state, like the FusedSOSCascade of one materialisation
+        return self.fir(y, epilogue) if epilogue is not None else self.fir(y)

@@ -33,7 +33,7 @@ from torchfx_amd import native
 
 __all__ = [
     "biquad_forward", "sos_forward", "sos_bank_forward", "sos_bank_sum_forward", "delay_line_forward",
-    "fir_direct_forward", "fft_conv_forward", "sos_fft_conv_forward", "sos_fft_conv_supported", "fir_stream_forward", "chunk_forward", "chunk_supported", "normalize_apply", "Epilogue", "sum_forward", "gain_forward", "quantile_abs", "stat_forward", "normalize_forward",
+    "fir_direct_forward", "fft_conv_forward", "sos_fft_conv_forward", "sos_fft_conv_supported", "sos_fft_conv_warmup", "fir_stream_forward", "chunk_forward", "chunk_supported", "normalize_apply", "Epilogue", "sum_forward", "gain_forward", "quantile_abs", "stat_forward", "normalize_forward",
     "deinterleave_forward", "interleave_forward", "sos_plan_info", "ols_plan_info", "prewarm",
 ]
 
@@ -175,6 +175,12 @@ def sos_fft_conv_supported(T: int, sos, taps: int, padding: tuple[int, int] = (0
     return bool(L.load().tfx_sos_fft_conv_supported(
         ctypes.c_int64(int(T)), s.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.c_int64(s.shape[0]),
         ctypes.c_int64(int(taps)), ctypes.c_int64(int(padding[0])), ctypes.c_int64(int(padding[1])), ctypes.c_int(int(force_block))))
+
+
+def sos_fft_conv_warmup(sos) -> int:
+    """Samples a row's recursion starts early (from zero state) inside the column pass of :func:`sos_fft_conv_forward`."""
+    s = np.ascontiguousarray(_coeff(sos).detach().cpu().numpy(), dtype=np.float64).reshape(-1, 6)
+    return int(L.load().tfx_sos_fft_conv_warmup(s.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.c_int64(s.shape[0])))
 
 
 def sos_fft_conv_forward(x: Tensor, sos, kernel, padding: tuple[int, int] = (0, 0), *, return_sections: bool = False,

@@ -11,11 +11,16 @@ steps), ``__len__`` / ``channels``.  ``from_file`` / ``save`` (:406-576) keep ``
 
 Beyond the reference, the planner merges consecutive FFT-mode ``FIR`` steps into one overlap-save
 pass (``fuse_fir``): convolution is associative, so ``FIR(b1) | FIR(b2)`` == ``FIR(b1 * b2)``; the
-merged taps are computed on the host in float64.  With ``fuse_spectral`` a fresh IIR cascade in front
-of such a run is folded in as well (``_spectral_plan``).  Both are on by default
-(``TORCHFX_AMD_FUSION=auto``) -- results stay within the FIR/FFT tolerance of the reference's staged
-output (``tests/golden/chain*.npz``, 1e-5) -- and off with ``TORCHFX_AMD_FUSION=reference``, which
-stages every step exactly as the reference does.
+merged taps are computed on the host in float64.  A fresh IIR cascade in front of such a run joins it
+in one of two ways.  ``fuse_recursive`` (default): the cascade keeps the reference's arithmetic -- float64
+recursion, one rounding to float32 -- and runs INSIDE the overlap-save pipeline's forward column pass
+(``filter.fused.CascadeFIR`` -> ``tfx_sos_fft_conv_forward``): no pass over the signal of its own, every
+section's output still readable.  ``fuse_spectral`` (opt-in, ``TORCHFX_AMD_FUSE_SPECTRAL=1``): the cascade is
+folded into the FIR run as its impulse response (``_spectral_plan``) -- one pass less again, but the IIR part
+then runs in float32 FFT arithmetic; taken only when a host-side replay bounds the extra error by 2e-6 of the
+output scale (``_fold_error_estimate``).  ``TORCHFX_AMD_FUSION=reference`` stages every step exactly as the
+reference does; under every policy results stay within the FIR/FFT tolerance of the reference's staged
+output (``tests/golden/chain*.npz``, 1e-5).
 
 ``fuse_gain=True`` (env ``TORCHFX_AMD_FUSE_GAIN=1``, also opt-in) folds a clamp-free ``Gain`` into
 the coefficients of the filter run it touches -- scaling is linear, so ``iir | gain | iir`` stays one
@@ -54,8 +59,43 @@ def _fusion_defaults() -> tuple[bool, bool, bool, bool]:
     def flag(name: str, dflt: bool) -> bool:
         v = os.environ.get(name)
         return dflt if v is None or v == "" else v == "1"
-    return (flag("TORCHFX_AMD_FUSE_FIR", auto), flag("TORCHFX_AMD_FUSE_SPECTRAL", auto), flag("TORCHFX_AMD_FUSE_GAIN", False),
+    return (flag("TORCHFX_AMD_FUSE_FIR", auto), flag("TORCHFX_AMD_FUSE_SPECTRAL", False), flag("TORCHFX_AMD_FUSE_GAIN", False),
             flag("TORCHFX_AMD_FUSE_EPILOGUE", auto))
+
+
+def _recursive_default() -> bool:
+    """``fuse_recursive`` of a new ``Wave``: on under ``TORCHFX_AMD_FUSION=auto`` (``TORCHFX_AMD_FUSE_RECURSIVE`` overrides)."""
+    v = os.environ.get("TORCHFX_AMD_FUSE_RECURSIVE")
+    if v is None or v == "":
+        return os.environ.get("TORCHFX_AMD_FUSION", "auto").lower() != "reference"
+    return v == "1"
+
+
+# The spectral fold is taken only when this bound holds (relative to max(1, max|y|) of the replay)
+FOLD_ERROR_LIMIT = 2e-6
+_FOLD_ERR: "OrderedDict[tuple, float]" = OrderedDict()
+
+
+def _fold_error_estimate(sos: np.ndarray, fir_flipped: np.ndarray, merged_flipped: np.ndarray) -> float:
+    """What folding a cascade into the FIR run costs in accuracy, measured on the host once per (cascade, FIR) pair:
+    2^16 pseudo-random samples through (a) the reference's staging -- float64 recursion, rounded to float32, float64
+    convolution with the float32 taps -- and (b) the folded form as the device runs it -- the merged taps rounded to
+    float32, one float32 FFT convolution (numpy's single-precision FFT; block length >= taps + 2^16, the device's
+    2^16 ... 2^20-point blocks behave alike: the error grows with log N).  Returns 2 x max|a - b| / max(1, max|a|)."""
+    import scipy.signal as sg
+
+    n = 1 << 16
+    x = np.random.default_rng(20240605).uniform(-1.0, 1.0, n).astype(np.float32)
+    y_iir = sg.sosfilt(sos, x.astype(np.float64)).astype(np.float32)
+    h_fir = fir_flipped[::-1].astype(np.float32).astype(np.float64)
+    ref = sg.fftconvolve(y_iir.astype(np.float64), h_fir)[:n]
+    h = merged_flipped[::-1].astype(np.float32)
+    nfft = 1 << int(np.ceil(np.log2(n + h.size)))
+    xf = np.zeros(nfft, np.float32); xf[:n] = x
+    hf = np.zeros(nfft, np.float32); hf[:h.size] = h
+    got = np.fft.irfft(np.fft.rfft(xf) * np.fft.rfft(hf), nfft)[:n]
+    assert got.dtype == np.float32, "numpy >= 2.0: single-precision FFT"
+    return 2.0 * float(np.abs(got.astype(np.float64) - ref).max()) / max(1.0, float(np.abs(ref).max()))
 
 
 def _planner_fir(taps_flipped64: np.ndarray) -> nn.Module:
@@ -166,6 +206,7 @@ def plan_cache_clear() -> None:
         _PLANS.clear()
         _MERGED.clear()
         _IIR_FIR.clear()
+        _FOLD_ERR.clear()
 
 
 def _member_key(m: nn.Module, guard: list) -> tuple:
@@ -204,6 +245,8 @@ def _instantiate(cached: list) -> list:
         if getattr(m, "_planner_built", False) and isinstance(m, FusedSOSCascade):
             c = FusedSOSCascade.from_table(m._stream.table)
             c._planner_built = True
+            if hasattr(m, "fold_refused"):
+                c.fold_refused = m.fold_refused
             return c
         if isinstance(m, Epilogued) and getattr(m.producer, "_planner_built", False):
             return Epilogued(fresh(m.producer), m.gain, m.norm)
@@ -231,6 +274,7 @@ class Wave:
         self._ys = ys if isinstance(ys, Tensor) else Tensor(ys)   # Tensor(ys): float32, as wave.py:137
         self.metadata = metadata or {}
         self.fuse_fir, self.fuse_spectral, self.fuse_gain, self.fuse_epilogue = _fusion_defaults()
+        self.fuse_recursive = _recursive_default()
         self.to(device)
 
     # ------------------------------------------------------------------ lazy data
@@ -248,7 +292,7 @@ class Wave:
         """The fused execution plan of the pending pipeline (``wave.py:216-233``), from the plan cache when
         this pipeline -- same members, same coefficients, same flags, same row length -- was planned before."""
         flags = (self.fuse_fir, getattr(self, "fuse_spectral", False), getattr(self, "fuse_gain", False),
-                 getattr(self, "fuse_epilogue", False))
+                 getattr(self, "fuse_epilogue", False), getattr(self, "fuse_recursive", False))
         length = int(self._ys.shape[-1]) if self._ys.dim() else 0
         dtype = self._ys.dtype                       # the overlap-save path (and so the fold decision) depends on it
         guard: list = []
@@ -338,6 +382,8 @@ class Wave:
         plan.extend(lead)
         if getattr(self, "fuse_spectral", False):
             plan = self._spectral_plan(plan, length, dtype)
+        if getattr(self, "fuse_recursive", False):
+            plan = self._recursive_plan(plan, length, dtype)
         if getattr(self, "fuse_epilogue", False):
             plan = self._epilogue_plan(plan)
         return plan
@@ -351,14 +397,14 @@ class Wave:
         from torchfx_amd.effect import Epilogued, Gain, Normalize
         from torchfx_amd.filter.biquad import Biquad
         from torchfx_amd.filter.fir import FIR
-        from torchfx_amd.filter.fused import FusedSOSCascade
+        from torchfx_amd.filter.fused import CascadeFIR, FusedSOSCascade
         from torchfx_amd.filter.iir import IIR
 
         out: list[nn.Module] = []
         i = 0
         while i < len(plan):
             m = plan[i]
-            producer = isinstance(m, (IIR, Biquad, FusedSOSCascade)) or (_plain_fir(m) and m._conv_mode != "direct")
+            producer = isinstance(m, (IIR, Biquad, FusedSOSCascade, CascadeFIR)) or (_plain_fir(m) and m._conv_mode != "direct")
             gain = norm = None
             j = i + 1
             if producer and j < len(plan) and isinstance(plan[j], Gain):
@@ -414,9 +460,52 @@ class Wave:
                     except RuntimeError:          # signal shorter than the taps: nothing to gain
                         pays = False
                     if pays:
-                        out.append(_merge_fir_run([eq, nxt]))
-                        i += 2
-                        continue
+                        merged = _merge_fir_run([eq, nxt])
+                        # ... and only when the float32 FFT arithmetic the IIR part then runs in is measured to be harmless
+                        ek = (m._sos.numpy().tobytes(), id(nxt.kernel), nxt.kernel._version)
+                        err = _lru_get(_FOLD_ERR, ek)
+                        if err is None:
+                            err = _fold_error_estimate(m._sos.numpy(), nxt.kernel.detach().cpu().reshape(-1).numpy().astype(np.float64),
+                                                       merged.kernel.detach().cpu().reshape(-1).numpy())
+                            _lru_put(_FOLD_ERR, ek, (err, nxt.kernel))
+                        else:
+                            err = err[0]
+                        if err <= FOLD_ERROR_LIMIT:
+                            merged.fold_error_estimate = err
+                            out.append(merged)
+                            i += 2
+                            continue
+                        m.fold_refused = err                  # staged (or run inside the column pass): the plan shows why
+            out.append(m)
+            i += 1
+        return out
+
+    @staticmethod
+    def _recursive_plan(plan: list[nn.Module], length: int = 0, dtype: torch.dtype = torch.float32) -> list[nn.Module]:
+        """``fuse_recursive``: a cascade the planner built itself (fresh, zero state, dropped after the
+        materialisation -- ``wave.py:221-233``) followed by an FFT-mode FIR runs as ONE overlap-save pipeline
+        with the float64 recursion inside the forward column pass (``filter.fused.CascadeFIR``): the reference's
+        arithmetic, one pass over the signal less.  Only where the kernel serves the geometry
+        (``torchfx_ext.sos_fft_conv_supported``: float32 rows of a multiple of 32 samples, <= 8 sections whose memory
+        fades within a 4096-sample row, taps long enough for the 2^20-point block); a lone IIR step, a user-held
+        ``FusedSOSCascade`` (stateful across waves) and direct-mode FIRs stay staged."""
+        from torchfx_amd import torchfx_ext
+        from torchfx_amd.filter.fused import CascadeFIR, FusedSOSCascade
+
+        if dtype != torch.float32 or length <= 0:
+            return plan
+        out: list[nn.Module] = []
+        i = 0
+        while i < len(plan):
+            m = plan[i]
+            nxt = plan[i + 1] if i + 1 < len(plan) else None
+            if (isinstance(m, FusedSOSCascade) and getattr(m, "_planner_built", False) and m._state_x is None
+                    and _plain_fir(nxt) and nxt._conv_mode != "direct"):
+                k = int(nxt.kernel.numel())
+                if torchfx_ext.sos_fft_conv_supported(length, m._sos, k, (k - 1, 0)):
+                    out.append(CascadeFIR(m._stream.table, nxt))
+                    i += 2
+                    continue
             out.append(m)
             i += 1
         return out
@@ -433,12 +522,13 @@ class Wave:
     @classmethod
     def _deferred(cls, ys: Tensor, fs: int, device, metadata, pipeline: list[nn.Module],
                   fuse_fir: bool = False, fuse_spectral: bool = False, fuse_gain: bool = False,
-                  fuse_epilogue: bool = False) -> "Wave":
+                  fuse_epilogue: bool = False, fuse_recursive: bool = False) -> "Wave":
         w = object.__new__(cls)
         w._ys, w.fs, w._device, w.metadata, w._pipeline, w.fuse_fir = ys, fs, device, metadata, pipeline, fuse_fir
         w.fuse_spectral = fuse_spectral
         w.fuse_gain = fuse_gain
         w.fuse_epilogue = fuse_epilogue
+        w.fuse_recursive = fuse_recursive
         return w
 
     # ------------------------------------------------------------------ device
@@ -469,7 +559,8 @@ class Wave:
         steps = list(f.children()) if isinstance(f, nn.Sequential) else [f]
         return Wave._deferred(self._ys, self.fs, self._device, self.metadata,
                               self._pipeline + steps, self.fuse_fir, getattr(self, "fuse_spectral", False),
-                              getattr(self, "fuse_gain", False), getattr(self, "fuse_epilogue", False))
+                              getattr(self, "fuse_gain", False), getattr(self, "fuse_epilogue", False),
+                              getattr(self, "fuse_recursive", False))
 
     # ------------------------------------------------------------------ files
     _SUBTYPE_BY_ENCODING = {"PCM_S": lambda b: f"PCM_{b}", "PCM_U": lambda b: "PCM_U8" if b == 8 else f"PCM_{b}",
@@ -502,6 +593,7 @@ class Wave:
             w._ys = _io.upload_interleaved(data_np, device)
             w.fs, w._device, w.metadata, w._pipeline = fs, device, metadata, []
             w.fuse_fir, w.fuse_spectral, w.fuse_gain, w.fuse_epilogue = _fusion_defaults()
+            w.fuse_recursive = _recursive_default()
             return w
         return cls(torch.from_numpy(np.ascontiguousarray(data_np.T)), fs, metadata=metadata)
 
