@@ -567,6 +567,7 @@ def main() -> None:
     if extras and chainlike:
         old_env = {k: os.environ.get(k) for k in ("TFX_OLS_STREAMS", "TFX_OLS_SOS_STREAMS")}
         os.environ["TFX_OLS_STREAMS"] = os.environ["TFX_OLS_SOS_STREAMS"] = "1"
+        lib.tfx_env_reload()               # the library reads its knobs once per process
         try:
             _, prof_serial, _ = timed_region(step, 2, 1, sync, lib)
         finally:
@@ -575,6 +576,7 @@ def main() -> None:
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
+            lib.tfx_env_reload()
 
     variants = None
     if extras and args.workload == "chain":

@@ -297,6 +297,10 @@ int tfx_ols_plan_info2(int64_t K, int64_t T, int64_t pad_left, int64_t pad_right
  * host work of its own before its first call (the Python planner merges taps, src/torchfx/wave.py:207-239 is the
  * reference's counterpart) overlaps the two.  No reference counterpart; needs a device. */
 int tfx_prewarm(void);
+/* TFX_* tuning knobs are read from the environment ONCE per process (a dispatch asks for about ten of them); a process
+ * that changes them at run time calls this afterwards -- or sets TFX_ENV_DYNAMIC=1 before the first call, which makes
+ * every lookup a fresh getenv (the test suite does). */
+int tfx_env_reload(void);
 
 /* ---------------------------------------------------------------------------
  * tfx_delay_line_forward -- kept because the reference extension exports it

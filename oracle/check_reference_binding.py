@@ -9,10 +9,12 @@ imports the REAL reference package from /root/reference/src and checks that
      path as available (``is_native_available``, tests/test_ops_dispatch.py:20-35 of the reference);
   2. the three entry points the reference calls exist with the reference's argument names, in its order
      (binding.cpp:83-96) -- read from the docstrings pybind11 generates;
-  3. the reference's own call sequences reach our C++: ``_ops.parallel_iir_forward`` / ``_ops.biquad_forward`` /
-     ``_ops.delay_line_forward`` and ``IIR.forward`` through ``filter/iir.py::_sos_cascade_forward`` on HOST tensors end
-     in our explicit "no CPU path" RuntimeError (there is no GPU in the build container; on a device tensor the same
-     calls are what tests/test_gpu_boundary.py makes on the GPU box, against fixtures generated from the reference).
+  3. the reference's own call sequences run THROUGH our C++ on host tensors -- the module dispatches on ``x.is_cuda()``
+     like ``binding.cpp:30-81``, its host branch is ``torchfx_amd/csrc/ext/host_branch.h`` -- and give the reference's
+     numbers: BASELINE.json's cfg 1 literally (``LoButterworth(1000, order=4, fs=48000)`` on ``iir_cfg1.npz``: the
+     float32 output bit for bit), the cfg-2 cascade section by section (``iir_cfg2_sections.npz``), the reference's
+     ``Wave | iir | iir`` pipe, ``_ops.biquad_forward`` and ``_ops.delay_line_forward`` against closed forms.  (On a
+     device tensor the same calls are what tests/test_gpu_boundary.py makes on the GPU box.)
 
 Nothing of the reference is copied; nothing here runs on the GPU box (/root/reference does not exist there).
 Exit code 0 = all checks passed.
@@ -55,24 +57,46 @@ def main() -> int:
         sig = doc.splitlines()[0]
         got = [a.split(":")[0].strip() for a in sig[sig.index("(") + 1: sig.index(")")].split(",")]
         assert got == args, (name, got)
-    x = torch.randn(2, 256)
-    sos = torch.tensor([[0.2, 0.4, 0.2, 1.0, -0.3, 0.1], [1.0, 0.0, 0.0, 1.0, 0.0, 0.0]], dtype=torch.float64)
-    calls = {
-        "_ops.parallel_iir_forward": lambda: _ops.parallel_iir_forward(x, sos, None, None),
-        "_ops.biquad_forward": lambda: _ops.biquad_forward(x, sos[0, :3], sos[0, 3:], None, None),
-        "_ops.delay_line_forward": lambda: _ops.delay_line_forward(x, 10, 0.5, 0.3),
-        "IIR.forward": lambda: F.LoButterworth(1000, order=4, fs=48000)(x),
-        "Wave | iir | iir": lambda: (torchfx.Wave(x, 48000) | F.LoButterworth(1000, order=4) | F.HiButterworth(100, order=2)).ys,
-    }
-    for what, fn in calls.items():
-        try:
-            fn()
-        except RuntimeError as e:
-            assert "no CPU path" in str(e), (what, str(e))
-            print(f"  {what}: reached the HIP module ({str(e).splitlines()[0][:90]} ...)")
-        else:
-            raise AssertionError(f"{what}: did not reach the HIP module")
-    print("check_reference_binding: ok -- the reference package binds to torchfx_amd/native/torchfx_ext and its call paths end in it")
+    import numpy as np
+    import scipy.signal as sg
+
+    gold = os.path.join(ROOT, "tests", "golden")
+    g1 = np.load(os.path.join(gold, "iir_cfg1.npz"))
+    g2 = np.load(os.path.join(gold, "iir_cfg2_sections.npz"))
+
+    def err(a, b):
+        return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max())
+    # cfg 1 of BASELINE.json: the reference's own module class, its forward, our C++ underneath
+    f = F.LoButterworth(1000, order=4, fs=48000)
+    y = f(torch.from_numpy(g1["x"]))
+    assert y.dtype == torch.float32 and np.array_equal(y.numpy(), g1["y"]), err(y.numpy(), g1["y"])
+    print("  IIR.forward (cfg 1, LoButterworth order 4, 1 x 48000): bit-identical to the reference fixture")
+    # the cfg-2 cascade, every section, through the reference's public op (_ops.py:119-176)
+    cur = torch.from_numpy(g2["x"]).double()
+    sos2 = torch.from_numpy(g2["sos"])
+    for k in range(sos2.shape[0]):
+        cur, _, _ = _ops.parallel_iir_forward(cur, sos2[k:k + 1], None, None)
+        e = err(cur.numpy(), g2["y_sections"][k])
+        assert e <= 2e-11 * max(1.0, float(np.abs(g2["y_sections"][k]).max())), (k, e)
+    yf, sx, sy = _ops.parallel_iir_forward(torch.from_numpy(g2["x"]), sos2, None, None)
+    assert err(yf.numpy(), g2["y_sections"][-1]) <= 2e-11 and err(sx.numpy(), g2["state_x"]) <= 2e-10 and err(sy.numpy(), g2["state_y"]) <= 2e-10
+    print("  _ops.parallel_iir_forward (cfg-2 cascade): every section within 2e-11 of the fixture, states within 2e-10")
+    # the reference's pipe: Wave | iir | iir  (wave.py:207-239 -> FusedSOSCascade -> our module)
+    x = torch.from_numpy(g2["x"])
+    f1, f2 = F.LoButterworth(2000, order=6), F.ParametricEQ(frequency=1000, q=2.0, gain=3.0)
+    yw = (torchfx.Wave(x, 48000) | f1 | f2).ys
+    assert yw.dtype == torch.float32 and np.array_equal(yw.numpy(), g2["y"]), err(yw.numpy(), g2["y"])
+    print("  Wave | LoButterworth-6 | ParametricEQ (cfg 2's chain): bit-identical to the reference fixture")
+    # the other two entry points against closed forms
+    xr = torch.randn(3, 4000, dtype=torch.float64)
+    b, a = sg.butter(2, 0.2)
+    yb, _, _ = _ops.biquad_forward(xr, torch.from_numpy(b), torch.from_numpy(a), None, None)
+    assert err(yb.numpy(), sg.lfilter(b, a, xr.numpy(), axis=-1)) <= 1e-12
+    yd = _ops.delay_line_forward(xr.float(), 100, 0.5, 0.3)
+    ex = xr.float().clone(); ex[:, 100:] += 0.15 * xr.float()[:, :-100]
+    assert err(yd.numpy(), ex.numpy()) <= 1e-6 and _ops.delay_line_forward(xr[:, :50], 100, 0.5, 0.3).shape == (3, 50)
+    print("  _ops.biquad_forward == scipy.lfilter (1e-12), _ops.delay_line_forward == x + mix*decay*x[n-D]")
+    print("check_reference_binding: ok -- the reference package binds to torchfx_amd/native/torchfx_ext and computes through it")
     return 0
 
 

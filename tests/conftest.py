@@ -4,6 +4,7 @@ import sys
 import numpy as np
 import pytest
 
+os.environ.setdefault("TFX_ENV_DYNAMIC", "1")      # tests flip TFX_* knobs inside one process: the library re-reads them per call
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

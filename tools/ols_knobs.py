@@ -2,6 +2,7 @@
 usage: python tools/ols_knobs.py "A=1,B=2" "A=0" ...   ('' = defaults).  Each set is timed on one
 internal stream (clean per-kernel times) and with the default two streams (wall)."""
 import os
+os.environ.setdefault("TFX_ENV_DYNAMIC", "1")      # this tool flips TFX_* knobs inside one process
 import sys
 
 import numpy as np

@@ -1,5 +1,6 @@
 """Developer sweep: cfg-4 overlap-save wall time over (slab MB, internal streams).  usage: python tools/ols_stream_sweep.py"""
 import os
+os.environ.setdefault("TFX_ENV_DYNAMIC", "1")      # this tool flips TFX_* knobs inside one process
 import sys
 import time
 

@@ -3,6 +3,7 @@ library's own HIP-event profiler, sweeping the tuning knobs exposed as env vars.
 import ctypes
 import json
 import os
+os.environ.setdefault("TFX_ENV_DYNAMIC", "1")      # this tool flips TFX_* knobs inside one process
 import sys
 import time
 

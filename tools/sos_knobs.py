@@ -1,6 +1,7 @@
 """Developer sweep: the cascade kernel (cfg-2 filter) under sets of env knobs, float64 and float32 arithmetic, 64 x 2.88 M (cfg 2)
 and 64 x 28.8 M.  usage: python tools/sos_knobs.py "A=1,B=2" "A=0" ...   ('' = defaults)."""
 import os
+os.environ.setdefault("TFX_ENV_DYNAMIC", "1")      # this tool flips TFX_* knobs inside one process
 import sys
 
 import torch

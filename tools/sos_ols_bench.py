@@ -2,6 +2,7 @@
 (tfx_sos_fft_conv_forward) against the staged cascade kernel + overlap-save and the float32 spectral fold.
 Knobs through the environment (TFX_OLS_SOS_PAIRS / _STREAMS / _SLAB_MB ...).  usage: python tools/sos_ols_bench.py [reps] [what]"""
 import os
+os.environ.setdefault("TFX_ENV_DYNAMIC", "1")      # this tool flips TFX_* knobs inside one process
 import sys
 import time
 

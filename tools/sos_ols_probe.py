@@ -4,6 +4,7 @@ usage: python tools/sos_ols_probe.py"""
 import ctypes
 import json
 import os
+os.environ.setdefault("TFX_ENV_DYNAMIC", "1")      # this tool flips TFX_* knobs inside one process
 import sys
 
 import numpy as np

@@ -1,5 +1,6 @@
 """Second sweep of the cascade-in-pass-A chain step: staggered lanes on / off x lanes x pairs per slab (wall clock)."""
 import os, sys, time
+os.environ.setdefault("TFX_ENV_DYNAMIC", "1")      # this tool flips TFX_* knobs inside one process
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from torchfx_amd import torchfx_ext as E

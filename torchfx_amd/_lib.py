@@ -54,6 +54,7 @@ SIGNATURES = {
     "tfx_ols_plan_info2": (_int, [_i64, _i64, _i64, _i64, _int, ctypes.POINTER(_i64), ctypes.POINTER(_i64),
                                   ctypes.POINTER(_i64), ctypes.POINTER(_int)]),
     "tfx_prewarm": (_int, []),
+    "tfx_env_reload": (_int, []),
     "tfx_delay_line_forward": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _dbl, _dbl, _vp]),
     "tfx_sum_forward": (_int, [_vp, _int, _vp, _int, _i64, _vp]),
     "tfx_gain_forward": (_int, [_vp, _vp, _int, _i64, _dbl, _int, _vp]),

@@ -62,6 +62,56 @@ void interleave_forward(const float *in, float *out, int64_t F, int64_t C, int64
                         hipStream_t stream);
 int64_t fftconv_block_size(int64_t K, int64_t L);
 
+// ---- environment knobs, read once --------------------------------------------------------------
+namespace {
+struct EnvTable {
+    std::mutex mu;
+    std::map<const void *, std::pair<bool, int64_t>> by_ptr;      // literal address -> (set, value)
+    std::map<std::string, std::pair<bool, int64_t>> by_name;
+    bool dynamic = false;
+    EnvTable()
+    {
+        const char *e = getenv("TFX_ENV_DYNAMIC");
+        dynamic = e && *e && *e != '0';
+    }
+};
+EnvTable &env_table()
+{
+    static EnvTable t;
+    return t;
+}
+}  // namespace
+
+int64_t env_i64(const char *name, int64_t dflt)
+{
+    EnvTable &t = env_table();
+    if (t.dynamic) {
+        const char *e = getenv(name);
+        return (e && *e) ? atoll(e) : dflt;
+    }
+    std::lock_guard<std::mutex> lk(t.mu);
+    auto it = t.by_ptr.find((const void *)name);
+    if (it == t.by_ptr.end()) {
+        auto in = t.by_name.find(name);
+        if (in == t.by_name.end()) {
+            const char *e = getenv(name);
+            in = t.by_name.emplace(name, std::make_pair(e && *e, (e && *e) ? (int64_t)atoll(e) : (int64_t)0)).first;
+        }
+        it = t.by_ptr.emplace((const void *)name, in->second).first;
+    }
+    return it->second.first ? it->second.second : dflt;
+}
+
+void env_reload()
+{
+    EnvTable &t = env_table();
+    std::lock_guard<std::mutex> lk(t.mu);
+    t.by_ptr.clear();
+    t.by_name.clear();
+    const char *e = getenv("TFX_ENV_DYNAMIC");
+    t.dynamic = e && *e && *e != '0';
+}
+
 // ---- errors ------------------------------------------------------------------------------------
 static thread_local std::string t_last_error;
 void set_last_error(const std::string &msg) { t_last_error = msg; }
@@ -407,6 +457,13 @@ int tfx_ols_plan_info2(int64_t K, int64_t T, int64_t pad_left, int64_t pad_right
 {
     TFX_API_BEGIN
     ols_plan(K, T, pad_left, pad_right, dtype, N, S, F, path);
+    TFX_API_END
+}
+
+int tfx_env_reload(void)
+{
+    TFX_API_BEGIN
+    env_reload();
     TFX_API_END
 }
 

@@ -64,6 +64,14 @@ void scratch_clear();
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ---- tuning knobs from the environment (TFX_*) --------------------------------------------------
+// Read ONCE per process and name (capi.hip): a dispatch asks for about ten of them and a short-row call lasts 8-30 us.
+// `name` must be a string literal (the table is keyed by its address first, by its text on a miss).  Development and
+// tests change knobs inside one process: TFX_ENV_DYNAMIC=1 (read when the library is first used) makes every lookup a
+// fresh getenv, and tfx_env_reload() drops the table.
+int64_t env_i64(const char *name, int64_t dflt);
+void env_reload();
+
 // Streaming (nontemporal) 16-byte global accesses for data a pass touches exactly once: a linear float32 sweep runs at
 // 6.80 instead of 6.29 TB/s with them on MI355X (tools/ubench/stream_copy2.hip, profiles/r03_experiments.txt).
 typedef unsigned tfx_u32x4 __attribute__((ext_vector_type(4)));

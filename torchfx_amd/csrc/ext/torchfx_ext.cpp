@@ -10,8 +10,10 @@
 // extern "C" ABI of libtorchfx_hip.so (include/torchfx_hip.h) is called -- the C ABI stays the one
 // boundary non-torch hosts and this module share.
 //
-// There is no CPU path: the ops are registered for the CUDA dispatch key only (= ROCm device tensors
-// in a ROCm build of PyTorch) and for Meta (shape inference); a CPU tensor gets an explicit error.
+// Host tensors: the reference's module dispatches on x.is_cuda() (binding.cpp:30-81), so the three pybind entry points
+// at the bottom do too -- their host branch is host_branch.h (this module's own Direct Form I loop).  Everything else is
+// device-only: the dispatcher ops are registered for the CUDA key (= ROCm device tensors in a ROCm build of PyTorch) and
+// for Meta (shape inference), and a CPU tensor gets an explicit error there.
 #include <torch/extension.h>
 #include <torch/library.h>
 
@@ -23,6 +25,7 @@
 #include <vector>
 
 #include "../../../include/torchfx_hip.h"
+#include "host_branch.h"
 
 namespace {
 
@@ -664,6 +667,7 @@ PYBIND11_MODULE(torchfx_ext, m)
     m.doc() = "torchfx native extension for MI355X (HIP kernels behind the reference's torchfx_ext interface)";
     m.def("biquad_forward",
           [](const Tensor &x, const Tensor &b, double a1, double a2, const OptTensor &state_x, const OptTensor &state_y) {
+              if (!x.is_cuda()) return host::biquad_forward(x, b, a1, a2, state_x, state_y);      // binding.cpp:30-50 dispatches the same way
               return biquad_op(x, b, a1, a2, state_x, state_y, std::nullopt, -1);
           },
           "Biquad forward pass (x, b, a1, a2, state_x, state_y) -> (y, new_state_x, new_state_y)", py::arg("x"), py::arg("b"),
@@ -671,10 +675,16 @@ PYBIND11_MODULE(torchfx_ext, m)
     m.def("sos_forward",
           [](const Tensor &x, const OptTensor &sos, const Tensor &sos_cpu, const OptTensor &state_x, const OptTensor &state_y) {
               (void)sos;      // device copy of the coefficients: the reference's sync-avoidance argument, unused here
+              if (!x.is_cuda()) return host::sos_forward(x, sos_cpu, state_x, state_y);             // binding.cpp:52-66
               return sos_op(x, sos_cpu, state_x, state_y, std::nullopt, -1);
           },
           "SOS cascade forward pass (x, sos, sos_cpu, state_x, state_y) -> (y, new_state_x, new_state_y)", py::arg("x"),
           py::arg("sos"), py::arg("sos_cpu"), py::arg("state_x"), py::arg("state_y"));
-    m.def("delay_line_forward", &delay_line_op, "Delay line forward pass (x, delay_samples, decay, mix) -> y", py::arg("x"),
-          py::arg("delay_samples"), py::arg("decay"), py::arg("mix"));
+    m.def("delay_line_forward",
+          [](const Tensor &x, int64_t delay_samples, double decay, double mix) {
+              if (!x.is_cuda()) return host::delay_line_forward(x, delay_samples, decay, mix);    // binding.cpp:68-81
+              return delay_line_op(x, delay_samples, decay, mix);
+          },
+          "Delay line forward pass (x, delay_samples, decay, mix) -> y", py::arg("x"), py::arg("delay_samples"), py::arg("decay"),
+          py::arg("mix"));
 }

@@ -32,6 +32,7 @@ bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out);
 void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const float *kf_host, int64_t K,
                        int64_t pl, int64_t pr, int64_t N, hipStream_t stream, const float *hist, int64_t H, const Epilogue *ep,
                        const SosFuseHost *sosf = nullptr);
+void olsnative_wait_warm();
 bool olsnative_sos_supported(int64_t Ksos, int64_t warm, int64_t K, int64_t Tn, int64_t pl, int64_t pr, int force, int64_t *N_out);
 void sos_plan_info(const double *sos_host, int64_t K, int *precision, int64_t *warmup, double *err_bound);
 int64_t sos_warmup_bits(const double *sos_host, int64_t K, int bits);
@@ -238,11 +239,6 @@ void fftconv_clear()
     g_fft_plans.clear();
 }
 
-static int64_t env_i64(const char *name, int64_t dflt)
-{
-    const char *e = getenv(name);
-    return (e && *e) ? atoll(e) : dflt;
-}
 
 int64_t fftconv_block_size(int64_t K, int64_t L)
 {
@@ -337,6 +333,7 @@ void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, c
     if (C == 0) return;
     TFX_CHECK(C > 0 && T >= 0, "fft_conv_forward: negative size");
     TFX_CHECK(y && kernel_host && (x || T == 0), "fft_conv_forward: null pointer");
+    olsnative_wait_warm();               // a set-up helper started by tfx_prewarm finishes before anything here is enqueued
     int64_t Nn = 0;
     if (olslds_supported(K, dtype, L, &Nn)) {
         // kernels that fit on chip: no workspace, epilogue in the store of the inverse transform
@@ -369,8 +366,7 @@ static int64_t fused_warmup(const double *sos_host, int64_t Ksos)
 {
     static std::mutex mu;
     static std::map<std::vector<double>, int64_t> memo;
-    const char *e = getenv("TFX_OLS_SOS_HALO_BITS");
-    const int bits = (e && *e) ? std::max(20, std::min(60, atoi(e))) : 48;
+    const int bits = (int)std::max<int64_t>(20, std::min<int64_t>(60, env_i64("TFX_OLS_SOS_HALO_BITS", 48)));
     std::vector<double> key(sos_host, sos_host + 6 * Ksos);
     key.push_back((double)bits);
     std::lock_guard<std::mutex> lk(mu);

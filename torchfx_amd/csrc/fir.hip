@@ -283,11 +283,7 @@ fir_direct_simple_kernel(const T *__restrict__ x, T *__restrict__ y, const T *__
     }
 }
 
-static int64_t envi_fir(const char *name, int64_t dflt)
-{
-    const char *e = getenv(name);
-    return e ? atoll(e) : dflt;
-}
+static int64_t envi_fir(const char *name, int64_t dflt) { return env_i64(name, dflt); }      // read once per process (common.h)
 
 // The last H samples of the logical signal [hist | x] (what the next chunk needs as its history).
 template <typename T>
@@ -350,8 +346,8 @@ void fir_direct_forward(const void *x, void *y, int dtype, int64_t C, int64_t T,
             const int64_t cost = ceil_div(K, cand) * ((cand + 32) / 32 + 4);
             if (best < 0 || cost < best) best = cost, kc = cand;
         }
-        if (const char *e = getenv("TFX_FIR_KC")) {
-            const int v = atoi(e);
+        {
+            const int v = (int)envi_fir("TFX_FIR_KC", 0);
             if (v == 128 || v == 512 || v == 1024) kc = v;
         }
         const int nchunks = (int)ceil_div(K, kc);

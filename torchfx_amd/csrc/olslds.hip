@@ -31,6 +31,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -607,13 +608,21 @@ ols_lds16k_kernel(const float *__restrict__ x, float *__restrict__ y, const v4f 
 }
 
 // ---- host: per-filter tables ---------------------------------------------------------------------
+// A plan's device buffer (spectrum | tables, one allocation) is OWNED by the plan objects that point into it: get_plan hands
+// out a copy, so a caller keeps the buffer alive until its launches are enqueued, whatever another host thread evicts in
+// the meantime; the last owner's hipFree synchronises the device, i.e. runs behind those launches (round 4 returned a
+// plain copy and freed every spectrum when the 66th filter arrived: a launch on a freed buffer).
 struct Plan {
     void *Hs = nullptr, *tw256 = nullptr, *t4lo = nullptr, *w8k = nullptr;
+    std::shared_ptr<void> owner;
 };
 static std::mutex g_mu;
 static std::map<std::vector<char>, Plan> g_plans;
+static std::map<std::vector<char>, uint64_t> g_used;                     // last use of a key (eviction: least recently used first)
+static uint64_t g_tick = 0;
 static const std::vector<char> *g_last_key[TFX_MAX_DEVICES] = {};       // std::map nodes are stable
 static const Plan *g_last[TFX_MAX_DEVICES] = {};
+constexpr size_t LDS_PLAN_CAP = 64;
 
 template <typename R> static void *upload(const std::vector<cx<R>> &h)
 {
@@ -624,24 +633,35 @@ template <typename R> static void *upload(const std::vector<cx<R>> &h)
 }
 
 // kind: 0 = 4096 points, 1 = 8192 (radix 2 around 4096), 2 = 16 384 in a 1024-thread workgroup, 3 = 16 384 as radix 4 around 4096
-template <typename R> static Plan get_plan(const R *kf, int64_t K, int64_t lead, int N, int kind)
+template <typename R> static Plan get_plan(const R *kf, int64_t K, int64_t lead, int N, int kind, hipStream_t stream)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     const int dev = current_device();
     const size_t nb = (size_t)K * sizeof(R);
     const char tail[3] = {(char)(sizeof(R) + 16 * kind), (char)lead, (char)dev};
     if (const std::vector<char> *lk_ = g_last_key[dev]) {       // steady state: one memcmp, no key construction
-        if (lk_->size() == nb + 3 && memcmp(lk_->data(), kf, nb) == 0 && memcmp(lk_->data() + nb, tail, 3) == 0) return *g_last[dev];
+        if (lk_->size() == nb + 3 && memcmp(lk_->data(), kf, nb) == 0 && memcmp(lk_->data() + nb, tail, 3) == 0) {
+            g_used[*lk_] = ++g_tick;
+            return *g_last[dev];
+        }
     }
     std::vector<char> key((const char *)kf, (const char *)kf + nb);
     key.insert(key.end(), tail, tail + 3);
     auto it = g_plans.find(key);
     if (it == g_plans.end()) {
-        if (g_plans.size() > 64) {
-            (void)hipDeviceSynchronize();
-            for (auto &kv : g_plans) (void)hipFree(kv.second.Hs);
-            g_plans.clear();
-            for (int d = 0; d < TFX_MAX_DEVICES; ++d) { g_last_key[d] = nullptr; g_last[d] = nullptr; }
+        // a new filter costs a device allocation and a blocking upload: not inside a stream capture
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        TFX_CHECK(!(hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone),
+                  "overlap-save: first use of this filter (%lld taps) inside a stream capture -- run it once before capturing "
+                  "(its spectrum is uploaded with a blocking copy)", (long long)K);
+        while (g_plans.size() >= LDS_PLAN_CAP) {              // least recently used entry goes; its buffer lives on with whoever still holds it
+            auto victim = g_used.begin();
+            for (auto u = g_used.begin(); u != g_used.end(); ++u)
+                if (u->second < victim->second) victim = u;
+            for (int d = 0; d < TFX_MAX_DEVICES; ++d)
+                if (g_last_key[d] && *g_last_key[d] == victim->first) { g_last_key[d] = nullptr; g_last[d] = nullptr; }
+            g_plans.erase(victim->first);
+            g_used.erase(victim);
         }
         // conj(FFT(taps behind `lead` zeros, zero padded to N)) / N in float64  (_fftconv.py:123-124,131 + irfft scaling)
         std::vector<double> re((size_t)N, 0.0), im((size_t)N, 0.0);
@@ -672,6 +692,7 @@ template <typename R> static Plan get_plan(const R *kf, int64_t K, int64_t lead,
                 }
             hs.insert(hs.end(), tab.begin(), tab.end());
             p.Hs = upload<R>(hs);                             // one allocation, one copy: spectrum | tables
+            p.owner = std::shared_ptr<void>(p.Hs, [](void *q) { (void)hipFree(q); });
             p.tw256 = (char *)p.Hs + (size_t)N * sizeof(cx<R>);
             p.t4lo = nullptr;
         } else {
@@ -708,22 +729,20 @@ template <typename R> static Plan get_plan(const R *kf, int64_t K, int64_t lead,
                 for (int r = 1; r < 4; ++r)
                     for (int i = 0; i < 256; ++i) hs.push_back(W(r * i, 16384));
             p.Hs = upload<R>(hs);
+            p.owner = std::shared_ptr<void>(p.Hs, [](void *q) { (void)hipFree(q); });
             p.tw256 = (char *)p.Hs + (size_t)N * sizeof(cx<R>);
             p.t4lo = (char *)p.tw256 + 256 * sizeof(cx<R>);
             p.w8k = (char *)p.t4lo + 256 * sizeof(cx<R>);
         }
         it = g_plans.emplace(std::move(key), p).first;
     }
+    g_used[it->first] = ++g_tick;
     g_last_key[dev] = &it->first;
     g_last[dev] = &it->second;
     return it->second;
 }
 
-static int64_t envi(const char *name, int64_t dflt)
-{
-    const char *e = getenv(name);
-    return (e && *e) ? atoll(e) : dflt;
-}
+static int64_t envi(const char *name, int64_t dflt) { return env_i64(name, dflt); }      // read once per process (common.h)
 
 }  // namespace ldsfft
 
@@ -731,9 +750,8 @@ void olslds_clear()
 {
     using namespace ldsfft;
     std::lock_guard<std::mutex> lk(g_mu);
-    (void)hipDeviceSynchronize();
-    for (auto &kv : g_plans) (void)hipFree(kv.second.Hs);
-    g_plans.clear();
+    g_plans.clear();                        // the owners free their buffers (hipFree waits for the device)
+    g_used.clear();
     for (int d = 0; d < TFX_MAX_DEVICES; ++d) { g_last_key[d] = nullptr; g_last[d] = nullptr; }
 }
 
@@ -808,7 +826,7 @@ static void olslds_typed(const R *x, R *y, int64_t C, int64_t Tn, const R *kf_ho
     const int64_t r4 = envi("TFX_OLS_LDS16K_R4", 1);
     const bool use_r4 = N == LDS16K && sizeof(R) == 4 && (r4 >= 2 || (r4 == 1 && L >= 65536 && envi("TFX_OLS_LDS16K", 1) < 2));
     const int kind = N == LDS_N ? 0 : N == LDS8K ? 1 : use_r4 ? 3 : 2;
-    const Plan plan = get_plan<R>(kf_host, K, lead, (int)N, kind);
+    const Plan plan = get_plan<R>(kf_host, K, lead, (int)N, kind, stream);      // holds its buffer until this function has enqueued its launch
     const int64_t npairs = ceil_div(g.nframes, 2);
     if (g.ep_stat >= 0) g.ep_partial = (double *)scratch("olslds_ep_partial", (size_t)g.nframes * sizeof(double), stream);
     const int dev = current_device();

@@ -1142,11 +1142,23 @@ struct NativePlan {
     cpx *tables = nullptr;          // the one allocation tw256 ... t4hi point into
     hipEvent_t ready = nullptr;     // recorded behind the spectrum kernels: other streams wait for it before they read Hp
     hipStream_t ready_stream = nullptr;
+    NativePlan() = default;
+    NativePlan(const NativePlan &) = delete;
+    NativePlan &operator=(const NativePlan &) = delete;
+    ~NativePlan()                   // the last owner frees: hipFree waits for the device, i.e. runs behind every launch that used the plan
+    {
+        for (cpx *q : {Hp, tables}) if (q) (void)hipFree(q);
+        if (taps_dev) (void)hipFree(taps_dev);
+        if (ready) (void)hipEventDestroy(ready);
+    }
 };
+// Plans are shared_ptr-owned: olsnative_forward keeps its plan alive until its launches are enqueued, whatever another host
+// thread evicts meanwhile (round 4 handed out raw pointers and freed every plan when the 18th filter arrived).
+typedef std::shared_ptr<NativePlan> NativePlanPtr;
 static std::mutex g_np_mu;
-static std::map<std::vector<char>, NativePlan *> g_nplans;
+static std::map<std::vector<char>, NativePlanPtr> g_nplans;
 static int64_t g_free_mb[TFX_MAX_DEVICES] = {};                  // per device: free memory (MB) seen at first use, 0 = not asked yet
-static NativePlan *g_last_plan[TFX_MAX_DEVICES] = {};          // per device: the plan used last and its key
+static NativePlanPtr g_last_plan[TFX_MAX_DEVICES];             // per device: the plan used last and its key
 static std::vector<char> g_last_key[TFX_MAX_DEVICES];
 
 // Forward FFT in float64 of a real sequence of L samples zero-padded to n = 2^m points (the spectrum of the taps, once per
@@ -1256,11 +1268,7 @@ static std::vector<cpx> twiddles(int64_t n, int64_t count, int64_t step)   // W_
     return t;
 }
 
-static int64_t envi(const char *name, int64_t dflt)
-{
-    const char *e = getenv(name);
-    return (e && *e) ? atoll(e) : dflt;
-}
+static int64_t envi(const char *name, int64_t dflt) { return env_i64(name, dflt); }      // read once per process (common.h)
 
 // ---- per-device one-time set-up: kernel attributes (the first touch of a kernel loads the library's code object: 10-25 ms)
 // and the internal streams with their fork / join events (the first stream of a process costs ~5 ms each).  The first call
@@ -1349,6 +1357,26 @@ void olsnative_prewarm()
     }).share();
 }
 
+// Every overlap-save entry waits for a running helper first: its hipMalloc / hipStreamCreate must not land in a stream capture
+// the caller starts right after the call (advisor, round 4).  A failure of the helper is reported once, then forgotten.
+void olsnative_wait_warm()
+{
+    const int dev = current_device();
+    std::shared_future<void> w;
+    {
+        std::lock_guard<std::mutex> lk(g_warm_mu);
+        w = g_warm[dev];
+    }
+    if (!w.valid()) return;
+    try {
+        w.get();
+    } catch (...) {
+        std::lock_guard<std::mutex> lk(g_warm_mu);
+        g_warm[dev] = std::shared_future<void>();
+        throw;
+    }
+}
+
 // TFX_OLS_TRACE=1: host milliseconds of the set-up phases of a call on stderr (where the first call of a process goes)
 struct HostTrace {
     bool on;
@@ -1363,11 +1391,11 @@ struct HostTrace {
     }
 };
 
-static NativePlan *get_native_plan(const float *kf, int64_t K, int64_t N, int64_t lead, hipStream_t stream)
+static NativePlanPtr get_native_plan(const float *kf, int64_t K, int64_t N, int64_t lead, hipStream_t stream)
 {
     // steady state (the same filter call after call, e.g. streaming chunks): one memcmp against the plan
     // used last, no key construction
-    NativePlan **last = g_last_plan;
+    NativePlanPtr *last = g_last_plan;
     std::vector<char> *last_key = g_last_key;
     const int dev_ = current_device();
     {
@@ -1383,19 +1411,18 @@ static NativePlan *get_native_plan(const float *kf, int64_t K, int64_t N, int64_
     key.push_back((char)current_device());
     auto it = g_nplans.find(key);
     if (it != g_nplans.end()) { last[dev_] = it->second; last_key[dev_] = key; return it->second; }
-    if (g_nplans.size() > 16) {
-        for (int d = 0; d < TFX_MAX_DEVICES; ++d) last[d] = nullptr;
-        (void)hipDeviceSynchronize();
-        for (auto &kv : g_nplans) {
-            NativePlan *p = kv.second;
-            for (cpx *q : {p->Hp, p->tables}) if (q) (void)hipFree(q);
-            if (p->taps_dev) (void)hipFree(p->taps_dev);
-            if (p->ready) (void)hipEventDestroy(p->ready);
-            delete p;
-        }
+    {
+        // a new filter costs device allocations, blocking uploads (and, for N = 2^20, two launches): not inside a stream capture
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        TFX_CHECK(!(hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone),
+                  "overlap-save: first use of this filter (%lld taps) inside a stream capture -- run it once before capturing "
+                  "(its spectrum and tables are uploaded with blocking copies)", (long long)K);
+    }
+    if (g_nplans.size() > 16) {            // the map lets go; a plan lives on with whoever still holds it
+        for (int d = 0; d < TFX_MAX_DEVICES; ++d) last[d].reset();
         g_nplans.clear();
     }
-    NativePlan *pl = new NativePlan();
+    NativePlanPtr pl = std::make_shared<NativePlan>();
     pl->N = N; pl->K = K; pl->N2 = (int)(N / OLS_N1);
     HostTrace tr;
     const int N2 = pl->N2;
@@ -1484,17 +1511,13 @@ static NativePlan *get_native_plan(const float *kf, int64_t K, int64_t N, int64_
 
 void olsnative_clear()
 {
-    std::lock_guard<std::mutex> lk(g_np_mu);
-    (void)hipDeviceSynchronize();
-    for (auto &kv : g_nplans) {
-        NativePlan *p = kv.second;
-        for (cpx *q : {p->Hp, p->tables}) if (q) (void)hipFree(q);
-        if (p->taps_dev) (void)hipFree(p->taps_dev);
-        if (p->ready) (void)hipEventDestroy(p->ready);
-        delete p;
+    {
+        std::lock_guard<std::mutex> lk(g_np_mu);
+        g_nplans.clear();
+        for (int d = 0; d < TFX_MAX_DEVICES; ++d) { g_last_plan[d].reset(); g_free_mb[d] = 0; }
     }
-    g_nplans.clear();
-    for (int d = 0; d < TFX_MAX_DEVICES; ++d) { g_last_plan[d] = nullptr; g_free_mb[d] = 0; }
+    std::lock_guard<std::mutex> lk(g_warm_mu);          // a failed helper is not remembered beyond a clear
+    for (int d = 0; d < TFX_MAX_DEVICES; ++d) g_warm[d] = std::shared_future<void>();
 }
 
 
@@ -1569,7 +1592,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     // while this thread computes the spectrum (both are tens of milliseconds, one bound by the driver, one by the host's cores);
     // tfx_prewarm() starts the same helper earlier (the Python planner calls it before it merges taps)
     olsnative_prewarm();
-    NativePlan *plan = nullptr;
+    NativePlanPtr plan;
     std::exception_ptr plan_err;
     try {
         std::lock_guard<std::mutex> lk(g_np_mu);
@@ -1581,7 +1604,15 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
             std::lock_guard<std::mutex> lk(g_warm_mu);
             w = g_warm[dev];
         }
-        if (w.valid()) w.get();                              // rethrows what the helper threw
+        if (w.valid()) {
+            try {
+                w.get();                                     // rethrows what the helper threw ...
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(g_warm_mu);   // ... once: the next call starts the set-up again (advisor, round 4)
+                g_warm[dev] = std::shared_future<void>();
+                throw;
+            }
+        }
     }
     if (plan_err) std::rethrow_exception(plan_err);
     if (plan->ready && plan->ready_stream != stream) TFX_HIP(hipStreamWaitEvent(stream, plan->ready, 0));   // spectrum computed on another stream

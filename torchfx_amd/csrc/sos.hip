@@ -951,11 +951,7 @@ void sos_clear_plans()
     g_plans.clear();
 }
 
-static int env_int(const char *name, int dflt)
-{
-    const char *e = getenv(name);
-    return (e && *e) ? atoi(e) : dflt;
-}
+static int env_int(const char *name, int dflt) { return (int)env_i64(name, dflt); }      // read once per process (common.h)
 
 static int g_cus[TFX_MAX_DEVICES] = {0};
 static int device_cus()

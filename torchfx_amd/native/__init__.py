@@ -12,6 +12,7 @@ Missing build products raise ``RuntimeError`` -- there is no Python or CPU fallb
 from __future__ import annotations
 
 import importlib
+import os
 import threading
 
 _lock = threading.Lock()
@@ -33,19 +34,20 @@ def load():
                 raise RuntimeError(
                     "torchfx_amd: the compiled extension torchfx_amd/native/torchfx_ext*.so is missing or does not load "
                     f"({e}); build it with `python __graft_entry__.py` (make -C torchfx_amd/csrc).") from e
-            _prewarm()
+            if os.environ.get("TORCHFX_AMD_PREWARM", "0") == "1":
+                _prewarm()
     return _mod
 
 
 def _prewarm() -> None:
-    """With a ROCm device present, start the library's one-time device set-up (load of its code object, internal streams)
-    on a helper thread as soon as the module is loaded (`tfx_prewarm`): it costs 20-80 ms of driver time that would otherwise
-    sit in the first filter call.  Best effort; `TORCHFX_AMD_PREWARM=0` turns it off."""
-    import os
-
+    """Opt-in (`TORCHFX_AMD_PREWARM=1`): start the library's one-time device set-up (load of its code object, internal
+    streams) on a helper thread as soon as the module is loaded -- on the device that is CURRENT then.  Importing a library
+    does not touch a device by default (round 4 did, and a rank that addresses its GPU as `cuda:3` without
+    `torch.cuda.set_device` got a context on GPU 0): the planner starts the same helper with the wave's own device when it
+    first plans a pipeline with an FFT-mode FIR (`Wave.plan`), and `torchfx_ext.prewarm(device)` does it on request."""
     import torch
 
-    if os.environ.get("TORCHFX_AMD_PREWARM", "1") == "0" or not torch.cuda.is_available():
+    if not torch.cuda.is_available():
         return
     try:
         from torchfx_amd import _lib
