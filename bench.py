@@ -519,15 +519,20 @@ def main() -> None:
     chainlike = args.workload.startswith("chain") or args.workload == "fftconv"
     seconds = args.seconds if args.seconds is not None else (600.0 if chainlike else 60.0)
     if args.scaling == "strong":
-        if args.total_channels % world:
-            raise SystemExit(f"--total-channels {args.total_channels} does not divide over {world} ranks")
-        C = args.total_channels // world
+        # a fixed batch split like torchfx_amd.distributed.shard_bounds: contiguous blocks, the first `total % world` ranks one
+        # row more (9 channels over 8 ranks = 2, 1, 1, ...; fewer channels than ranks leaves empty blocks: those ranks idle)
+        from torchfx_amd.distributed import shard_bounds as _sb
+        lo_, hi_ = _sb(args.total_channels, world, rank)
+        C = hi_ - lo_
+        total_rows = args.total_channels
     else:
         C = args.channels
+        total_rows = C * world
     T = int(seconds * FS)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
     x = torch.randn(C, T, device=dev, generator=gen, dtype=torch.float32)
-    x.mul_(1.0 / float(x.abs().max()))     # max|x| <= 1 (benchmarks/conftest.py:70-82 of the reference)
+    if C > 0:
+        x.mul_(1.0 / float(x.abs().max()))     # max|x| <= 1 (benchmarks/conftest.py:70-82 of the reference)
     if os.environ.get("TFX_BENCH_ZERO_INPUT", "0") == "1":
         x.zero_()                          # development only: a compute-bound kernel without data toggling (clock / power study)
 
@@ -661,11 +666,11 @@ def main() -> None:
         from torchfx_amd.distributed import gather_rows
         sync()
         g0 = time.perf_counter()
-        gathered = gather_rows(out, C * world, dst=0)          # one RCCL gather: each peer -> root over its own xGMI link
+        gathered = gather_rows(out, total_rows, dst=0)         # one RCCL gather: each peer -> root over its own xGMI link
         sync()
         gather_ms = (time.perf_counter() - g0) * 1e3
         if rank == 0:
-            assert gathered.shape == (C * world, out.shape[1])
+            assert gathered.shape == (total_rows, out.shape[1])
         del gathered
         if world > 1:
             tg = torch.tensor([gather_ms], device="cpu" if share else dev, dtype=torch.float64)
@@ -680,7 +685,7 @@ def main() -> None:
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         samples = C * T
-        value = world * samples / (elapsed / args.steps) / 1e6            # whole-job Msamples/s
+        value = total_rows * T / (elapsed / args.steps) / 1e6             # whole-job Msamples/s (all ranks' rows / slowest rank's time)
         kernels = kernel_table(prof, args.steps)
         # per-kernel HBM model: the bytes each launch group must move by design (not the 8 B/sample
         # algorithmic figure) -> achieved GB/s of that kernel; PMC-measured traffic agrees within a few %
@@ -831,7 +836,7 @@ def main() -> None:
             "scaling": args.scaling, "vs_baseline": None,      # no published number for THIS metric; see vs_baseline_context
             "dtype": dtype,
             "data": "synthetic", "per_gpu_value": round(value / world, 1),
-            "config": {"workload": desc, "channels_per_gpu": C, "total_channels": C * world, "seconds": seconds, "fs": FS,
+            "config": {"workload": desc, "channels_per_gpu": C, "total_channels": total_rows, "seconds": seconds, "fs": FS,
                        "samples_per_gpu": samples, "parallelism": f"channel-shard x{world}, no data-path collective",
                        "fusion_policy": os.environ.get("TORCHFX_AMD_FUSION", "auto"),
                        "iir_precision": iir_how,
@@ -873,7 +878,7 @@ def main() -> None:
             line["variants"] = variants
         if gather_ms is not None:
             line["gather_ms"] = round(gather_ms, 2)
-            line["value_with_gather"] = round(world * samples / (elapsed / args.steps + gather_ms * 1e-3) / 1e6, 1)
+            line["value_with_gather"] = round(total_rows * T / (elapsed / args.steps + gather_ms * 1e-3) / 1e6, 1)
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N=1 only (contract)
             try:
                 base_wl = "chain" if args.workload.startswith("chain") else args.workload

@@ -216,6 +216,42 @@ def test_bench_starts_its_own_ranks():
             assert 0 < line["value_with_gather"] < line["value"]
 
 
+def test_bench_starts_eight_ranks_uneven_strong_split_and_gather():
+    """the shape of the first 8-GPU run -- `python bench.py --gpus 8 [--gather]` starts eight ranks itself
+    (share-device, gloo: one GPU here), 2 s signals; weak scaling, a strong split of 8 channels (one row per rank) and of 9
+    (uneven: one rank holds two rows).  Rank 0 prints ONE line with value, value_with_gather, gather_ms, ranks_seen == 8 and
+    eight device records; a launcher whose world size disagrees with --gpus gets no line at all."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["TFX_BENCH_SHARE_DEVICE"] = "1"
+    env["OMP_NUM_THREADS"] = "2"
+    for extra, scaling, total, c0 in ((["--channels", "1"], "weak", 8, 1),
+                                      (["--scaling", "strong", "--total-channels", "8"], "strong", 8, 1),
+                                      (["--scaling", "strong", "--total-channels", "9"], "strong", 9, 2)):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                            "--seconds", "2", "--gather"] + extra, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and len(line["devices"]) == 8
+        assert {d["rank"] for d in line["devices"]} == set(range(8)) and all(d["uuid"] for d in line["devices"])
+        assert line["distinct_device_uuids"] == 1                     # share-device mode: eight ranks, one GPU (the driver's run: 8)
+        assert line["scaling"] == scaling and line["config"]["total_channels"] == total and line["config"]["channels_per_gpu"] == c0
+        assert line["value"] > 0 and line["gather_ms"] > 0 and 0 < line["value_with_gather"] < line["value"]
+    # the launcher's world size and --gpus disagree: nothing is printed
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = str(sk.getsockname()[1]); sk.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0", "--seconds", "2"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_two_devices_in_one_process_keep_their_own_caches():
     """Every device-side cache is keyed by the device ordinal (plans, taps, spectra, scratch, internal streams):
     the same filters driven alternately on cuda:0 and cuda:1 from ONE process give the single-device results.

@@ -62,19 +62,23 @@ def gather_rows(y_local: Tensor, n_rows: int, dst: int = 0, group=None, out: Ten
     sizes = [shard_bounds(n_rows, world, r) for r in range(world)]
     T = y_local.shape[1]
     lo, hi = sizes[rank]
-    if y_local.shape[0] != hi - lo:
-        raise ValueError(f"rank {rank} holds {y_local.shape[0]} rows, its block of {n_rows} rows over {world} ranks has {hi - lo}")
 
     def peer(r: int) -> int:
         return r if group is None else dist.get_global_rank(group, r)
     # "nccl" (= RCCL) moves device buffers peer to root directly; a gloo group (CPU collectives: the
     # development set-up where several ranks share one GPU) stages device rows through host memory
-    staged = y_local.is_cuda and dist.get_backend(group) == "gloo"
-    # Ranks with an empty block (n_rows < world) have nothing to send.  On RCCL the FIRST communication of a group creates
-    # the communicator and every rank has to take part in it, so when anybody sits the batch out a cheap all-reduce comes
-    # first: every rank enters it, later point-to-point batches may then involve any subset (advisor, round 3).
-    if any(rhi == rlo for rlo, rhi in sizes) and dist.get_backend(group) == "nccl":
-        dist.all_reduce(torch.zeros(1, dtype=torch.int32, device=y_local.device), group=group)
+    nccl = dist.get_backend(group) == "nccl"
+    staged = y_local.is_cuda and not nccl
+    # ONE small all-reduce opens every gather, and every rank enters it: (1) the arguments are validated collectively -- a rank
+    # whose block has the wrong shape makes ALL ranks raise instead of leaving the others blocked in the transfer (advisor,
+    # round 4); (2) on RCCL the first communication of a group creates its communicator and needs every rank, also those
+    # whose block is empty (n_rows < world) and who sit the point-to-point batch out.  A few bytes beside a gather of GBs.
+    bad = 0 if y_local.shape[0] == hi - lo else 1
+    flag = torch.tensor([bad, T, -T], dtype=torch.int64, device=y_local.device if nccl else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    if int(flag[0]) != 0 or int(flag[1]) != -int(flag[2]):
+        raise ValueError(f"gather_rows: rank {rank} holds {tuple(y_local.shape)}; its block of {n_rows} rows over {world} ranks has "
+                         f"{hi - lo} rows and all ranks must agree on the row length (some rank disagrees: every rank raises)")
     if rank != dst:
         if hi > lo:
             wire = y_local.contiguous()
