@@ -622,7 +622,7 @@ def test_precision_auto_estimate_is_a_replay_of_the_float32_kernel():
 def test_host_taps_are_converted_once_per_module_buffer():
     """FIR.forward hands `self.kernel.reshape(-1)` (a new view object per call) to the backend; the host copy in the
     signal's dtype must be made once per buffer, not once per call (a fresh quarter-megabyte host allocation per step
-    stalls the GPU queues of the process)."""
+    stalls the GPU queues of the process, docs/HISTORY.md section 6.2)."""
     from torchfx_amd.torchfx_ext import _kernel_host
     buf = torch.randn(1, 1, 70000, dtype=torch.float64)
     a = _kernel_host(buf.reshape(-1), torch.float32)

@@ -38,7 +38,7 @@ def main() -> None:
                        "WRITE_SIZE in separate runs, tools/profile_gpu.sh). read = 2 x FETCH_SIZE (gfx950 tallies 64 B per 128-B request "
                        "for coalesced streams), write = WRITE_SIZE. Sources: profiles/%s_<workload>.{txt,json}." % tag,
            "source_digest": bench.source_digest()}
-    for wl in ("chain", "chain_iir_kernel", "sos", "fir", "fir_fft", "fftconv"):
+    for wl in ("chain", "chain_fold", "chain_iir_kernel", "sos", "fir", "fir_fft", "fftconv"):
         p = os.path.join(src, f"{tag}_{wl}.json")
         if not os.path.exists(p):
             continue

@@ -35,8 +35,31 @@ def main():
             res[tag] = q(f[0], "select kernel_name, counter_name, count(*) as dispatches, sum(value) as total, "
                                "avg(value) as per_dispatch, avg(duration) as avg_ns from counters_collection "
                                "group by kernel_name, counter_name order by total desc")
+    c = glob.glob(f"{d}/clock/*.db")
+    if c:
+        rows = q(c[0], "select kernel_name, count(*) as dispatches, avg(value) as gui_active, avg(duration) as avg_ns from counters_collection "
+                       "where counter_name = 'GRBM_GUI_ACTIVE' group by kernel_name order by sum(duration) desc")
+        res["clock"] = [dict(r, ghz=round(r["gui_active"] / 8.0 / r["avg_ns"], 3)) for r in rows if r["avg_ns"]]
+    import os
+    for name in ("bench_trace.json", "bench_clock.json"):
+        pth = os.path.join(d, name)
+        try:
+            line = json.loads(open(pth).read().strip().splitlines()[-1])
+            dev = (line.get("devices") or [{}])[0]
+            res.setdefault("device", {"name": dev.get("name"), "uuid": dev.get("uuid"), "cus": dev.get("cus")})
+            res.setdefault("bench_ms_per_step_under_rocprofv3", {})[name.split(".")[0]] = line.get("ms_per_step")
+        except Exception:
+            pass
     json.dump(res, open(out + ".json", "w"), indent=1)
     with open(out + ".txt", "w") as fh:
+        if "device" in res:
+            fh.write(f"device: {res['device'].get('name')}  uuid {res['device'].get('uuid')}  CUs {res['device'].get('cus')}   "
+                     f"bench ms/step under rocprofv3: {res.get('bench_ms_per_step_under_rocprofv3')}\n")
+        if "clock" in res:
+            fh.write("== effective clock per kernel: GRBM_GUI_ACTIVE / 8 XCDs / duration (separate --pmc pass) ==\n")
+            for r in res["clock"][:8]:
+                fh.write(f"{r['kernel_name'][:70]:70s} {r['dispatches']:6d} disp  {r['avg_ns'] / 1e3:10.2f} us  {r['ghz']:6.3f} GHz\n")
+            fh.write("\n")
         fh.write("== rocprofv3 --kernel-trace --stats : per-kernel time (the view reports microseconds) ==\n")
         fh.write(f"{'kernel':70s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'%':>6s}\n")
         for r in res.get("top_kernels", []):

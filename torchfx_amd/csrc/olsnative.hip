@@ -1318,7 +1318,7 @@ static void ols_set_attributes(int dev)
         }
     for (int a = 0; a < 4; ++a)
         for (int b = 0; b < SOSF_MAXK; ++b)
-            TFX_HIP(hipFuncSetAttribute((const void *)colsos_tab[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, (int)OLS_SHM_SOSF));
+            TFX_HIP(hipFuncSetAttribute((const void *)colsos_tab[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, (int)OLS_SHM_SOSF + 16384));
     attr_tab[dev] = true;
 }
 static void ols_make_lanes(int dev, int nlanes)           // lanes are created when first used
@@ -1720,6 +1720,8 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     int64_t slab_idx = 0;
     // Cascade in pass A: the lanes would otherwise march in step (all in pass A', then all in B, then all in C) -- the first
     // slab of lane i is cut to (i + 1) / nlanes of a slab so that the three kinds of pass meet on the chip
+    // development: extra dynamic LDS for the recursion pass = one workgroup per CU, the rest of the CU stays free for passes B / C
+    const size_t sos_lds_pad = sosf ? (size_t)envi("TFX_OLS_SOS_LDS_PAD", 0) : 0;
     const int64_t sos_sub = sosf ? envi("TFX_OLS_SOS_SUB_PAIRS", 0) : 0;
     const int stagger = sosf ? (int)envi("TFX_OLS_SOS_STAGGER", 0) : 0;
     for (int64_t p0 = 0, step_pairs = slab; p0 < npairs; p0 += step_pairs, ++slab_idx) {
@@ -1730,7 +1732,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
         cpx *T = Tlane[ln];
         if (sosf) {
             ProfScope ps("ols_col_fwd16_sos_kernel", stream);
-            hipLaunchKernelGGL(colsos_tab[(sosf->sections ? 1 : 0) + (sos_unit ? 2 : 0)][sosf->K - 1], dim3((unsigned)np), dim3(512), OLS_SHM_SOSF, stream,
+            hipLaunchKernelGGL(colsos_tab[(sosf->sections ? 1 : 0) + (sos_unit ? 2 : 0)][sosf->K - 1], dim3((unsigned)np), dim3(512), OLS_SHM_SOSF + sos_lds_pad, stream,
                                x, T, plan->tw256, g, 2 * p0, sosk);
             TFX_HIP(hipGetLastError());
         } else {

@@ -19,7 +19,7 @@ PCM16_SCALE = 1.0 / 32768.0          # libsndfile's normalisation of 16-bit PCM 
 
 # Staging buffers live as long as the process: a streaming caller (StreamProcessor.process_file) uploads and downloads
 # one chunk after the other, and fresh pinned / pageable host buffers per chunk are exactly the host-side churn that
-# makes the driver hold the process's GPU queues.  One set per (device, geometry); a call leaves
+# makes the driver hold the process's GPU queues (docs/HISTORY.md section 6.2).  One set per (device, geometry); a call leaves
 # them idle (it waits for its last kernel / copy before returning).
 _UP: dict = {}
 _DOWN: dict = {}

@@ -448,7 +448,7 @@ class StreamConfig:
 class AudioBackend(abc.ABC):
     """What the processor needs from an audio I/O backend (``realtime/backend.py:140-268``, reduced to the four calls
     the processor makes).  A backend calls ``callback(input [channels_in, frames], output [channels_out, frames],
-    frames)`` once per buffer; the sound-device backends themselves are out of scope here (DESIGN.md section 8)."""
+    frames)`` once per buffer; the sound-device backends themselves are out of scope here (DESIGN.md section 9)."""
 
     @abc.abstractmethod
     def open_stream(self, config: StreamConfig, callback=None) -> None: ...
