@@ -280,8 +280,9 @@ int tfx_chunk_forward(const float *x, int64_t x_pitch, float *y, int64_t C, int6
 
 /* Block geometry the overlap-save op would use for a [*, T] signal and a K-tap kernel with
  * padding (l, r): *N = FFT block length, *S = hop (valid outputs per block), *F = blocks per row,
- * *native = 1 when the hand-written LDS-FFT path runs (0 = rocFFT path).  For bench/DESIGN
- * traffic models; no GPU needed. */
+ * *native = 1 when a hand-written LDS-FFT path runs -- the three-pass pipeline OR (since round 4) a one-launch kernel --
+ * and 0 for the rocFFT path: callers that price traffic must use tfx_ols_plan_info2's *path (the 20 N/S + 4 model
+ * holds for path 1 only).  No GPU needed. */
 int tfx_ols_plan_info(int64_t K, int64_t T, int64_t pad_left, int64_t pad_right,
                       int64_t *N, int64_t *S, int64_t *F, int *native);
 /* The same for a signal of `dtype` (tfx_ols_plan_info answers for float32).  *path = 2: one launch, the

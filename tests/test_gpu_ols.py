@@ -41,10 +41,13 @@ def test_fftconv_slabbing(monkeypatch):
 @pytest.mark.parametrize("C,T,K", [(1, 70000, 4096), (3, 200001, 9000), (2, 300000, 16384),
                                    (1, 262144, 65536), (3, 600000, 65536), (2, 700003, 66559),
                                    (5, 400000, 40000), (2, 2500000, 65536), (3, 1100000, 5000),
-                                   (2, 200000, 1024), (1, 70000, 16), (3, 150016, 100)])
+                                   (2, 200000, 1024), (1, 70000, 16), (3, 150016, 100), (1, 2_200_000, 140_000)])
 def test_native_ols_vs_rocfft_and_f64(C, T, K, monkeypatch):
     """The hand-written four-step pipeline (two frames per complex FFT) against the rocFFT path
-    and against a float64 FFT convolution; odd frame counts leave an unpaired frame."""
+    and against a float64 FFT convolution; odd frame counts leave an unpaired frame.  The last case (140 000 taps) takes
+    the 2^20-point block on its own -- whose filter spectrum is computed ON THE DEVICE in float32 by the pipeline's forward
+    kernels (olsnative.hip, `TFX_OLS_GPU_SPECTRUM`), like the reference's own float32 `rfft` of the kernel
+    (_fftconv.py:123-124): same 4e-6 of the float64 convolution as the host-float64 spectra of the smaller blocks."""
     from scipy.signal import fftconvolve
     rng = np.random.default_rng(K + T)
     k = (rng.standard_normal(K) * np.exp(-np.arange(K) / (K / 6))).astype(np.float32)

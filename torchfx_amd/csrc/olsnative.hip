@@ -16,8 +16,9 @@
 //          row (N2 = 4096)                                                     -> T[k1][n2]
 //       C  column inverse FFTs over k1; real part -> frame_a's output samples, imaginary part ->
 //          frame_b's, only the first S = N-K+1 (valid) samples are stored      -> y
-//     Hp[k1][k2] = conj(FFT(kf_pad))[k1 + N1 k2] / N is precomputed once per filter on the host
-//     in float64.
+//     Hp[k1][k2] = conj(FFT(kf_pad))[k1 + N1 k2] / N is precomputed once per filter: on the host in float64 for
+//     N = 2^16 / 2^18, ON THE DEVICE in float32 by this pipeline's own forward kernels for N = 2^20 (ols_rowspec4096_kernel;
+//     the reference's rfft of the kernel is float32 too, _fftconv.py:123-124; TFX_OLS_GPU_SPECTRUM=0: host float64).
 //   * every FFT is a Stockham autosort in registers + LDS -- radix 16 x 16 in the column passes (one
 //     LDS exchange), radix 16 x 16 x 4 / 16 x 16 x 16 in the row passes (two exchanges per direction),
 //     radix 4 for N2 = 256; layouts are chosen so all LDS accesses of the column passes are
