@@ -697,14 +697,20 @@ def main() -> None:
             if ols_taps:
                 kk = ols_taps
                 info = E.ols_plan_info(kk, T, (kk - 1, 0))
+                _f = build_filters()
+                _sos = torch.cat([_f[0]._sos, _f[1]._sos])
+                fused = E.sos_fft_conv_plan_info(T, _sos, kk, (kk - 1, 0)) if args.workload == "chain" else None
+                if fused and "CascadeFIR" in desc:      # the recursion-in-pass-A pipeline picks its own block (2^21 on long rows)
+                    info = dict(info, N=fused["N"], S=fused["S"], F=fused["F"])
                 frames = C * info["F"]
                 pairs = (frames + 1) // 2
                 n = info["N"]
                 model["ols_col_fwd16_kernel"] = frames * n * 4.0 + pairs * n * 8.0
                 # the recursion's column pass also reads every row's warm-up (61 of 128 blocks for the cfg-2 cascade at 2^-48)
-                _f = build_filters()
-                wb = -(-max(0, E.sos_fft_conv_warmup(torch.cat([_f[0]._sos, _f[1]._sos]))) // 32)
-                model["ols_col_fwd16_sos_kernel"] = frames * n * 4.0 * (1.0 + min(wb, 128) / 128.0) + pairs * n * 8.0
+                wb = -(-max(0, E.sos_fft_conv_warmup(_sos)) // 32)
+                rows_blk = n // 256 // 32                               # column blocks per row: 128 (4096-sample rows) or 256 (8192)
+                model["ols_col_fwd16_sos_kernel"] = frames * n * 4.0 * (1.0 + min(wb, rows_blk) / rows_blk) + pairs * n * 8.0
+                model["ols_row8192_kernel"] = pairs * n * 16.0
                 model["ols_col_inv16_kernel"] = pairs * n * 8.0 + 4.0 * samples
                 for nm in ("ols_row_kernel", "ols_row1024_kernel", "ols_row4096_kernel"):
                     model[nm] = pairs * n * 16.0

@@ -212,7 +212,7 @@ int tfx_fft_conv_forward_ep(const void *x, void *y, int dtype, int64_t C, int64_
  * thread per 4096-sample row, exact warm-up from zero state), so it costs no pass over the signal of its own.
  *   x DEVICE float32 [C,T]; sos_host HOST float64 [K,6]; kernel_host HOST float32 [taps] FLIPPED;
  *   y DEVICE float32 [C, T+pad_left+pad_right-taps+1];  y_sections: optional DEVICE float64 [K,C,T], every
- *   section's output ("IIR compared section-by-section"), or NULL;  force_block != 0: take the 2^20-point
+ *   section's output ("IIR compared section-by-section"), or NULL;  force_block 1 / 2: take the 2^20 / 2^21-point
  *   block even when the row is shorter than one block (fixture-sized parity tests).
  * tfx_sos_fft_conv_supported answers 1 when the geometry is served (T and T+l+r-taps+1 multiples of 32,
  * K <= 8 sections whose memory fades within 4096 samples, taps that select the 2^20-point block), else 0:
@@ -220,6 +220,11 @@ int tfx_fft_conv_forward_ep(const void *x, void *y, int dtype, int64_t C, int64_
  * ------------------------------------------------------------------------- */
 int tfx_sos_fft_conv_supported(int64_t T, const double *sos_host, int64_t K, int64_t taps,
                                int64_t pad_left, int64_t pad_right, int force_block);
+/* 1 + the geometry the fused pipeline would use (*N block length: 2^20, or 2^21 = 256 rows of 8192 samples on rows of at
+ * least 2^23 samples; *S hop; *F frames per row; *warmup samples), 0 when tfx_sos_fft_conv_supported would say no.  Host-only. */
+int tfx_sos_fft_conv_plan_info(int64_t T, const double *sos_host, int64_t K, int64_t taps,
+                               int64_t pad_left, int64_t pad_right, int force_block,
+                               int64_t *N, int64_t *S, int64_t *F, int64_t *warmup);
 /* samples a row's recursion starts early from zero state inside the column pass (-1: more than 8 sections / no decay) */
 int64_t tfx_sos_fft_conv_warmup(const double *sos_host, int64_t K);
 int tfx_sos_fft_conv_forward(const float *x, float *y, int64_t C, int64_t T,

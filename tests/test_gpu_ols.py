@@ -67,7 +67,7 @@ def test_native_ols_vs_rocfft_and_f64(C, T, K, monkeypatch):
     yn2 = ext().fft_conv_forward(xd, k[::-1].copy(), (K - 1, 0))
     assert torch.equal(yn, yn2)          # slab size does not change results
     # every block size the native path implements (256 x {256, 1024, 4096})
-    for lg in (16, 18, 20):
+    for lg in (16, 18, 20, 21):                          # 21: 256 x 8192 (ols_row8192_kernel)
         if (1 << lg) >= 2 * K and T + K - 1 >= (1 << lg):
             monkeypatch.setenv("TFX_FFT_LOG2N", str(lg))
             yl = ext().fft_conv_forward(xd, k[::-1].copy(), (K - 1, 0))

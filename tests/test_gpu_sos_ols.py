@@ -65,15 +65,17 @@ def test_cfg2_sections_golden_through_the_fused_pass(golden):
     assert torch.equal(y, y2)                                     # the tap instantiation computes the same samples
 
 
-@pytest.mark.parametrize("C,T,K", [(1, 1 << 20, 8193), (3, 2_500_000 // 32 * 32, 66559), (2, 1_100_000 // 32 * 32, 20000)])
-def test_multi_frame_against_oracle_and_staged(C, T, K):
+@pytest.mark.parametrize("block", [1, 2], ids=["2^20", "2^21"])
+@pytest.mark.parametrize("C,T,K", [(1, 1 << 20, 8193), (3, 2_500_000 // 32 * 32, 66559), (2, 1_100_000 // 32 * 32, 20000),
+                                   (1, 4_500_000 // 32 * 32, 66559)])
+def test_multi_frame_against_oracle_and_staged(C, T, K, block):
     """Several frames per row, an odd number of frames (a pair without a second frame), frames that start in the left
-    padding and end beyond the row."""
+    padding and end beyond the row; both block sizes (rows of 4096 and of 8192 samples)."""
     sos = cfg2_sos()
     x = rnd((C, T), 11)
     k = taps(K)
     kf = torch.from_numpy(k[::-1].copy())
-    y = ext().sos_fft_conv_forward(dev(x), sos, kf, (K - 1, 0), force_block=True)
+    y = ext().sos_fft_conv_forward(dev(x), sos, kf, (K - 1, 0), force_block=block)
     assert tuple(y.shape) == (C, T)
     # staged HIP path: cascade kernel (float64 arithmetic, float32 out) then the overlap-save pipeline
     ys, _, _ = ext().sos_forward(dev(x), None, torch.from_numpy(sos), None, None)
@@ -84,15 +86,16 @@ def test_multi_frame_against_oracle_and_staged(C, T, K):
     close(y[:1], ref, TOL_CONV_F32, "fused vs oracle")
 
 
-def test_sections_on_a_multi_frame_row():
+@pytest.mark.parametrize("block", [1, 2], ids=["2^20", "2^21"])
+def test_sections_on_a_multi_frame_row(block):
     """Section taps over rows longer than a frame: every sample of every section against the oracle's float64 recursion
     (rows of frames that overlap by K - 1 samples are written by both frames -- same values to float64 round-off)."""
     sos = cfg2_sos()
-    T = (1 << 20) + 300_000 // 32 * 32
+    T = (block << 20) + 300_000 // 32 * 32
     x = rnd((2, T), 5)
     k = taps(66559)
     y, sec = ext().sos_fft_conv_forward(dev(x), sos, torch.from_numpy(k[::-1].copy()), (66558, 0), return_sections=True,
-                                        force_block=True)
+                                        force_block=block)
     _, _, _, ref = O.sos_forward(x.astype(np.float64), sos, sections=True)
     for s in range(sos.shape[0]):
         close(sec[s], ref[s], TOL_IIR_F64OUT, f"section {s}")

@@ -43,6 +43,8 @@ SIGNATURES = {
     "tfx_fft_conv_forward_ep": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp]),
     "tfx_sos_fft_conv_supported": (_int, [_i64, ctypes.POINTER(_dbl), _i64, _i64, _i64, _i64, _int]),
     "tfx_sos_fft_conv_warmup": (_i64, [ctypes.POINTER(_dbl), _i64]),
+    "tfx_sos_fft_conv_plan_info": (_int, [_i64, ctypes.POINTER(_dbl), _i64, _i64, _i64, _i64, _int, ctypes.POINTER(_i64),
+                                          ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "tfx_sos_fft_conv_forward": (_int, [_vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _int, _vp, _vp]),
     "tfx_normalize_apply": (_int, [_vp, _vp, _int, _i64, _i64, _int, _int, _dbl, _vp, _vp]),
     "tfx_fir_stream_forward": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _i64, _int, _vp, _vp, _vp]),

@@ -35,6 +35,8 @@ void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, c
                       int64_t H = 0, const Epilogue *ep = nullptr);
 bool sos_fft_conv_supported(int64_t T, const double *sos_host, int64_t Ksos, int64_t K, int64_t pad_left, int64_t pad_right, int force);
 int64_t sos_fft_conv_warmup(const double *sos_host, int64_t Ksos);
+bool sos_fft_conv_plan(int64_t T, const double *sos_host, int64_t Ksos, int64_t K, int64_t pad_left, int64_t pad_right, int force,
+                       int64_t *N_out, int64_t *S_out, int64_t *F_out, int64_t *warm_out);
 void sos_fft_conv_forward(const float *x, float *y, int64_t C, int64_t T, const double *sos_host, int64_t Ksos,
                           const float *kernel_host, int64_t K, int64_t pad_left, int64_t pad_right, double *sections, int force,
                           const Epilogue *ep, hipStream_t stream);
@@ -283,6 +285,16 @@ int tfx_sos_fft_conv_supported(int64_t T, const double *sos_host, int64_t K, int
 {
     try {
         return (sos_host && sos_fft_conv_supported(T, sos_host, K, taps, pad_left, pad_right, force_block)) ? 1 : 0;
+    } catch (...) {
+        return 0;
+    }
+}
+
+int tfx_sos_fft_conv_plan_info(int64_t T, const double *sos_host, int64_t K, int64_t taps, int64_t pad_left, int64_t pad_right,
+                               int force_block, int64_t *N, int64_t *S, int64_t *F, int64_t *warmup)
+{
+    try {
+        return (sos_host && sos_fft_conv_plan(T, sos_host, K, taps, pad_left, pad_right, force_block, N, S, F, warmup)) ? 1 : 0;
     } catch (...) {
         return 0;
     }

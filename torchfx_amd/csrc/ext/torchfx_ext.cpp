@@ -302,7 +302,7 @@ std::tuple<Tensor, Tensor> fft_conv_ep_op(const Tensor &x_in, const Tensor &kern
 // zero-state SOS cascade | FFT-mode FIR as one overlap-save pipeline (tfx_sos_fft_conv_forward): y, the statistic of the
 // epilogue and -- on request -- every section's float64 output [K, C, T]
 std::tuple<Tensor, Tensor, Tensor> sos_fft_conv_op(const Tensor &x_in, const Tensor &sos_cpu, const Tensor &kernel, int64_t pad_left,
-                                                   int64_t pad_right, bool sections, bool force_block, double gain, bool clamp,
+                                                   int64_t pad_right, bool sections, int64_t force_block, double gain, bool clamp,
                                                    int64_t stat_mode, bool per_row)
 {
     TORCH_CHECK(x_in.dim() == 2, "sos_fft_conv_forward: x must be [C, T], got ", x_in.sizes());
@@ -319,7 +319,7 @@ std::tuple<Tensor, Tensor, Tensor> sos_fft_conv_op(const Tensor &x_in, const Ten
     const tfx_epilogue ep = make_epilogue(gain, clamp, stat_mode, per_row, stat, x, C);
     c10::hip::HIPGuard guard(x.get_device());
     check_rc(tfx_sos_fft_conv_forward(x.data_ptr<float>(), y.data_ptr<float>(), C, T, sos.data_ptr<double>(), K, k.data_ptr<float>(), taps,
-                                      pad_left, pad_right, sections ? sec.data_ptr<double>() : nullptr, force_block ? 1 : 0, &ep,
+                                      pad_left, pad_right, sections ? sec.data_ptr<double>() : nullptr, (int)force_block, &ep,
                                       stream_of(x)),
              "sos_fft_conv_forward");
     return {y, stat, sec};
@@ -591,7 +591,7 @@ TORCH_LIBRARY(torchfx_hip, m)
     m.def("fft_conv_forward_ep(Tensor x, Tensor kernel, int pad_left, int pad_right, float gain, bool clamp, int stat_mode, "
           "bool per_row) -> (Tensor, Tensor)");
     m.def("sos_fft_conv_forward(Tensor x, Tensor sos_cpu, Tensor kernel, int pad_left, int pad_right, bool sections=False, "
-          "bool force_block=False, float gain=1.0, bool clamp=False, int stat_mode=-1, bool per_row=False) -> (Tensor, Tensor, Tensor)");
+          "int force_block=0, float gain=1.0, bool clamp=False, int stat_mode=-1, bool per_row=False) -> (Tensor, Tensor, Tensor)");
     m.def("normalize_apply(Tensor x, Tensor stat, float peak, int mode, bool per_row) -> Tensor");
     m.def("sum_forward(Tensor[] tensors) -> Tensor");
     m.def("gain_forward(Tensor x, float gain, bool clamp) -> Tensor");

@@ -33,6 +33,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
                        int64_t pl, int64_t pr, int64_t N, hipStream_t stream, const float *hist, int64_t H, const Epilogue *ep,
                        const SosFuseHost *sosf = nullptr);
 void olsnative_wait_warm();
+void olsnative_geometry(int64_t K, int64_t Tn, int64_t pl, int64_t pr, int64_t N, int64_t *S_out, int64_t *F_out);
 bool olsnative_sos_supported(int64_t Ksos, int64_t warm, int64_t K, int64_t Tn, int64_t pl, int64_t pr, int force, int64_t *N_out);
 void sos_plan_info(const double *sos_host, int64_t K, int *precision, int64_t *warmup, double *err_bound);
 int64_t sos_warmup_bits(const double *sos_host, int64_t K, int bits);
@@ -383,6 +384,20 @@ bool sos_fft_conv_supported(int64_t T, const double *sos_host, int64_t Ksos, int
     if (Ksos < 1 || T <= 0 || K < 1) return false;
     int64_t N = 0;
     return Ksos <= 8 && olsnative_sos_supported(Ksos, fused_warmup(sos_host, Ksos), K, T, pad_left, pad_right, force, &N);
+}
+
+// block length, hop, frames per row and warm-up samples the fused pipeline would use; false when it does not serve the geometry
+bool sos_fft_conv_plan(int64_t T, const double *sos_host, int64_t Ksos, int64_t K, int64_t pad_left, int64_t pad_right, int force,
+                       int64_t *N_out, int64_t *S_out, int64_t *F_out, int64_t *warm_out)
+{
+    if (Ksos < 1 || Ksos > 8 || T <= 0 || K < 1) return false;
+    const int64_t warm = fused_warmup(sos_host, Ksos);
+    int64_t N = 0;
+    if (!olsnative_sos_supported(Ksos, warm, K, T, pad_left, pad_right, force, &N)) return false;
+    olsnative_geometry(K, T, pad_left, pad_right, N, S_out, F_out);
+    if (N_out) *N_out = N;
+    if (warm_out) *warm_out = warm;
+    return true;
 }
 
 void sos_fft_conv_forward(const float *x, float *y, int64_t C, int64_t T, const double *sos_host, int64_t Ksos,

@@ -1094,6 +1094,125 @@ ols_row4096_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *_
 }
 
 
+// ---------------------------------------------------------------------------------------------
+// Row pass B for 8192-point rows (N = 2^21 = 256 x 8192): the row transform is ONE radix-2 step in registers around two
+// 4096-point transforms that run one after the other through the same exchange buffer (the construction of
+// ols_lds8192_kernel, olslds.hip): thread j holds z[j + 256 t], t < 32;  a = z_lo + z_hi,  b = (z_lo - z_hi) W8192^n,
+// FFT_4096(a) = even bins, FFT_4096(b) = odd bins, and the mirror image on the way back.  The spectrum row is stored in that
+// order ([even | odd], each half pair-interleaved so that a thread reads two bins per 16-byte load): the order of the bins is
+// irrelevant to a convolution.  Why 8192-sample rows: frames of 2^21 points waste 3.3 % of a block on the 66 559-tap overlap
+// instead of 6.7 %, and a row of the recursion pass (ols_col_fwd16_sos_kernel) pays its warm-up once per 8192 samples.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int row8192_at(int k2)          // position of bin k2 inside a spectrum row
+{
+    const int h = k2 & 1, m = k2 >> 1, t = m >> 8, jj = m & 255;
+    return ((h * 8 + (t >> 1)) * 256 + jj) * 2 + (t & 1);
+}
+inline int row8192_at_host(int k2)
+{
+    const int h = k2 & 1, m = k2 >> 1, t = m >> 8, jj = m & 255;
+    return ((h * 8 + (t >> 1)) * 256 + jj) * 2 + (t & 1);
+}
+
+__global__ void __launch_bounds__(256, 4)
+ols_row8192_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *__restrict__ tw256g,
+                   const cpx *__restrict__ t4log, const cpx *__restrict__ tlo, const cpx *__restrict__ thi,
+                   const cpx *__restrict__ tu, const cpx *__restrict__ w8kg, int64_t Nmask, int P2)
+{
+    using pk::v2f;
+    using pk::v4f;
+    constexpr int N2 = 8192;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cpx *lds = (cpx *)smem;                      // [4096 + 256]
+    cpx *twBc = lds + 4096 + 256;                // [16][16]  W256^(t k)
+    cpx *twAc = twBc + 256;                      // [16][16]  W4096^(t a)
+    const int j = threadIdx.x;
+    twBc[j] = tw256g[((j >> 4) * (j & 15)) & 255];
+    twAc[j] = t4log[j];
+    typedef const float __attribute__((address_space(4))) *cfp;
+    const cfp tuc = (cfp)(uintptr_t)tu;          // uniform per row: W_N^(256 k1 t)
+    const unsigned umask = (unsigned)(Nmask >> 8);
+    const int k1 = (int)(blockIdx.x % OLS_N1);
+    const int64_t p = blockIdx.x / OLS_N1;
+    const v2f wj = ((const v2f *)w8kg)[j];       // W8192^j
+    __syncthreads();                             // tables visible
+    const v2f *twB = (const v2f *)twBc, *twA = (const v2f *)twAc;
+    const v4f *Hq = (const v4f *)(Hp + (int64_t)k1 * N2);
+    const unsigned ml = (unsigned)(k1 * j);
+    const cpx wl = cmul(tlo[ml & 511], thi[ml >> 9]);          // W_N^(k1 j)
+    cpx *base = T + (p * OLS_N1 + k1) * P2;
+    const v2f Wc = {0.92387953251128675613f, 0.38268343236508977173f}, Wr = {0.70710678118654752440f, 0.70710678118654752440f};
+    // wave-uniform row base + one 32-bit lane offset: the 32 addresses of a row are immediates and adds, not 64-bit registers
+    char *rowb = (char *)base;
+    unsigned roff = (unsigned)j * (unsigned)sizeof(cpx);
+    asm volatile("" : "+v"(roff));
+    v2f a[16], b[16];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {         // two batches of loads: 32 registers in flight, not 64
+        v2f lo[8], hi[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = 8 * half + u;
+            lo[u] = *(const v2f *)(rowb + (roff + 2048u * (unsigned)t));
+            hi[u] = *(const v2f *)(rowb + (roff + 2048u * (unsigned)(t + 16)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = 8 * half + u;
+            const unsigned i0 = 2u * ((unsigned)(k1 * t) & umask), i1 = 2u * ((unsigned)(k1 * (t + 16)) & umask);
+            const cpx w0 = cmul(wl, make_float2(tuc[i0], tuc[i0 + 1])), w1 = cmul(wl, make_float2(tuc[i1], tuc[i1 + 1]));   // W_N^(k1 n2)
+            const v2f l = pk::pk_cmul<false>(lo[u], __builtin_bit_cast(v2f, w0)), h = pk::pk_cmul<false>(hi[u], __builtin_bit_cast(v2f, w1));
+            const v2f w = t ? pk::pk_cmul<false>(wj, twB[16 * t + 8]) : wj;                     // W8192^(j + 256 t) = W8192^j W32^t
+            a[t] = l + h;
+            b[t] = pk::pk_cmul<false>(l - h, w);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    pk::fft4096_pk<false>(a, (v2f *)lds, twB, twA, j, Wc, Wr);
+    {
+        v4f q[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) q[m] = Hq[m * 256 + j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            a[2 * m] = pk::pk_cmul<false>(a[2 * m], v2f{q[m].x, q[m].y});
+            a[2 * m + 1] = pk::pk_cmul<false>(a[2 * m + 1], v2f{q[m].z, q[m].w});
+        }
+    }
+    pk::fft4096_pk<false>(b, (v2f *)lds, twB, twA, j, Wc, Wr);
+    {
+        v4f q[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) q[m] = Hq[(8 + m) * 256 + j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            b[2 * m] = pk::pk_cmul<false>(b[2 * m], v2f{q[m].x, q[m].y});
+            b[2 * m + 1] = pk::pk_cmul<false>(b[2 * m + 1], v2f{q[m].z, q[m].w});
+        }
+    }
+    pk::fft4096_pk<true>(a, (v2f *)lds, twB, twA, j, Wc, Wr);
+    pk::fft4096_pk<true>(b, (v2f *)lds, twB, twA, j, Wc, Wr);
+    float wlx = wl.x, wly = wl.y;
+    asm volatile("" : "+v"(wlx), "+v"(wly));     // recompute the row twiddles, do not keep 32 of them live
+    const cpx wl2 = make_float2(wlx, wly);
+    v2f wj2 = wj;
+    asm volatile("" : "+v"(wj2));                // likewise the sixteen W8192^(j + 256 t): two instructions each, not 32 live registers
+    unsigned roff2 = (unsigned)j * (unsigned)sizeof(cpx);
+    asm volatile("" : "+v"(roff2));
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const v2f w = t ? pk::pk_cmul<false>(wj2, twB[16 * t + 8]) : wj2;
+        const v2f bw = pk::pk_cmul<true>(b[t], w);
+        const unsigned i0 = 2u * ((unsigned)(k1 * t) & umask), i1 = 2u * ((unsigned)(k1 * (t + 16)) & umask);
+        const cpx w0 = cmul(wl2, make_float2(tuc[i0], tuc[i0 + 1])), w1 = cmul(wl2, make_float2(tuc[i1], tuc[i1 + 1]));
+        *(v2f *)(rowb + (roff2 + 2048u * (unsigned)t)) = pk::pk_cmul<true>(a[t] + bw, __builtin_bit_cast(v2f, w0));
+        *(v2f *)(rowb + (roff2 + 2048u * (unsigned)(t + 16))) = pk::pk_cmul<true>(a[t] - bw, __builtin_bit_cast(v2f, w1));
+    }
+}
+
 // The spectrum of a long kernel on the device (N = 2^20): the taps go through the forward column pass as a one-frame
 // "signal" (zero fill outside the taps) and then through this FORWARD-ONLY row pass, which leaves conj(X[k1 + 256 k2]) / N at
 // [k1][k2] -- exactly the layout and scaling the row pass multiplies by.  Replaces a float64 host FFT of 2^20 points
@@ -1138,7 +1257,7 @@ ols_rowspec4096_kernel(cpx *__restrict__ T, const cpx *__restrict__ tw256g, cons
 struct NativePlan {
     int64_t N = 0, K = 0;
     int N2 = 0;
-    cpx *Hp = nullptr, *tw256 = nullptr, *twr = nullptr, *tlo = nullptr, *thi = nullptr, *tu = nullptr, *t4lo = nullptr, *t4hi = nullptr;
+    cpx *Hp = nullptr, *tw256 = nullptr, *twr = nullptr, *tlo = nullptr, *thi = nullptr, *tu = nullptr, *t4lo = nullptr, *t4hi = nullptr, *w8k = nullptr;
     float *taps_dev = nullptr;      // device copy of the taps while the spectrum kernels may still read it (N = 2^20)
     cpx *tables = nullptr;          // the one allocation tw256 ... t4hi point into
     hipEvent_t ready = nullptr;     // recorded behind the spectrum kernels: other streams wait for it before they read Hp
@@ -1312,6 +1431,7 @@ static void ols_set_attributes(int dev)
     if (attr_tab[dev]) return;
     for (int a = 0; a < 8; ++a)
         TFX_HIP(hipFuncSetAttribute((const void *)row_tab[a], hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
+    TFX_HIP(hipFuncSetAttribute((const void *)ols_row8192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
     for (int a = 0; a < 2; ++a)
         for (int b = 0; b < 5; ++b) {
             TFX_HIP(hipFuncSetAttribute((const void *)colf_tab[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, (int)OLS_SHM_COL));
@@ -1444,7 +1564,8 @@ static NativePlanPtr get_native_plan(const float *kf, int64_t K, int64_t N, int6
                 for (int k1 = lo; k1 < hi; ++k1)
                     for (int k2 = 0; k2 < N2; ++k2) {
                         const size_t k = (size_t)k1 + (size_t)OLS_N1 * (size_t)k2;
-                        hp[(size_t)k1 * N2 + k2] = make_float2((float)(re[k] * inv_n), (float)(-im[k] * inv_n));
+                        // 8192-point rows keep their bins in the order of ols_row8192_kernel's radix-2 split
+                        hp[(size_t)k1 * N2 + (N2 == 8192 ? row8192_at_host(k2) : k2)] = make_float2((float)(re[k] * inv_n), (float)(-im[k] * inv_n));
                     }
             };
             const unsigned hw = std::thread::hardware_concurrency();
@@ -1469,18 +1590,19 @@ static NativePlanPtr get_native_plan(const float *kf, int64_t K, int64_t N, int6
                 ta[16 * t + a2] = make_float2((float)cos(ang), (float)sin(ang));
             }
         // row-uniform factors: W_N^(64 i) for the 1024-point rows, W_N^(256 i) for the 4096-point rows
-        const std::vector<cpx> parts[7] = {twiddles(256, 256, 1), twiddles(N2, N2, 1), twiddles(N, 512, 1), twiddles(N, N / 512, 512),
-                                           (N2 == 4096) ? twiddles(N, N / 256, 256) : twiddles(N, N / 64, 64), ta, twiddles(4096, 64, 64)};
-        cpx **slots[7] = {&pl->tw256, &pl->twr, &pl->tlo, &pl->thi, &pl->tu, &pl->t4lo, &pl->t4hi};
+        const std::vector<cpx> parts[8] = {twiddles(256, 256, 1), twiddles(N2, N2, 1), twiddles(N, 512, 1), twiddles(N, N / 512, 512),
+                                           (N2 >= 4096) ? twiddles(N, N / 256, 256) : twiddles(N, N / 64, 64), ta, twiddles(4096, 64, 64),
+                                           twiddles(8192, 256, 1)};
+        cpx **slots[8] = {&pl->tw256, &pl->twr, &pl->tlo, &pl->thi, &pl->tu, &pl->t4lo, &pl->t4hi, &pl->w8k};
         std::vector<cpx> all;
-        size_t off[7];
-        for (int i = 0; i < 7; ++i) {
+        size_t off[8];
+        for (int i = 0; i < 8; ++i) {
             off[i] = all.size();
             all.insert(all.end(), parts[i].begin(), parts[i].end());
             all.resize((all.size() + 31) & ~(size_t)31);          // 256-byte aligned sub-tables
         }
         cpx *basep = upload_cpx(all);
-        for (int i = 0; i < 7; ++i) *slots[i] = basep + off[i];
+        for (int i = 0; i < 8; ++i) *slots[i] = basep + off[i];
         pl->tables = basep;
     }
     tr.mark("  twiddle tables");
@@ -1522,18 +1644,22 @@ void olsnative_clear()
 }
 
 
-// block sizes this path implements: N = 256 * N2, N2 in {256, 1024, 4096}
+// block sizes this path implements: N = 256 * N2, N2 in {256, 1024, 4096, 8192}
 bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out)
 {
     if (envi("TFX_OLS_NATIVE", 1) == 0) return false;
     int64_t N = 0;
     const int64_t lg = envi("TFX_FFT_LOG2N", 0);
-    if (lg == 16 || lg == 18 || lg == 20) N = (int64_t)1 << lg;
+    if (lg == 16 || lg == 18 || lg == 20 || lg == 21) N = (int64_t)1 << lg;
     else if (lg != 0) return false;
     else if (K < envi("TFX_OLS_NATIVE_MIN_K", 16)) return false;   // a handful of taps: use the direct kernel / rocFFT
     else if (4 * K <= (1 << 16)) N = 1 << 16;
     else if (2 * K <= (1 << 18) && L < 4 * ((int64_t)1 << 20)) N = 1 << 18;
-    else if (2 * K <= (1 << 20)) N = (int64_t)1 << 20;  // long signals: 4x fewer blocks, less overlap
+    else if (2 * K <= (1 << 20)) {
+        N = (int64_t)1 << 20;                            // long signals: 4x fewer blocks, less overlap
+        // 2^21 = 256 x 8192 on signals of at least four such blocks: half the overlap again (TFX_OLS_N21: 0 never)
+        if (envi("TFX_OLS_N21", 0) != 0 && K > 16384 && L >= ((int64_t)1 << 23)) N = (int64_t)1 << 21;
+    }
     else return false;
     if (N < 2 * K) return false;
     if (L < N) {                                        // signal shorter than one block
@@ -1554,13 +1680,31 @@ bool olsnative_sos_supported(int64_t Ksos, int64_t warm, int64_t K, int64_t Tn, 
 {
     if (envi("TFX_OLS_SOS", 1) == 0) return false;
     if (Ksos < 1 || Ksos > SOSF_MAXK || warm < 0 || warm > envi("TFX_OLS_SOS_MAXWARM", 4096)) return false;
-    const int64_t L = Tn + pl + pr, N = (int64_t)1 << 20;
+    const int64_t L = Tn + pl + pr;
     if (L < K || Tn % 32 != 0 || (L - K + 1) % 32 != 0 || envi("TFX_OLS_ALIGN", 1) == 0) return false;
-    int64_t n = 0;
+    int64_t N = (int64_t)1 << (force == 2 ? 21 : 20);       // force: 1 = the 2^20-point block, 2 = the 2^21-point block, whatever the row length
     if (force) { if (N < 2 * (K + 32)) return false; }
-    else if (!olsnative_supported(K, L, &n) || n != N) return false;
+    else {
+        if (!olsnative_supported(K, L, &N) || (N != ((int64_t)1 << 20) && N != ((int64_t)1 << 21))) return false;
+        // rows of 8192 samples (N = 2^21) halve the warm-up share of the recursion pass: 9.7 against 10.1 ms on the cfg-5 chain
+        // (the plain pipeline is 5 % slower at 2^21 and stays at 2^20; profiles/r05_experiments.txt section 8)
+        if (N == ((int64_t)1 << 20) && envi("TFX_OLS_SOS_N21", 1) != 0 && L >= ((int64_t)1 << 23) && 2 * (K + 32) <= ((int64_t)1 << 21))
+            N = (int64_t)1 << 21;
+    }
     if (N_out) *N_out = N;
     return true;
+}
+
+// hop and frames per row of a block size on this path (what olsnative_forward computes for itself below)
+void olsnative_geometry(int64_t K, int64_t Tn, int64_t pl, int64_t pr, int64_t N, int64_t *S_out, int64_t *F_out)
+{
+    const int64_t L = Tn + pl + pr, Tout = L - K + 1;
+    const bool align = (Tn % 32 == 0) && (Tout % 32 == 0) && envi("TFX_OLS_ALIGN", 1) != 0;
+    const int64_t lead = align ? (32 - (pl % 32)) % 32 : 0;
+    int64_t S = N - (K + lead) + 1;
+    if (align && S > 64) S -= S % 32;
+    if (S_out) *S_out = S;
+    if (F_out) *F_out = ceil_div(Tout, S);
 }
 
 void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const float *kf_host, int64_t K,
@@ -1631,8 +1775,9 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     // B and C find the slab pass A / B just wrote in the cache instead of in HBM and the whole step gains 8-11 % despite
     // the smaller launches -- cfg 4: 9.4-9.5 ms at 3 x 1 GB, 8.4-8.5 ms at 2 x 64 MB; 48 MB x 3 is as good, 4 lanes or
     // >= 128 MB slabs are not (profiles/r03_experiments.txt).  Default: 64 MB slabs on two lanes.
-    // Cascade in pass A: one workgroup per frame pair lives for a whole frame (~190 column blocks), so a launch needs
-    // hundreds of pairs to fill the chip -- slabs of 320 pairs (2.5 GB) on three lanes (profiles/r05_experiments.txt).
+    // Cascade in pass A: one workgroup per frame pair lives for a whole frame (190-320 column blocks), so a launch needs
+    // hundreds of pairs to fill the chip -- slabs of 320 pairs (2.5 GB; N = 2^21: 240 pairs, 3.75 GB) on three lanes
+    // (profiles/r05_experiments.txt).
     int nlanes = (int)(sosf ? envi("TFX_OLS_SOS_STREAMS", 3) : envi("TFX_OLS_STREAMS", 2));
     if (nlanes < 1) nlanes = 1;
     if (nlanes > MAXL) nlanes = MAXL;
@@ -1641,7 +1786,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     if (slab <= 0) {
         // The workspace lives outside PyTorch's caching allocator and is kept between calls (scratch(), released by
         // tfx_clear_caches); TFX_OLS_SLAB_MB bounds a lane's share, never more than 1/8 of the free memory over all lanes.
-        int64_t slab_mb = sosf ? envi("TFX_OLS_SOS_SLAB_MB", 2560) : envi("TFX_OLS_SLAB_MB", 64);
+        int64_t slab_mb = sosf ? envi("TFX_OLS_SOS_SLAB_MB", N == ((int64_t)1 << 21) ? 3840 : 2560) : envi("TFX_OLS_SLAB_MB", 64);
         {
             // the cap follows the memory free when the device is first used (and again after tfx_clear_caches), not at every call:
             // a driver query per step costs tens of microseconds, is not allowed while a stream is capturing, and would make the
@@ -1684,7 +1829,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     SosFuse sosk{};
     bool sos_unit = false;
     if (sosf) {
-        TFX_CHECK(g.N2 == 4096 && align && !hist && sosf->K >= 1 && sosf->K <= SOSF_MAXK && sosf->warm >= 0,
+        TFX_CHECK((g.N2 == 4096 || g.N2 == 8192) && align && !hist && sosf->K >= 1 && sosf->K <= SOSF_MAXK && sosf->warm >= 0,
                   "olsnative_forward: the cascade cannot run inside the column pass here (olsnative_sos_supported)");
         sos_unit = envi("TFX_OLS_SOS_UNIT_B0", 1) != 0 && sos_unit_rows(sosf->sos, sosf->K, sosk.co);
         for (int64_t s = 0; s < sosf->K && !sos_unit; ++s) {
@@ -1742,7 +1887,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
                                x, T, plan->tw256, g, 2 * p0);
             TFX_HIP(hipGetLastError());
         }
-        if (sosf && probe == 0 && sos_sub > 0 && sos_sub < np) {
+        if (sosf && probe == 0 && sos_sub > 0 && sos_sub < np && g.N2 == 4096) {
             // behind the one wide launch of the recursion pass, passes B and C walk the slab in cache-sized pieces so that pass C
             // finds what pass B just wrote in the Infinity Cache (the regime of the plain pipeline's 64 MB slabs).  Measured
             // slower (10.4-10.5 against 9.7-10.2 ms, profiles/r05_experiments.txt): off by default (TFX_OLS_SOS_SUB_PAIRS)
@@ -1765,12 +1910,15 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
         }
         {
             const int64_t nrows = np * OLS_N1;
-            ProfScope ps(g.N2 == 4096 ? "ols_row4096_kernel" : (g.N2 == 1024 && envi("TFX_OLS_ROW_R4", 0) == 0 ? "ols_row1024_kernel" : "ols_row_kernel"), stream);
+            ProfScope ps(g.N2 == 4096 ? "ols_row4096_kernel" : g.N2 == 8192 ? "ols_row8192_kernel" : (g.N2 == 1024 && envi("TFX_OLS_ROW_R4", 0) == 0 ? "ols_row1024_kernel" : "ols_row_kernel"), stream);
             if (g.N2 == 4096 && probe == 0) {
                 hipLaunchKernelGGL(rowk, dim3((unsigned)nrows), dim3(256), (size_t)(4096 + 256 + 512) * sizeof(cpx), stream,
                                    T, plan->Hp, plan->tw256, plan->t4lo, plan->t4hi, plan->tlo, plan->thi, plan->tu,
                                    N - 1, g.P2, np);
             } else if (g.N2 == 4096) {
+            } else if (g.N2 == 8192) {
+                hipLaunchKernelGGL(ols_row8192_kernel, dim3((unsigned)nrows), dim3(256), (size_t)(4096 + 256 + 512) * sizeof(cpx), stream,
+                                   T, plan->Hp, plan->tw256, plan->t4lo, plan->tlo, plan->thi, plan->tu, plan->w8k, N - 1, g.P2);
             }
             else if (g.N2 == 1024 && envi("TFX_OLS_ROW_R4", 0) == 0)
                 hipLaunchKernelGGL(envi("TFX_OLS_PK", 1) ? ols_row1024_kernel<true> : ols_row1024_kernel<false>, dim3((unsigned)ceil_div(nrows, 4)), dim3(256),

@@ -33,7 +33,7 @@ from torchfx_amd import native
 
 __all__ = [
     "biquad_forward", "sos_forward", "sos_bank_forward", "sos_bank_sum_forward", "delay_line_forward",
-    "fir_direct_forward", "fft_conv_forward", "sos_fft_conv_forward", "sos_fft_conv_supported", "sos_fft_conv_warmup", "fir_stream_forward", "chunk_forward", "chunk_supported", "normalize_apply", "Epilogue", "sum_forward", "gain_forward", "quantile_abs", "stat_forward", "normalize_forward",
+    "fir_direct_forward", "fft_conv_forward", "sos_fft_conv_forward", "sos_fft_conv_supported", "sos_fft_conv_warmup", "sos_fft_conv_plan_info", "fir_stream_forward", "chunk_forward", "chunk_supported", "normalize_apply", "Epilogue", "sum_forward", "gain_forward", "quantile_abs", "stat_forward", "normalize_forward",
     "deinterleave_forward", "interleave_forward", "sos_plan_info", "ols_plan_info", "prewarm",
 ]
 
@@ -177,6 +177,18 @@ def sos_fft_conv_supported(T: int, sos, taps: int, padding: tuple[int, int] = (0
         ctypes.c_int64(int(taps)), ctypes.c_int64(int(padding[0])), ctypes.c_int64(int(padding[1])), ctypes.c_int(int(force_block))))
 
 
+def sos_fft_conv_plan_info(T: int, sos, taps: int, padding: tuple[int, int] = (0, 0), force_block: int = 0) -> dict | None:
+    """Block length ``N``, hop ``S``, frames per row ``F`` and warm-up samples of :func:`sos_fft_conv_forward` for rows of
+    ``T`` samples, or None where it does not serve the geometry (``tfx_sos_fft_conv_plan_info``; host-only)."""
+    s = np.ascontiguousarray(_coeff(sos).detach().cpu().numpy(), dtype=np.float64).reshape(-1, 6)
+    n, h, f, w = (ctypes.c_int64(0) for _ in range(4))
+    ok = L.load().tfx_sos_fft_conv_plan_info(ctypes.c_int64(int(T)), s.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                             ctypes.c_int64(s.shape[0]), ctypes.c_int64(int(taps)), ctypes.c_int64(int(padding[0])),
+                                             ctypes.c_int64(int(padding[1])), ctypes.c_int(int(force_block)), ctypes.byref(n),
+                                             ctypes.byref(h), ctypes.byref(f), ctypes.byref(w))
+    return {"N": n.value, "S": h.value, "F": f.value, "warmup": w.value} if ok else None
+
+
 def sos_fft_conv_warmup(sos) -> int:
     """Samples a row's recursion starts early (from zero state) inside the column pass of :func:`sos_fft_conv_forward`."""
     s = np.ascontiguousarray(_coeff(sos).detach().cpu().numpy(), dtype=np.float64).reshape(-1, 6)
@@ -184,16 +196,17 @@ def sos_fft_conv_warmup(sos) -> int:
 
 
 def sos_fft_conv_forward(x: Tensor, sos, kernel, padding: tuple[int, int] = (0, 0), *, return_sections: bool = False,
-                         force_block: bool = False, epilogue: Epilogue | None = None):
+                         force_block: int = 0, epilogue: Epilogue | None = None):
     """A zero-state SOS cascade followed by ``fft_conv1d`` as ONE overlap-save pipeline in the reference's arithmetic:
     float64 DF1 recursion (``_ops.py:119-176`` with ``state=None`` -> ``iir_cpu.cpp:64-159``), the downcast to float32
     (``iir.py:84-184``), float32 overlap-save (``_fftconv.py:70-141``).  The recursion runs inside the forward column
     pass of the transform.  ``x [C,T]`` float32; returns ``y [C, T+l+r-K+1]`` (+ the float64 output of every section
-    ``[K,C,T]`` with ``return_sections``).  Raises when :func:`sos_fft_conv_supported` says no."""
+    ``[K,C,T]`` with ``return_sections``).  ``force_block``: 1 / 2 = take the 2^20 / 2^21-point block whatever the row length
+    (tests at fixture size).  Raises when :func:`sos_fft_conv_supported` says no."""
     ep = epilogue if epilogue is not None else Epilogue()
     y, stat, sec = native.ops().sos_fft_conv_forward(
         x, _coeff(sos), _kernel_host(kernel, x.dtype), int(padding[0]), int(padding[1]), bool(return_sections),
-        bool(force_block), ep.gain, ep.clamp, ep.stat_mode, ep.per_row)
+        int(force_block), ep.gain, ep.clamp, ep.stat_mode, ep.per_row)
     if epilogue is not None:
         epilogue.stat_value = stat
     return (y, sec) if return_sections else y
