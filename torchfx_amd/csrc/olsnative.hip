@@ -17,7 +17,7 @@
 //       C  column inverse FFTs over k1; real part -> frame_a's output samples, imaginary part ->
 //          frame_b's, only the first S = N-K+1 (valid) samples are stored      -> y
 //     Hp[k1][k2] = conj(FFT(kf_pad))[k1 + N1 k2] / N is precomputed once per filter: on the host in float64 for
-//     N = 2^16 / 2^18, ON THE DEVICE in float32 by this pipeline's own forward kernels for N = 2^20 (ols_rowspec4096_kernel;
+//     N = 2^16 / 2^18, ON THE DEVICE in float32 by this pipeline's own forward kernels for N = 2^20 / 2^21 (ols_rowspec4096_kernel, ols_rowspec8192_kernel;
 //     the reference's rfft of the kernel is float32 too, _fftconv.py:123-124; TFX_OLS_GPU_SPECTRUM=0: host float64).
 //   * every FFT is a Stockham autosort in registers + LDS -- radix 16 x 16 in the column passes (one
 //     LDS exchange), radix 16 x 16 x 4 / 16 x 16 x 16 in the row passes (two exchanges per direction),
@@ -1251,6 +1251,52 @@ ols_rowspec4096_kernel(cpx *__restrict__ T, const cpx *__restrict__ tw256g, cons
     for (int t = 0; t < 16; ++t) base[j + 256 * t] = make_float2(u[t].x * inv_n, -u[t].y * inv_n);
 }
 
+// The same for 8192-point rows (N = 2^21): forward-only, conj(X[k1 + 256 k2]) / N written in the bin order
+// ols_row8192_kernel multiplies by (row8192_at).  In place: a thread's 32 loads of the row precede its stores by four barriers.
+__global__ void __launch_bounds__(256, 4)
+ols_rowspec8192_kernel(cpx *__restrict__ T, const cpx *__restrict__ tw256g, const cpx *__restrict__ t4log,
+                       const cpx *__restrict__ tlo, const cpx *__restrict__ thi, const cpx *__restrict__ tu,
+                       const cpx *__restrict__ w8kg, int64_t Nmask, int P2, float inv_n)
+{
+    using pk::v2f;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cpx *lds = (cpx *)smem;
+    cpx *twBc = lds + 4096 + 256;
+    cpx *twAc = twBc + 256;
+    const int j = threadIdx.x;
+    twBc[j] = tw256g[((j >> 4) * (j & 15)) & 255];
+    twAc[j] = t4log[j];
+    typedef const float __attribute__((address_space(4))) *cfp;
+    const cfp tuc = (cfp)(uintptr_t)tu;
+    const unsigned umask = (unsigned)(Nmask >> 8);
+    const int k1 = (int)blockIdx.x;
+    const v2f wj = ((const v2f *)w8kg)[j];
+    __syncthreads();
+    const v2f *twB = (const v2f *)twBc, *twA = (const v2f *)twAc;
+    const unsigned ml = (unsigned)(k1 * j);
+    const cpx wl = cmul(tlo[ml & 511], thi[ml >> 9]);
+    cpx *base = T + (int64_t)k1 * P2;
+    const v2f Wc = {0.92387953251128675613f, 0.38268343236508977173f}, Wr = {0.70710678118654752440f, 0.70710678118654752440f};
+    v2f a[16], b[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const unsigned i0 = 2u * ((unsigned)(k1 * t) & umask), i1 = 2u * ((unsigned)(k1 * (t + 16)) & umask);
+        const cpx w0 = cmul(wl, make_float2(tuc[i0], tuc[i0 + 1])), w1 = cmul(wl, make_float2(tuc[i1], tuc[i1 + 1]));
+        const v2f l = pk::pk_cmul<false>(((const v2f *)base)[j + 256 * t], __builtin_bit_cast(v2f, w0));
+        const v2f h = pk::pk_cmul<false>(((const v2f *)base)[j + 256 * (t + 16)], __builtin_bit_cast(v2f, w1));
+        const v2f w = t ? pk::pk_cmul<false>(wj, twB[16 * t + 8]) : wj;
+        a[t] = l + h;
+        b[t] = pk::pk_cmul<false>(l - h, w);
+    }
+    pk::fft4096_pk<false>(a, (v2f *)lds, twB, twA, j, Wc, Wr);
+    pk::fft4096_pk<false>(b, (v2f *)lds, twB, twA, j, Wc, Wr);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {          // even bins 2 (j + 256 t) from a, odd bins from b
+        base[((0 * 8 + (t >> 1)) * 256 + j) * 2 + (t & 1)] = make_float2(a[t].x * inv_n, -a[t].y * inv_n);
+        base[((1 * 8 + (t >> 1)) * 256 + j) * 2 + (t & 1)] = make_float2(b[t].x * inv_n, -b[t].y * inv_n);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host: plan (tables + permuted spectrum) cache and orchestration
 // ---------------------------------------------------------------------------------------------
@@ -1432,6 +1478,8 @@ static void ols_set_attributes(int dev)
     for (int a = 0; a < 8; ++a)
         TFX_HIP(hipFuncSetAttribute((const void *)row_tab[a], hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
     TFX_HIP(hipFuncSetAttribute((const void *)ols_row8192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
+    TFX_HIP(hipFuncSetAttribute((const void *)ols_rowspec8192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
+    TFX_HIP(hipFuncSetAttribute((const void *)ols_rowspec4096_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
     for (int a = 0; a < 2; ++a)
         for (int b = 0; b < 5; ++b) {
             TFX_HIP(hipFuncSetAttribute((const void *)colf_tab[a][b], hipFuncAttributeMaxDynamicSharedMemorySize, (int)OLS_SHM_COL));
@@ -1459,7 +1507,9 @@ static std::shared_future<void> g_warm[TFX_MAX_DEVICES];
 void olsnative_prewarm()
 {
     const int dev = current_device();
-    const int want_lanes = (int)std::min<int64_t>(MAXL, std::max<int64_t>(1, envi("TFX_OLS_STREAMS", 2)));
+    // the lanes of both pipelines (plain: 2; recursion in pass A: 3) -- a stream created later, behind gigabytes of workspace
+    // allocations, cost 64 ms in the first call (profiles/r05_experiments.txt section 9)
+    const int want_lanes = (int)std::min<int64_t>(MAXL, std::max<int64_t>(1, std::max(envi("TFX_OLS_STREAMS", 2), envi("TFX_OLS_SOS_STREAMS", 3))));
     std::lock_guard<std::mutex> lk(g_warm_mu);
     if (g_warm[dev].valid()) return;                         // started before (its result, or error, is kept)
     if (attr_tab[dev] && (want_lanes <= 1 || lanes_tab[dev].stream[want_lanes - 1])) return;
@@ -1547,7 +1597,7 @@ static NativePlanPtr get_native_plan(const float *kf, int64_t K, int64_t N, int6
     pl->N = N; pl->K = K; pl->N2 = (int)(N / OLS_N1);
     HostTrace tr;
     const int N2 = pl->N2;
-    const bool dev_spectrum = N2 == 4096 && envi("TFX_OLS_GPU_SPECTRUM", 1) != 0;
+    const bool dev_spectrum = (N2 == 4096 || N2 == 8192) && envi("TFX_OLS_GPU_SPECTRUM", 1) != 0;
     if (!dev_spectrum) {
         // spectrum in float64 on the host: conj(FFT(kf zero-padded)) / N   (_fftconv.py:123-124,131 + irfft scaling)
         std::vector<double> re((size_t)N, 0.0), im((size_t)N, 0.0);
@@ -1619,8 +1669,12 @@ static NativePlanPtr get_native_plan(const float *kf, int64_t K, int64_t N, int6
         hipLaunchKernelGGL(colf_tab[1][0], dim3((unsigned)(N2 / OLS_CB)), dim3(512), OLS_SHM_COL, stream,
                            (const float *)pl->taps_dev, pl->Hp, pl->tw256, g, (int64_t)0);
         TFX_HIP(hipGetLastError());
-        hipLaunchKernelGGL(ols_rowspec4096_kernel, dim3(OLS_N1), dim3(256), (size_t)(4096 + 256 + 512) * sizeof(cpx), stream,
-                           pl->Hp, pl->tw256, pl->t4lo, pl->tlo, pl->thi, pl->tu, N - 1, N2, (float)(1.0 / (double)N));
+        if (N2 == 4096)
+            hipLaunchKernelGGL(ols_rowspec4096_kernel, dim3(OLS_N1), dim3(256), (size_t)(4096 + 256 + 512) * sizeof(cpx), stream,
+                               pl->Hp, pl->tw256, pl->t4lo, pl->tlo, pl->thi, pl->tu, N - 1, N2, (float)(1.0 / (double)N));
+        else
+            hipLaunchKernelGGL(ols_rowspec8192_kernel, dim3(OLS_N1), dim3(256), (size_t)(4096 + 256 + 512) * sizeof(cpx), stream,
+                               pl->Hp, pl->tw256, pl->t4lo, pl->tlo, pl->thi, pl->tu, pl->w8k, N - 1, N2, (float)(1.0 / (double)N));
         TFX_HIP(hipGetLastError());
         TFX_HIP(hipEventCreateWithFlags(&pl->ready, hipEventDisableTiming));
         TFX_HIP(hipEventRecord(pl->ready, stream));
