@@ -1114,10 +1114,11 @@ inline int row8192_at_host(int k2)
     return ((h * 8 + (t >> 1)) * 256 + jj) * 2 + (t & 1);
 }
 
+template <int MAP>                               // 0: row = blockIdx; 1: the XCD-aware map of ols_row4096_kernel (a spectrum row is an L2 hit for all pairs but one)
 __global__ void __launch_bounds__(256, 4)
 ols_row8192_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *__restrict__ tw256g,
                    const cpx *__restrict__ t4log, const cpx *__restrict__ tlo, const cpx *__restrict__ thi,
-                   const cpx *__restrict__ tu, const cpx *__restrict__ w8kg, int64_t Nmask, int P2)
+                   const cpx *__restrict__ tu, const cpx *__restrict__ w8kg, int64_t Nmask, int P2, int64_t npairs)
 {
     using pk::v2f;
     using pk::v4f;
@@ -1132,8 +1133,16 @@ ols_row8192_kernel(cpx *__restrict__ T, const cpx *__restrict__ Hp, const cpx *_
     typedef const float __attribute__((address_space(4))) *cfp;
     const cfp tuc = (cfp)(uintptr_t)tu;          // uniform per row: W_N^(256 k1 t)
     const unsigned umask = (unsigned)(Nmask >> 8);
-    const int k1 = (int)(blockIdx.x % OLS_N1);
-    const int64_t p = blockIdx.x / OLS_N1;
+    int k1;
+    int64_t p;
+    if (MAP == 0) {
+        k1 = (int)(blockIdx.x % OLS_N1);
+        p = blockIdx.x / OLS_N1;
+    } else {
+        const unsigned xcd = blockIdx.x & 7u, m = blockIdx.x >> 3;
+        k1 = (int)((m / (unsigned)npairs) * 8u + xcd);
+        p = m % (unsigned)npairs;
+    }
     const v2f wj = ((const v2f *)w8kg)[j];       // W8192^j
     __syncthreads();                             // tables visible
     const v2f *twB = (const v2f *)twBc, *twA = (const v2f *)twAc;
@@ -1477,7 +1486,8 @@ static void ols_set_attributes(int dev)
     if (attr_tab[dev]) return;
     for (int a = 0; a < 8; ++a)
         TFX_HIP(hipFuncSetAttribute((const void *)row_tab[a], hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
-    TFX_HIP(hipFuncSetAttribute((const void *)ols_row8192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
+    TFX_HIP(hipFuncSetAttribute((const void *)ols_row8192_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
+    TFX_HIP(hipFuncSetAttribute((const void *)ols_row8192_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
     TFX_HIP(hipFuncSetAttribute((const void *)ols_rowspec8192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
     TFX_HIP(hipFuncSetAttribute((const void *)ols_rowspec4096_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 256 + 512) * sizeof(cpx))));
     for (int a = 0; a < 2; ++a)
@@ -1971,8 +1981,9 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
                                    N - 1, g.P2, np);
             } else if (g.N2 == 4096) {
             } else if (g.N2 == 8192) {
-                hipLaunchKernelGGL(ols_row8192_kernel, dim3((unsigned)nrows), dim3(256), (size_t)(4096 + 256 + 512) * sizeof(cpx), stream,
-                                   T, plan->Hp, plan->tw256, plan->t4lo, plan->tlo, plan->thi, plan->tu, plan->w8k, N - 1, g.P2);
+                hipLaunchKernelGGL(rowmap == 0 ? ols_row8192_kernel<0> : ols_row8192_kernel<1>, dim3((unsigned)nrows), dim3(256),
+                                   (size_t)(4096 + 256 + 512) * sizeof(cpx), stream,
+                                   T, plan->Hp, plan->tw256, plan->t4lo, plan->tlo, plan->thi, plan->tu, plan->w8k, N - 1, g.P2, np);
             }
             else if (g.N2 == 1024 && envi("TFX_OLS_ROW_R4", 0) == 0)
                 hipLaunchKernelGGL(envi("TFX_OLS_PK", 1) ? ols_row1024_kernel<true> : ols_row1024_kernel<false>, dim3((unsigned)ceil_div(nrows, 4)), dim3(256),
