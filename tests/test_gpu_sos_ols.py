@@ -101,6 +101,45 @@ def test_sections_on_a_multi_frame_row(block):
         close(sec[s], ref[s], TOL_IIR_F64OUT, f"section {s}")
 
 
+@pytest.mark.parametrize("block", [1, 2], ids=["2^20", "2^21"])
+@pytest.mark.parametrize("nsec", [1, 2, 3, 5, 6, 8])
+def test_every_section_count(nsec, block):
+    """One kernel instantiation per section count (1 ... 8; up to 4 sections two workgroups per CU, above one): each against
+    the staged HIP path and, section by section, against the oracle's float64 recursion."""
+    import scipy.signal as sg
+    rows = [sg.butter(2, 0.05 + 0.07 * i, "lowpass" if i % 2 == 0 else "highpass", output="sos")[0] for i in range(nsec)]
+    sos = np.ascontiguousarray(np.vstack(rows))
+    if not ext().sos_fft_conv_supported(1 << 20, sos, 9001, (9000, 0), force_block=block):
+        pytest.skip("this cascade's memory is longer than a row")
+    T = (block << 20) + 64_000
+    x = rnd((2, T), 40 + nsec)
+    k = taps(9001)
+    kf = torch.from_numpy(k[::-1].copy())
+    y, sec = ext().sos_fft_conv_forward(dev(x), sos, kf, (9000, 0), return_sections=True, force_block=block)
+    y2 = ext().sos_fft_conv_forward(dev(x), sos, kf, (9000, 0), force_block=block)
+    assert torch.equal(y, y2)
+    _, _, _, ref = O.sos_forward(x.astype(np.float64), sos, sections=True)
+    for s in range(nsec):
+        close(sec[s], ref[s], TOL_IIR_F64OUT, f"section {s} of {nsec}")
+    ys, _, _ = ext().sos_forward(dev(x), None, torch.from_numpy(sos), None, None)
+    ys = ext().fft_conv_forward(ys, kf, (9000, 0))
+    close(y, ys.cpu().numpy(), 2e-6, "fused vs staged HIP")
+
+
+def test_cascade_without_a_unit_b0_form():
+    """A section with b0 = 0 (a pure delay in the numerator) has no unit-b0 form: the kernel's plain instantiation runs."""
+    sos = np.array([[0.0, 0.5, 0.25, 1.0, -0.6, 0.2], [0.3, 0.1, 0.0, 1.0, 0.4, 0.1]])
+    T = (1 << 20) + 32_000
+    x = rnd((1, T), 9)
+    k = taps(9001)
+    kf = torch.from_numpy(k[::-1].copy())
+    y, sec = ext().sos_fft_conv_forward(dev(x), sos, kf, (9000, 0), return_sections=True, force_block=1)
+    _, _, _, ref = O.sos_forward(x.astype(np.float64), sos, sections=True)
+    for s in range(2):
+        close(sec[s], ref[s], TOL_IIR_F64OUT, f"section {s}")
+    close(y, O.chain_forward(x, sos, [k[::-1].copy()]), TOL_CONV_F32, "chain")
+
+
 def test_epilogue_rides_along():
     sos = cfg2_sos()
     T = 1_200_000 // 32 * 32
