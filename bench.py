@@ -500,7 +500,9 @@ def main() -> None:
     # TFX_BENCH_SHARE_DEVICE=1 (development only): every rank uses cuda:0 and the collectives go over
     # gloo, so the N > 1 control flow can be exercised on a one-GPU box; never set by the driver
     share = os.environ.get("TFX_BENCH_SHARE_DEVICE", "0") == "1"
-    local_dev = 0 if share else local
+    # one rank per GPU: LOCAL_RANK indexes the visible devices; a launcher that isolates each rank with HIP_VISIBLE_DEVICES leaves one
+    # visible device per rank (index 0) -- the UUID check before the line is printed catches ranks that really share a GPU
+    local_dev = 0 if (share or torch.cuda.device_count() <= local) else local
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     if world > 1:
@@ -620,10 +622,7 @@ def main() -> None:
                 sms, sgroups, skern, sout = batch_timed(sstep, sync, lib, 5, 5)
                 n = xs.numel()
                 ent = {"workload": sdesc, "channels": C, "seconds": sec, "ms_per_step": round(sms, 4),
-                       "timing": f"median of 5 groups of {batch_timed.per_batch} back-to-back steps (>= 20 ms per group), wall clock, device "
-                                 "synchronised around each group, no event profiling; kernel_ms_per_step from one more group with "
-                                 "the library's HIP events",
-                       "ms_per_step_groups": sgroups,
+                       "steps_per_group": batch_timed.per_batch, "ms_per_step_groups": sgroups,
                        "Msamples_per_s": round(n / sms / 1e3, 1), "bound": bound, "kernel_ms_per_step": skern}
                 if bound == "hbm":
                     ent["achieved_GBps"] = round(8.0 * n / (sms * 1e-3) / 1e9, 1)
@@ -879,6 +878,8 @@ def main() -> None:
         if stages:
             if first_call_ms is not None:
                 stages["first_ys_ms"] = round(first_call_ms, 2)       # first (Wave(x) | ...).ys of the process, planning included
+            stages["_timing"] = ("every stage: median of 5 groups of back-to-back steps (>= 20 ms per group), wall clock, device synchronised "
+                                 "around each group, no event profiling; kernel_ms_per_step from one more group with the library's HIP events")
             line["stages"] = stages
         if variants:
             line["variants"] = variants
