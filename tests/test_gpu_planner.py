@@ -229,6 +229,30 @@ def test_default_plan_runs_the_recursion_inside_the_overlap_save_pass():
     close(wo.ys, ref[:, :-7], TOL_CONV_F32, "staged at an odd length")
 
 
+def test_gain_and_normalize_ride_on_the_cascade_fir_step():
+    """`iir | iir | fir | Gain | Normalize` on long rows: ONE producing step (Epilogued around CascadeFIR) + the apply pass;
+    equal to the same pipeline with every fusion off (the reference's staging) to the FIR tolerance."""
+    import torchfx_amd as fx
+    from torchfx_amd import effect as E
+    from torchfx_amd import filter as F
+    T = 4_200_000 // 32 * 32
+    x = rnd((2, T), 21)
+    f1, f2 = F.LoButterworth(2000, order=6, fs=48000), F.ParametricEQ(frequency=1000, q=2.0, gain=3.0, fs=48000)
+    rev = F.FIR(reverb_ir(65536))
+
+    def pipe(reference):
+        w = fx.Wave(x, 48000, device=DEV)
+        if reference:
+            w.fuse_fir = w.fuse_spectral = w.fuse_recursive = w.fuse_epilogue = w.fuse_gain = False
+        return w | f1 | f2 | rev | E.Gain(2.0, gain_type="amplitude", clamp=True) | E.Normalize(peak=0.5)
+    wp = pipe(False)
+    plan = wp.plan()
+    assert [type(m).__name__ for m in plan] == ["Epilogued"] and type(plan[0].producer).__name__ == "CascadeFIR"
+    wr = pipe(True)
+    assert len(wr.plan()) == 4
+    close(wp.ys, wr.ys.cpu().numpy(), TOL_CONV_F32, "epilogue on the fused step vs staged")
+
+
 def test_module_shapes_dtype_and_state_rules(golden):
     from torchfx_amd import filter as F
     g = golden("iir_shapes")
