@@ -202,3 +202,38 @@ def test_no_kernel_spills_registers_to_scratch():
                     bad.append((os.path.basename(path), name[:90], int(m.group(1))))
     assert seen > 50, f"only {seen} kernels in the reports"
     assert not bad, f"kernels with scratch memory: {bad}"
+
+
+def test_tuning_knobs_are_read_once_per_process_and_reloadable():
+    """the library reads its TFX_* knobs ONCE per process (a dispatch asks for about ten of them); a host that
+    changes one at run time calls `tfx_env_reload()` -- or sets TFX_ENV_DYNAMIC=1 before the first call, which this test
+    suite does (tests/conftest.py).  Checked in a fresh process without that switch, on a host-only planning query."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "os.environ.pop('TFX_ENV_DYNAMIC', None); os.environ.pop('TFX_FFT_LOG2N', None)\n"
+        "from torchfx_amd import _lib, torchfx_ext as E\n"
+        "lib = _lib.load()\n"
+        "n = lambda: E.ols_plan_info(66559, 28_800_000, (66558, 0))['N']\n"
+        "a = n()\n"
+        "os.environ['TFX_FFT_LOG2N'] = '18'\n"
+        "b = n()\n"
+        "lib.tfx_env_reload()\n"
+        "c = n()\n"
+        "os.environ['TFX_ENV_DYNAMIC'] = '1'; os.environ['TFX_FFT_LOG2N'] = '20'\n"
+        "d0 = n()\n"
+        "lib.tfx_env_reload()\n"
+        "os.environ['TFX_FFT_LOG2N'] = '18'\n"
+        "d1 = n()\n"
+        "print(a, b, c, d0, d1)\n" % root)
+    env = {k: v for k, v in os.environ.items() if k not in ("TFX_ENV_DYNAMIC", "TFX_FFT_LOG2N")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    a, b, c, d0, d1 = (int(v) for v in r.stdout.split()[-5:])
+    assert a == 1 << 20 and b == 1 << 20          # the second lookup comes from the table, not from the environment
+    assert c == 1 << 18                           # ... until the host asks for a reload
+    assert d0 == 1 << 18 and d1 == 1 << 18        # the dynamic switch itself is read at reload; then every lookup is fresh
