@@ -1,6 +1,6 @@
 """(Wave | LoButterworth-6 | ParametricEQ | FIR-1024).ys on 64 x 2.88 M: folded into one overlap-save pass vs cascade + FIR (development)."""
-import os
-os.environ.setdefault("TFX_ENV_DYNAMIC", "1")      # this tool flips TFX_* knobs inside one process, sys, time
+import os, sys, time
+os.environ.setdefault("TFX_ENV_DYNAMIC", "1")      # this tool flips TFX_* knobs inside one process
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench

@@ -1,6 +1,6 @@
 """16 384-point radix-4 LDS overlap-save (TFX_OLS_LDS16K_R4=2) against a float64 FFT convolution (development)."""
-import os
-os.environ.setdefault("TFX_ENV_DYNAMIC", "1")      # this tool flips TFX_* knobs inside one process, sys
+import os, sys
+os.environ.setdefault("TFX_ENV_DYNAMIC", "1")      # this tool flips TFX_* knobs inside one process
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from scipy.signal import fftconvolve

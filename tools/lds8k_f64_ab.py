@@ -1,6 +1,6 @@
 """float64: 4096- vs 8192-point block of the one-launch overlap-save kernel (development)."""
-import os
-os.environ.setdefault("TFX_ENV_DYNAMIC", "1")      # this tool flips TFX_* knobs inside one process, sys
+import os, sys
+os.environ.setdefault("TFX_ENV_DYNAMIC", "1")      # this tool flips TFX_* knobs inside one process
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tools.quick_bench import timed, E

@@ -1,6 +1,6 @@
 """[2, 44100] (the reference's test / benchmark shape): one-launch kernels against each other, wall us per call (development)."""
-import os
-os.environ.setdefault("TFX_ENV_DYNAMIC", "1")      # this tool flips TFX_* knobs inside one process, sys, time
+import os, sys, time
+os.environ.setdefault("TFX_ENV_DYNAMIC", "1")      # this tool flips TFX_* knobs inside one process
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from torchfx_amd import torchfx_ext as E

@@ -1,6 +1,6 @@
 """Cascade kernel: time against the number of sections (1 ... 4 of cfg 2's), old structure vs LDS-DMA prefetch (development)."""
-import os
-os.environ.setdefault("TFX_ENV_DYNAMIC", "1")      # this tool flips TFX_* knobs inside one process, sys
+import os, sys
+os.environ.setdefault("TFX_ENV_DYNAMIC", "1")      # this tool flips TFX_* knobs inside one process
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from scipy.signal import butter
