@@ -412,6 +412,8 @@ void sos_fft_conv_forward(const float *x, float *y, int64_t C, int64_t T, const 
     if (C == 0) return;
     TFX_CHECK(C > 0 && T > 0, "sos_fft_conv_forward: bad shape");
     TFX_CHECK(x && y && kernel_host && sos_host, "sos_fft_conv_forward: null pointer");
+    TFX_CHECK(((uintptr_t)x & 15) == 0, "sos_fft_conv_forward: x must be 16-byte aligned (rows are read 16 bytes at a time)");
+    olsnative_wait_warm();               // a set-up helper started by tfx_prewarm finishes before anything here is enqueued
     int64_t N = 0;
     const int64_t warm = Ksos <= 8 ? fused_warmup(sos_host, Ksos) : -1;
     TFX_CHECK(olsnative_sos_supported(Ksos, warm, K, T, pad_left, pad_right, force, &N),
