@@ -38,8 +38,15 @@ def test_traffic_file_is_consistent():
     # Tight bounds per row-map mode (advisor, round 3): a launch reads its slab once plus the 8.4 MB spectrum at least once
     # (XCD-aware map, PMC round 4: slab + 1.08 spectra) and at most ~2.2 times (plain map, the default for 8-pair slabs: every
     # spectrum row is re-fetched by about every fourth of the 8 pairs that use it); anything above means workspace re-reads.
+    # Round 5: the default chain runs 2^21-point blocks in slabs of 160 frame pairs with the XCD-aware row map: a launch reads its
+    # slab once plus the 16.8 MB spectrum about once (PMC: 1.1 spectra); the plain pipeline (fftconv / the fold) keeps 8-pair slabs.
     slab = mc["row_pass_slab_GB_per_launch"]
-    pairs = round(slab * 1e9 / (256 * 4096 * 8))
-    spectrum = 256 * 4096 * 8 / 1e9
+    spectrum = 256 * 8192 * 8 / 1e9
+    pairs = round(slab * 1e9 / (256 * 8192 * 8))
     extra = (mc["measured_read"] - slab) / spectrum
-    assert pairs == 8 and 0.95 <= extra <= 2.4, (pairs, extra)
+    assert pairs == 160 and 0.9 <= extra <= 2.0, (pairs, extra)
+    mp = tr["fftconv"]["model_check"]
+    slab4 = mp["row_pass_slab_GB_per_launch"]
+    pairs4 = round(slab4 * 1e9 / (256 * 4096 * 8))
+    extra4 = (mp["measured_read"] - slab4) / (256 * 4096 * 8 / 1e9)
+    assert pairs4 == 8 and 0.95 <= extra4 <= 2.4, (pairs4, extra4)

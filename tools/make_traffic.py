@@ -62,7 +62,7 @@ def main() -> None:
         alg = 8.0 * 64 * seconds * 48000
         out[wl] = {"seconds": seconds, "bytes_per_step": round(total), "algorithmic_bytes_per_step": alg,
                    "traffic_over_algorithmic": round(total / alg, 3), "per_kernel_GB_per_launch": per}
-        row = per.get("ols_row4096_kernel")
+        row = per.get("ols_row4096_kernel") or per.get("ols_row8192_kernel")
         if row:       # the row pass touches its slab exactly once each way: known bytes
             ols = under["config"]["overlap_save"]
             frames = 64 * ols["blocks_per_row"]
