@@ -126,6 +126,40 @@ def test_every_section_count(nsec, block):
     close(y, ys.cpu().numpy(), 2e-6, "fused vs staged HIP")
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_random_geometry_against_the_staged_path(seed):
+    """Seeded fuzz: rows, row length (a multiple of 32), taps, sections, block size and left padding drawn at random; the fused
+    pipeline against cascade kernel + overlap-save (same arithmetic, different kernels) and, on one row, against the oracle."""
+    import scipy.signal as sg
+    rng = np.random.default_rng(1000 + seed)
+    block = int(rng.integers(1, 3))
+    C = int(rng.integers(1, 5))
+    T = int(rng.integers((block << 20) // 32, (3 << 20) * block // 32)) * 32
+    K = int(rng.integers(8193, 90_000))
+    nsec = int(rng.integers(1, 9))
+    rows = []
+    for i in range(nsec):
+        f = float(rng.uniform(0.03, 0.6))
+        kind = ["lowpass", "highpass"][int(rng.integers(0, 2))]
+        rows.append(sg.butter(2, f, kind, output="sos")[0])
+    sos = np.ascontiguousarray(np.vstack(rows))
+    extra = int(rng.integers(0, 4)) * 32                       # more causal padding than K - 1 (output longer than the row)
+    pad = (K - 1 + extra, 0)
+    if not ext().sos_fft_conv_supported(T, sos, K, pad, force_block=block):
+        pytest.skip("geometry not served (memory longer than a row)")
+    x = rnd((C, T), 2000 + seed)
+    k = taps(K, seed=seed)
+    kf = torch.from_numpy(k[::-1].copy())
+    y = ext().sos_fft_conv_forward(dev(x), sos, kf, pad, force_block=block)
+    assert tuple(y.shape) == (C, T + extra)
+    ys, _, _ = ext().sos_forward(dev(x), None, torch.from_numpy(sos), None, None)
+    ys = ext().fft_conv_forward(ys, kf, pad)
+    close(y, ys.cpu().numpy(), 2e-6, f"fused vs staged (block 2^{19 + block}... C={C} T={T} K={K} sections={nsec} pad+{extra})")
+    yi, _, _ = O.iir_module_forward(x[:1], sos)
+    ref = O.fft_conv1d(yi, k[::-1].copy(), pad)
+    close(y[:1], ref, TOL_CONV_F32, "fused vs oracle")
+
+
 def test_cascade_without_a_unit_b0_form():
     """A section with b0 = 0 (a pure delay in the numerator) has no unit-b0 form: the kernel's plain instantiation runs."""
     sos = np.array([[0.0, 0.5, 0.25, 1.0, -0.6, 0.2], [0.3, 0.1, 0.0, 1.0, 0.4, 0.1]])
