@@ -217,8 +217,8 @@ def test_default_plan_runs_the_recursion_inside_the_overlap_save_pass():
     sos = np.vstack([f1._sos.numpy(), f2._sos.numpy()])
     ref = O.chain_forward(xl, sos, [fir.kernel.numpy().reshape(-1), rev.kernel.numpy().reshape(-1)])
     close(y, ref, TOL_CONV_F32, "default plan, recursion inside pass A")
-    y2, sec = plan[0](dev(xl), return_sections=True)
-    assert torch.equal(y2, y)
+    y2, sec = plan[0](dev(xl), return_sections=True)                # one row = a handful of frame pairs: `.ys` ran the two staged launches,
+    close(y2, y.cpu().numpy(), 2e-6, "fused pass vs the staged pair")  # the section taps come from the fused pass (same arithmetic)
     _, _, _, rs = O.sos_forward(xl.astype(np.float64), sos, sections=True)
     for s in range(4):
         close(sec[s], rs[s], TOL_IIR_F64OUT, f"section {s}")
@@ -248,6 +248,7 @@ def test_gain_and_normalize_ride_on_the_cascade_fir_step():
     wp = pipe(False)
     plan = wp.plan()
     assert [type(m).__name__ for m in plan] == ["Epilogued"] and type(plan[0].producer).__name__ == "CascadeFIR"
+    plan[0].producer.MIN_PAIRS = 1                                   # two rows: make the fused pass run (small batches take the staged pair)
     wr = pipe(True)
     assert len(wr.plan()) == 4
     close(wp.ys, wr.ys.cpu().numpy(), TOL_CONV_F32, "epilogue on the fused step vs staged")

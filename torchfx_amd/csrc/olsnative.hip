@@ -1718,7 +1718,9 @@ bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out)
     else if (lg != 0) return false;
     else if (K < envi("TFX_OLS_NATIVE_MIN_K", 16)) return false;   // a handful of taps: use the direct kernel / rocFFT
     else if (4 * K <= (1 << 16)) N = 1 << 16;
-    else if (2 * K <= (1 << 18) && L < 4 * ((int64_t)1 << 20)) N = 1 << 18;
+    // rows shorter than 4 M samples: 2^18 points -- but from ~24 K taps the 2^20-point block wins there too once a row holds two
+    // of them (64 x 2.88 M: 65 536 taps 1.01-1.07 -> 0.86 ms, 32 768 taps 0.92 -> 0.85; at 20 000 taps equal; r05 experiments section 11)
+    else if (2 * K <= (1 << 18) && L < 4 * ((int64_t)1 << 20)) N = (K > envi("TFX_OLS_N20_MINK", 24576) && L >= ((int64_t)1 << 21)) ? ((int64_t)1 << 20) : (1 << 18);
     else if (2 * K <= (1 << 20)) {
         N = (int64_t)1 << 20;                            // long signals: 4x fewer blocks, less overlap
         // 2^21 = 256 x 8192 on signals of at least four such blocks: half the overlap again (TFX_OLS_N21: 0 never)

@@ -100,6 +100,8 @@ class CascadeFIR(nn.Module):
     Rows the kernel does not serve (another dtype, a length that is not a multiple of 32, a misaligned view, a host tensor)
     run the two steps staged -- same arithmetic, two launches."""
 
+    MIN_PAIRS = 256          # frame pairs below which the staged pair of launches is the faster plan (profiles/r05_experiments.txt section 11)
+
     def __init__(self, table: CascadeTable, fir: nn.Module) -> None:
         super().__init__()
         self._table, self.fir = table, fir
@@ -122,8 +124,12 @@ class CascadeFIR(nn.Module):
         taps = self.fir.kernel.reshape(-1)
         k = int(taps.numel())
         rows = x.reshape(-1, x.shape[-1])
-        if (x.is_cuda and x.dtype == torch.float32 and rows.is_contiguous() and rows.data_ptr() % 16 == 0
-                and torchfx_ext.sos_fft_conv_supported(int(rows.shape[-1]), self._table.sos, k, (k - 1, 0))):
+        info = None
+        if x.is_cuda and x.dtype == torch.float32 and rows.is_contiguous() and rows.data_ptr() % 16 == 0:
+            info = torchfx_ext.sos_fft_conv_plan_info(int(rows.shape[-1]), self._table.sos, k, (k - 1, 0))
+        # the recursion pass runs one workgroup per frame PAIR for a whole frame: it needs a few hundred pairs in flight (64 ch x 600 s:
+        # 480); a small batch is faster as two launches (cascade kernel, then the plain pipeline) -- unless sections are asked for
+        if info is not None and (return_sections or int(rows.shape[0]) * info["F"] >= 2 * self.MIN_PAIRS):
             out = torchfx_ext.sos_fft_conv_forward(rows, self._table.sos, taps, (k - 1, 0), return_sections=return_sections,
                                                    epilogue=epilogue)
             if return_sections:
