@@ -19,7 +19,6 @@ CFG2_SOS = None
 
 
 def cfg2_sos():
-    import scipy.signal as sg
     global CFG2_SOS
     if CFG2_SOS is None:
         from torchfx_amd import filter as F
