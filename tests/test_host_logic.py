@@ -511,6 +511,31 @@ def test_default_plan_of_the_headline_chain_is_one_cascade_fir_step():
     assert type(p[0]).__name__ == "Epilogued" and type(p[0].producer).__name__ == "CascadeFIR"
 
 
+def test_cascade_fir_module_staged_fallback(oracle_backend, golden):
+    """`CascadeFIR` where its kernel does not serve the rows (here: host tensors, via the test backend): the two staged launches,
+    fresh state every call, epilogue handed to the FIR -- the reference's staging of `iir... | fir` (wave.py:207-239)."""
+    from torchfx_amd.effect import Gain
+    from torchfx_amd.filter._sos import CascadeTable
+    from torchfx_amd.filter.fused import CascadeFIR
+    from torchfx_amd import torchfx_ext as E
+    g = golden("chain")
+    f1, f2 = F.LoButterworth(2000, order=6, fs=48000), F.ParametricEQ(frequency=1000, q=2.0, gain=3.0, fs=48000)
+    fir = F.FIR(np.hanning(129) / np.hanning(129).sum())
+    m = CascadeFIR(CascadeTable.gather([f1, f2]), fir)
+    x = torch.from_numpy(g["xc"])
+    oracle_backend.calls.clear()
+    y = m(x)
+    assert [c[0] for c in oracle_backend.calls] == ["sos_forward", "fft_conv_forward"]
+    ref = fir(F.FusedSOSCascade(f1, f2)(x))
+    assert torch.equal(y, ref) and torch.equal(m(x), y)                 # stateless: a second call starts from zero state again
+    ep = E.Epilogue(gain=0.5, clamp=True)
+    assert torch.equal(m(x, epilogue=ep), torch.clamp(ref * 0.5, -1.0, 1.0))
+    assert m(x[0]).shape == x[0].shape and m(x[None]).shape == x[None].shape
+    with pytest.raises(RuntimeError, match="section taps"):
+        m(x, return_sections=True)
+    assert m._sos.shape == (4, 6) and m.fs == 48000
+
+
 def _gain_chain(wave):
     from scipy.signal import firwin
     irg = np.random.default_rng(2).standard_normal(2049) * np.exp(-np.arange(2049) / 300.0)
