@@ -6,6 +6,7 @@
  * tests/test_capi_exports.py builds and runs it that way).  With `--gpu` it also filters a buffer on device 0
  * through tfx_sos_forward using the HIP runtime for memory (link with -lamdhip64 and define WITH_HIP).
  */
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -40,6 +41,13 @@ int main(int argc, char **argv)
         return 1;
     }
     printf("overlap-save plan: N %lld hop %lld blocks/row %lld native %d\n", (long long)N, (long long)S, (long long)F, native);
+    {   /* the fused `cascade | FIR` step: host-only planning queries */
+        int64_t fn = 0, fs = 0, ff = 0, fw = 0;
+        const int ok = tfx_sos_fft_conv_plan_info(28800000, &SOS[0][0], 2, 66559, 66558, 0, 0, &fn, &fs, &ff, &fw);
+        printf("fused cascade|FIR plan: served %d block %lld hop %lld frames/row %lld warm-up %lld; 28800001-sample rows served %d\n", ok,
+               (long long)fn, (long long)fs, (long long)ff, (long long)fw,
+               tfx_sos_fft_conv_supported(28800001, &SOS[0][0], 2, 66559, 66558, 0, 0));
+    }
     /* error path: a null coefficient pointer is an error code, not a crash */
     if (tfx_sos_plan_info(NULL, 2, &precision, &warm, &bound) == 0) {
         fprintf(stderr, "expected an error for a null SOS pointer\n");
@@ -61,6 +69,25 @@ int main(int argc, char **argv)
         hipDeviceSynchronize();
         hipMemcpy(hy, dy, sizeof(float) * C * T, hipMemcpyDeviceToHost);
         printf("impulse response head: %.6f %.6f %.6f %.6f\n", hy[0], hy[1], hy[2], hy[3]);
+        {   /* the same cascade inside the overlap-save pipeline (tfx_sos_fft_conv_forward) with a 9001-tap FIR whose only non-zero
+             * tap is the LAST of the flipped kernel, i.e. h[0] = 1: the output must equal the cascade's */
+            const int64_t Kf = 9001;
+            float *taps = (float *)calloc((size_t)Kf, sizeof(float)), *hz = (float *)malloc(sizeof(float) * C * T);
+            float *dz = NULL;
+            double worst = 0.0;
+            taps[Kf - 1] = 1.0f;
+            if (hipMalloc((void **)&dz, sizeof(float) * C * T) != hipSuccess) return 2;
+            if (!tfx_sos_fft_conv_supported(T, &SOS[0][0], 2, Kf, Kf - 1, 0, 1)) { fprintf(stderr, "fused step not served\n"); return 1; }
+            if (tfx_sos_fft_conv_forward(dx, dz, C, T, &SOS[0][0], 2, taps, Kf, Kf - 1, 0, NULL, 1, NULL, NULL) != 0) {
+                fprintf(stderr, "tfx_sos_fft_conv_forward: %s\n", tfx_last_error());
+                return 1;
+            }
+            hipDeviceSynchronize();
+            hipMemcpy(hz, dz, sizeof(float) * C * T, hipMemcpyDeviceToHost);
+            for (int64_t i = 0; i < C * T; ++i) { const double d = fabs((double)hz[i] - (double)hy[i]); if (d > worst) worst = d; }
+            printf("fused cascade|identity FIR vs cascade: max difference %.3g\n", worst);
+            hipFree(dz); free(taps); free(hz);
+        }
         hipFree(dx); hipFree(dy); free(hx); free(hy);
     }
 #else

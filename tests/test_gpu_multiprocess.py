@@ -286,3 +286,6 @@ def test_plain_c_host_filters_on_the_device(tmp_path):
                     [1.0089, -1.9636, 0.9695, 1.0, -1.9636, 0.9784]])
     imp = np.zeros(8); imp[0] = 1.0
     np.testing.assert_allclose(head, sosfilt(sos, imp)[:4], rtol=0, atol=2e-6)
+    # ... and tfx_sos_fft_conv_forward from C: the cascade inside the overlap-save pipeline with an identity FIR == the cascade kernel
+    worst = float(out.split("fused cascade|identity FIR vs cascade: max difference")[1].split()[0])
+    assert worst <= 2e-6, out
