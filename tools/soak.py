@@ -53,7 +53,15 @@ def cases(dev, seconds_long=300.0):
     def chain():
         w = Wave(x_long, FS, device=dev) | LoButterworth(2000, order=6) | ParametricEQ(1000, 2.0, 3.0) | FIR(b1024) | FIR(rev)
         return w.ys
-    yield "chain .ys (spectral fold, 64 ch)", chain
+    yield "chain .ys (default: recursion inside pass A, 64 ch)", chain
+
+    def chain_fold():
+        w = Wave(x_long, FS, device=dev)
+        w.fuse_spectral = True
+        return (w | LoButterworth(2000, order=6) | ParametricEQ(1000, 2.0, 3.0) | FIR(b1024) | FIR(rev)).ys
+    yield "chain .ys (spectral fold, opt-in)", chain_fold
+    k20 = np.ascontiguousarray(rev[:20000][::-1])
+    yield "fused cascade|FIR op, 2^20-point blocks forced", lambda: E.sos_fft_conv_forward(x_long[:32], sos, k20, (19999, 0), force_block=1)
     yield "fft_conv 65536 taps", lambda: E.fft_conv_forward(x_long, rev[::-1].copy(), (65535, 0))
     yield "cascade f64", lambda: E.sos_forward(x_mid, None, sos, None, None)[0]
     yield "cascade f32", lambda: E.sos_forward(x_mid, None, sos, None, None, precision="f32")[0]
