@@ -378,17 +378,20 @@ ols_col_inv16_kernel(const cpx *__restrict__ T, float *__restrict__ y, const cpx
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pass A with the SOS cascade in front of it (N2 = 4096): `iir-cascade | FIR...` in the reference's own arithmetic --
+// Pass A with the SOS cascade in front of it (N2 = 4096 or 8192): `iir-cascade | FIR...` in the reference's own arithmetic --
 // float64 DF1 recursion (src/torchfx/_csrc/cpu/iir_cpu.cpp:132-147), one rounding to float32 (filter/iir.py: the downcast
 // of _sos_cascade_forward), float32 overlap-save (filter/_fftconv.py:123-140) -- without the recursion's own 8 B/sample pass.
 //
-// A frame is 256 rows of 4096 consecutive samples and the column transform wants 32 adjacent columns of ALL rows at once,
-// so no workgroup ever holds a long run of consecutive samples -- but it holds 512 SHORT runs that each continue where
-// the previous column block stopped.  One workgroup therefore owns a frame PAIR and walks its 128 column blocks in time
+// A frame is 256 rows of N2 = 4096 (N = 2^20) or 8192 (N = 2^21) consecutive samples and the column transform wants 32
+// adjacent columns of ALL rows at once, so no workgroup ever holds a long run of consecutive samples -- but it holds 512
+// SHORT runs that each continue where the previous column block stopped.  (The order the round-4 review proposed -- the
+// contiguous row transform first -- is not a factorisation of the DFT: Cooley-Tukey transforms the strided index first,
+// profiles/r05_experiments.txt section 1.)  One workgroup therefore owns a frame PAIR and walks its N2 / 32 column blocks in time
 // order; thread (frame, row) is the recursion of that row: it carries the 2K+2 float64 state values of its row in
 // registers from block to block and runs the plain sequential DF1 recursion over its 32 samples -- no scan, no matrices,
-// 5 fused multiply-adds per sample and section.  A row starts `warm` samples early from zero state (the planner's
-// max|A^W| < 2^-60 of sos.hip: the state at the row's first sample is the true one to float64 round-off); those
+// 5 operations per sample and section (4 in the unit-b0 form).  A row starts `warm` samples early from zero state (the
+// warm-up analysis of sos.hip at max|A^W| < 2^-48, fftconv.hip: the state at the row's first sample is the true one to the
+// round-off a float64 recursion gathers over a row anyway); those
 // warm-up blocks are read and filtered but not transformed.  Per block: coalesced 16-byte loads of the 512 lines
 // (prefetched one block ahead) -> LDS stage [512][36] -> each thread takes its line, filters it and puts the rounded
 // float32 samples back IN PLACE -> the stage is the column transform's input z = a + i b -> radix-16 x 16 transform through
