@@ -38,6 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FS = 48000
+COPY_RATE_GBS = 6290.0     # sustained device copy rate (MI355X_MICROARCH.md), the ceiling of a multi-pass design
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_PEAK_TF = 157.3
 def _latest_traffic_file() -> str:
@@ -308,12 +309,23 @@ def timed_region(step, steps: int, warmup: int, sync, lib, profile: bool = True)
     return elapsed, prof, out
 
 
+def group_stats(groups: list[float]) -> dict:
+    """min / median / max of the per-step times of the timed groups.  A FIRST group slower than 1.5 x the median of all groups
+    (clock ramp after the idle gap, a one-off allocator stall) is dropped and reported as dropped; nothing else is."""
+    used, dropped = list(groups), None
+    if len(used) >= 4 and used[0] > 1.5 * float(np.median(used)):
+        dropped, used = used[0], used[1:]
+    return {"min": round(min(used), 4), "median": round(float(np.median(used)), 4), "max": round(max(used), 4),
+            "groups_used": len(used), "dropped_first_group_ms": None if dropped is None else round(dropped, 4)}
+
+
 def batch_timed(step, sync, lib, batches: int, per_batch: int, warmup: int = 2, min_group_ms: float = 20.0):
-    """Secondary figures (stages, variants): `batches` groups of `per_batch` back-to-back steps, device
-    synchronised around every group, no event profiling; returns (median group time / per_batch in ms, all group values,
-    per-kernel ms per step from the library's HIP events -- one extra group, recorded with events after the timed ones --,
-    last output).  The median keeps a one-off allocator stall (a fresh multi-GB hipMalloc inside torch.empty) out of a
-    5-step figure."""
+    """Secondary figures (stages, variants): `batches` groups of `per_batch` back-to-back steps (at least 9 groups when a step
+    is shorter than 1 ms), device synchronised around every group, no event profiling; returns (median group time / per_batch
+    in ms, all group values, per-kernel ms per step from the library's HIP events -- one extra group, recorded with events
+    after the timed ones --, last output); `batch_timed.stats` = group_stats() of the groups (min / median / max, a slow first
+    group dropped and named).  The median keeps a one-off allocator stall (a fresh multi-GB hipMalloc inside torch.empty) out
+    of a 5-step figure."""
     out = None
     for _ in range(warmup):
         out = None
@@ -327,6 +339,8 @@ def batch_timed(step, sync, lib, batches: int, per_batch: int, warmup: int = 2, 
     sync()
     est_ms = (time.perf_counter() - t0) * 1e3
     per_batch = max(per_batch, min(200, int(np.ceil(min_group_ms / max(est_ms, 1e-3)))))
+    if est_ms < 1.0:
+        batches = max(batches, 9)
     groups = []
     for _ in range(batches):
         sync()
@@ -346,7 +360,8 @@ def batch_timed(step, sync, lib, batches: int, per_batch: int, warmup: int = 2, 
     lib.tfx_prof_enable(0)
     kern = {k: round(v["total_ms"] / per_batch, 4) for k, v in prof.items()}
     batch_timed.per_batch = per_batch
-    return float(np.median(groups)), [round(g, 4) for g in groups], kern, out
+    batch_timed.stats = group_stats(groups)
+    return batch_timed.stats["median"], [round(g, 4) for g in groups], kern, out
 
 
 def kernel_table(prof: dict, steps: int) -> dict:
@@ -622,7 +637,7 @@ def main() -> None:
                 sms, sgroups, skern, sout = batch_timed(sstep, sync, lib, 5, 5)
                 n = xs.numel()
                 ent = {"workload": sdesc, "channels": C, "seconds": sec, "ms_per_step": round(sms, 4),
-                       "steps_per_group": batch_timed.per_batch, "ms_per_step_groups": sgroups,
+                       "steps_per_group": batch_timed.per_batch, "ms_per_step_groups": sgroups, "ms_per_step_stats": batch_timed.stats,
                        "Msamples_per_s": round(n / sms / 1e3, 1), "bound": bound, "kernel_ms_per_step": skern}
                 if bound == "hbm":
                     ent["achieved_GBps"] = round(8.0 * n / (sms * 1e-3) / 1e9, 1)
@@ -705,7 +720,7 @@ def main() -> None:
                 pairs = (frames + 1) // 2
                 n = info["N"]
                 model["ols_col_fwd16_kernel"] = frames * n * 4.0 + pairs * n * 8.0
-                # the recursion's column pass also reads every row's warm-up (61 of 128 blocks for the cfg-2 cascade at 2^-48)
+                # the recursion's column pass also reads every row's warm-up (64 of 256 blocks for the cfg-2 cascade at 2^-48, round 5; fewer at round 6's 2^-40)
                 wb = -(-max(0, E.sos_fft_conv_warmup(_sos)) // 32)
                 rows_blk = n // 256 // 32                               # column blocks per row: 128 (4096-sample rows) or 256 (8192)
                 model["ols_col_fwd16_sos_kernel"] = frames * n * 4.0 * (1.0 + min(wb, rows_blk) / rows_blk) + pairs * n * 8.0
@@ -769,6 +784,16 @@ def main() -> None:
             roof["frac_is"] = "dominant kernel: algorithmic work of one launch / its average duration (HIP events)"
         roof["step_achieved"] = round(step_ach, 2)
         roof["step_frac"] = round(step_ach / roof["peak"], 4)
+        if multi_pass and line_ols:
+            # what THIS design can reach at best: a transform longer than LDS is three passes over a complex workspace, i.e.
+            # model bytes per sample (20 N / S + 4, + the warm-up re-reads of the recursion's column pass) moved at the rate a
+            # plain device copy sustains on this part (MI355X_MICROARCH.md: 6.29 TB/s) -- read `frac` against this, not 1.0
+            mb = float(line_ols["model_bytes_per_sample"])
+            if "ols_col_fwd16_sos_kernel" in kernels:
+                mb += 4.0 * min(wb, rows_blk) / rows_blk * line_ols["fft_block"] / line_ols["hop"]
+            roof["design_ceiling"] = {"frac": round(8.0 / mb * COPY_RATE_GBS / HBM_PEAK_GBS, 4), "model_bytes_per_sample": round(mb, 2),
+                                      "copy_rate_GBps": COPY_RATE_GBS,
+                                      "what": "8 B/sample / (model bytes per sample of the three-pass overlap-save) x the device's sustained copy rate / peak"}
         if args.workload == "chain" and "ols_col_fwd16_sos_kernel" in kernels:
             # the default plan IS the reference's arithmetic: float64 recursion (inside the forward column pass), float32 overlap-save
             roof["step_frac_reference_arithmetic"] = roof["step_frac"]
@@ -823,7 +848,7 @@ def main() -> None:
         iir_knob = os.environ.get("TORCHFX_AMD_IIR_PRECISION", "f64")
         if "ols_col_fwd16_sos_kernel" in kernels:
             iir_how = ("float64 DF1 recursion (iir_cpu.cpp:132-147) in registers inside the overlap-save pipeline's forward column pass "
-                       "(ols_col_fwd16_sos_kernel: one thread per 4096-sample row, warm-up to 2^-48 from zero state), rounded once to float32; "
+                       "(ols_col_fwd16_sos_kernel: one thread per 4096-sample row, warm-up to 2^-40 from zero state), rounded once to float32; "
                        "every section's output readable through y_sections (tests/test_gpu_sos_ols.py)")
         elif args.workload.startswith("chain") and not any(n.startswith("sos_stream_kernel") for n in kernels):
             iir_how = ("folded into the f32 overlap-save pass (fuse_spectral, opt-in: the cascade's impulse response joins the FIR run; "
@@ -878,8 +903,10 @@ def main() -> None:
         if stages:
             if first_call_ms is not None:
                 stages["first_ys_ms"] = round(first_call_ms, 2)       # first (Wave(x) | ...).ys of the process, planning included
-            stages["_timing"] = ("every stage: median of 5 groups of back-to-back steps (>= 20 ms per group), wall clock, device synchronised "
-                                 "around each group, no event profiling; kernel_ms_per_step from one more group with the library's HIP events")
+            stages["_timing"] = ("every stage: median of 5 groups (9 when a step is under 1 ms) of back-to-back steps (>= 20 ms per group), wall "
+                                 "clock, device synchronised around each group, no event profiling; ms_per_step_stats = min / median / max of the "
+                                 "groups used (a first group above 1.5 x the median is dropped and named); kernel_ms_per_step from one more group "
+                                 "with the library's HIP events")
             line["stages"] = stages
         if variants:
             line["variants"] = variants

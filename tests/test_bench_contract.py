@@ -18,6 +18,26 @@ def test_cpu_baseline_fields_and_workload_filters():
     json.dumps(cb)
 
 
+def test_group_stats_of_the_stage_timer():
+    """Secondary figures: min / median / max over the groups, a slow FIRST group (and only that) dropped and named."""
+    import bench
+    st = bench.group_stats([0.3596, 0.3326, 0.8002, 0.3628, 0.3319])            # round 5's bimodal cfg-2 groups: nothing dropped
+    assert st == {"min": 0.3319, "median": 0.3596, "max": 0.8002, "groups_used": 5, "dropped_first_group_ms": None}
+    st = bench.group_stats([0.81, 0.33, 0.34, 0.33, 0.35, 0.33, 0.34, 0.33, 0.33])
+    assert st["dropped_first_group_ms"] == 0.81 and st["groups_used"] == 8 and st["max"] == 0.35 and st["median"] == 0.33
+    assert bench.group_stats([9.4, 9.3, 9.5])["groups_used"] == 3
+
+    class Lib:
+        def tfx_prof_enable(self, on):
+            pass
+
+        def tfx_prof_collect(self):
+            return b"{}"
+    ms, groups, kern, out = bench.batch_timed(lambda: 1, lambda: None, Lib(), 5, 5, min_group_ms=0.05)
+    assert len(groups) >= 9 and set(bench.batch_timed.stats) == {"min", "median", "max", "groups_used", "dropped_first_group_ms"}
+    assert ms == bench.batch_timed.stats["median"] and out == 1
+
+
 def test_traffic_file_is_consistent():
     import os
     from tests.conftest import ROOT

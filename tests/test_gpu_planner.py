@@ -222,11 +222,15 @@ def test_default_plan_runs_the_recursion_inside_the_overlap_save_pass():
     _, _, _, rs = O.sos_forward(xl.astype(np.float64), sos, sections=True)
     for s in range(4):
         close(sec[s], rs[s], TOL_IIR_F64OUT, f"section {s}")
-    # odd length: staged, same numbers to the FIR tolerance
+    # odd length: the same single step since round 6 (rows shift their frame grid), and the plan says which route a tensor takes
     xo = xl[:, :-7].copy()
     wo = Wave(xo, 48000, device=DEV) | f1 | f2 | fir | rev
-    assert [type(m).__name__ for m in wo.plan()] == ["FusedSOSCascade", "FIR"]
-    close(wo.ys, ref[:, :-7], TOL_CONV_F32, "staged at an odd length")
+    assert [type(m).__name__ for m in wo.plan()] == ["CascadeFIR"]
+    lines = wo.explain()
+    assert len(lines) == 1 and lines[0].startswith("CascadeFIR: staged -- ") and "frame pairs <" in lines[0]
+    close(wo.ys, ref[:, :-7], TOL_CONV_F32, "an odd length")
+    y3, _ = wo.plan()[0](dev(xo), return_sections=True)
+    close(y3, ref[:, :-7], TOL_CONV_F32, "an odd length, fused pass")
 
 
 def test_gain_and_normalize_ride_on_the_cascade_fir_step():

@@ -501,8 +501,10 @@ def test_default_plan_of_the_headline_chain_is_one_cascade_fir_step():
     assert [type(m).__name__ for m in p] == ["CascadeFIR"] and p[0].fir.kernel.numel() == 66559 and p[0]._sos.shape == (4, 6)
     assert [type(m).__name__ for m in plan(fuse_recursive=False)] == ["FusedSOSCascade", "FIR"]
     assert [type(m).__name__ for m in plan(fuse_spectral=True)] == ["FIR"]             # the fold wins when both are on
-    assert [type(m).__name__ for m in plan(length=28_800_001)] == ["FusedSOSCascade", "FIR"]   # not whole 128-byte lines
-    assert [type(m).__name__ for m in plan(length=1_440_000)] == ["FusedSOSCascade", "FIR"]    # 2^18-point blocks there
+    assert [type(m).__name__ for m in plan(length=28_800_001)] == ["CascadeFIR"]       # any row length since round 6 (row_shift)
+    p18 = plan(length=1_440_000)
+    assert [type(m).__name__ for m in p18] == ["FusedSOSCascade", "FIR"]               # 2^18-point blocks there ...
+    assert "2^20" in p18[0].recursive_refused                                          # ... and the plan says so
     assert [type(m).__name__ for m in plan(length=2_880_000)] == ["CascadeFIR"]        # 2^20 blocks from two per row (the module itself
     #                                                                                  takes the staged pair of launches for small batches)
     g = fx.effect.Gain(0.5)

@@ -360,14 +360,16 @@ void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, c
 // (_ops.py:119-176 with state None -> iir_cpu.cpp:64-159), its result rounded to float32 (iir.py:84-184, the downcast), then
 // fft_conv1d (_fftconv.py:70-141) -- the cascade runs inside the forward column pass (olsnative.hip), no pass of its own.
 // Warm-up of a row's recursion inside the column pass: the state a row starts from is the true one to 2^-bits of the
-// state's scale (TFX_OLS_SOS_HALO_BITS, default 48 -- 3.6e-15, the round-off a float64 recursion gathers over a 4096-sample
-// row anyway; the stand-alone cascade kernel uses 60).  Cached by coefficient content: the analysis is a few dozen
+// state's scale (TFX_OLS_SOS_HALO_BITS, default 40 = 9e-13: 1/20 of the 2e-11 the section-by-section parity tests state
+// (tests/gpu_common.py TOL_IIR_F64OUT) and 5 orders below the float32 rounding the samples get next; round 5 ran 48, 3.6e-15:
+// +0.15 ms per chain step for digits no test can read, profiles/r05_experiments.txt section 6; the stand-alone cascade kernel
+// uses 60).  Cached by coefficient content: the analysis is a few dozen
 // long-double matrix products.
 static int64_t fused_warmup(const double *sos_host, int64_t Ksos)
 {
     static std::mutex mu;
     static std::map<std::vector<double>, int64_t> memo;
-    const int bits = (int)std::max<int64_t>(20, std::min<int64_t>(60, env_i64("TFX_OLS_SOS_HALO_BITS", 48)));
+    const int bits = (int)std::max<int64_t>(20, std::min<int64_t>(60, env_i64("TFX_OLS_SOS_HALO_BITS", 40)));
     std::vector<double> key(sos_host, sos_host + 6 * Ksos);
     key.push_back((double)bits);
     std::lock_guard<std::mutex> lk(mu);
@@ -412,13 +414,13 @@ void sos_fft_conv_forward(const float *x, float *y, int64_t C, int64_t T, const 
     if (C == 0) return;
     TFX_CHECK(C > 0 && T > 0, "sos_fft_conv_forward: bad shape");
     TFX_CHECK(x && y && kernel_host && sos_host, "sos_fft_conv_forward: null pointer");
-    TFX_CHECK(((uintptr_t)x & 15) == 0, "sos_fft_conv_forward: x must be 16-byte aligned (rows are read 16 bytes at a time)");
+    TFX_CHECK(((uintptr_t)x & 3) == 0 && ((uintptr_t)y & 3) == 0, "sos_fft_conv_forward: x and y must be float-aligned");
     olsnative_wait_warm();               // a set-up helper started by tfx_prewarm finishes before anything here is enqueued
     int64_t N = 0;
     const int64_t warm = Ksos <= 8 ? fused_warmup(sos_host, Ksos) : -1;
     TFX_CHECK(olsnative_sos_supported(Ksos, warm, K, T, pad_left, pad_right, force, &N),
-              "sos_fft_conv_forward: unsupported here (float32 rows of a multiple of 32 samples, at most 8 sections whose memory "
-              "fades within 4096 samples, taps that take the 2^20-point block) -- ask tfx_sos_fft_conv_supported first");
+              "sos_fft_conv_forward: unsupported here (at most 8 sections whose memory fades within 4096 samples, taps that take "
+              "the 2^20-point block) -- ask tfx_sos_fft_conv_supported first");
     const SosFuseHost sf{sos_host, Ksos, warm, sections};
     olsnative_forward(x, y, C, T, kernel_host, K, pad_left, pad_right, N, stream, nullptr, 0, (ep && ep->any()) ? ep : nullptr, &sf);
 }

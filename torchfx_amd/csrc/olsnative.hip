@@ -86,6 +86,10 @@ struct OlsGeom {
     double *ep_partial;   // [nframes][N2 / 32]: one partial per (frame, column block); row c owns F * N2/32 consecutive ones
     int N2;            // row length (N = 256 * N2)
     int P2;            // row pitch of the workspace T in elements (N2 + pad: breaks the power-of-two stride)
+    int sh_on, sh_base; // rows that are not whole 128-byte lines (T % 32 != 0, or a base pointer inside a line): row c's frame grid
+                       // moves left by sh(c) = (sh_base + c * Tn) % 32 samples, so every frame still starts on a 128-byte line of
+                       // memory; block output i of frame f is then y[f * S + i - sh(c)]  (sh_base = element offset of x in its line)
+    int *nf_flag;      // cascade in pass A: [nframes], 1 = the recursion of this frame met a non-finite value (every slot written)
     int nt;            // nontemporal hints (TFX_OLS_NT, default 3): 1 = signal loads of pass A, 2 = signal stores of pass C -- the signal
                        // is read once and written once; chain step 7.98 -> 7.87 ms.  (The same hint on the workspace loads of
                        // passes B and C, their last use, changes nothing.)
@@ -99,6 +103,7 @@ constexpr int OLS_CB = 32;      // columns per workgroup in the column passes
 // swizzle removes the remaining 2-way read conflict but costs 32 computed addresses per stage and
 // measured slower.)
 __device__ __forceinline__ int pad16(int p) { return p + (p >> 4); }
+__device__ __forceinline__ int row_shift(const OlsGeom &g, int64_t c) { return g.sh_on ? (int)(((int64_t)g.sh_base + c * g.Tn) & 31) : 0; }
 
 template <bool INV>
 __device__ __forceinline__ void dft16(cpx (&v)[16])
@@ -220,9 +225,9 @@ ols_col_fwd16_kernel(const float *__restrict__ x, cpx *__restrict__ T, const cpx
     const int cb = blockIdx.x % ncb;
     const int n2 = cb * OLS_CB + col;
     const int64_t fa = frame0 + 2 * pair, fb = fa + 1;
-    const int64_t ca = fa / g.F, ia0 = (fa % g.F) * g.S - g.pad_left;
+    const int64_t ca = fa / g.F, ia0 = (fa % g.F) * g.S - g.pad_left - row_shift(g, ca);
     const bool has_b = fb < g.nframes;
-    const int64_t cb_ = has_b ? fb / g.F : 0, ib0 = has_b ? (fb % g.F) * g.S - g.pad_left : 0;
+    const int64_t cb_ = has_b ? fb / g.F : 0, ib0 = has_b ? (fb % g.F) * g.S - g.pad_left - row_shift(g, cb_) : 0;
     const float *xa = x + ca * g.Tn, *xb = x + cb_ * g.Tn;
     cpx v[NBF][16];
     // interior frames (the common case) need no bounds checks
@@ -329,6 +334,7 @@ ols_col_inv16_kernel(const cpx *__restrict__ T, float *__restrict__ y, const cpx
         if (acc == 1.2345e30f) ya[oa0] = acc;
         return;
     }
+    const int64_t sha = g.out_shift + row_shift(g, ca), shb = g.out_shift + row_shift(g, cb_);
     const bool epi = g.ep_scale | g.ep_clamp | (g.ep_stat >= 0);
     double acc_a = 0.0, acc_b = 0.0;
 #pragma unroll
@@ -338,7 +344,7 @@ ols_col_inv16_kernel(const cpx *__restrict__ T, float *__restrict__ y, const cpx
             const int64_t n = (int64_t)(q + QS * i + 16 * k) * g.N2 + n2;
             if (n < g.S) {                                   // valid part of the block
                 cpx o = v[i][DFT16_AT(k)];
-                const int64_t oa = oa0 + n - g.out_shift, ob = ob0 + n - g.out_shift;
+                const int64_t oa = oa0 + n - sha, ob = ob0 + n - shb;
                 const bool wa = oa >= 0 && oa < g.Tout, wb = has_b && ob >= 0 && ob < g.Tout;
                 if (epi) {                                   // Gain / clamp / statistic on the stored values
                     if (g.ep_scale) { o.x *= g.ep_gain; o.y *= g.ep_gain; }
@@ -390,7 +396,7 @@ ols_col_inv16_kernel(const cpx *__restrict__ T, float *__restrict__ y, const cpx
 // order; thread (frame, row) is the recursion of that row: it carries the 2K+2 float64 state values of its row in
 // registers from block to block and runs the plain sequential DF1 recursion over its 32 samples -- no scan, no matrices,
 // 5 operations per sample and section (4 in the unit-b0 form).  A row starts `warm` samples early from zero state (the
-// warm-up analysis of sos.hip at max|A^W| < 2^-48, fftconv.hip: the state at the row's first sample is the true one to the
+// warm-up analysis of sos.hip at max|A^W| < 2^-40, fftconv.hip: the state at the row's first sample is the true one to the
 // round-off a float64 recursion gathers over a row anyway); those
 // warm-up blocks are read and filtered but not transformed.  Per block: coalesced 16-byte loads of the 512 lines
 // (prefetched one block ahead) -> LDS stage [512][36] -> each thread takes its line, filters it and puts the rounded
@@ -423,20 +429,24 @@ ols_col_fwd16_sos_kernel(const float *__restrict__ x, cpx *__restrict__ T, const
     if (tid < 256) tw256[tid] = tw256g[tid];
     const int64_t pair = blockIdx.x;
     const int64_t fa = frame0 + 2 * pair, fb = fa + 1;
-    const int64_t ca = fa / g.F, ia0 = (fa % g.F) * g.S - g.pad_left;
+    const int64_t ca = fa / g.F, ia0 = (fa % g.F) * g.S - g.pad_left - row_shift(g, ca);
     const bool has_b = fb < g.nframes;
-    const int64_t cb_ = has_b ? fb / g.F : 0, ib0 = has_b ? (fb % g.F) * g.S - g.pad_left : 0;
+    const int64_t cb_ = has_b ? fb / g.F : 0, ib0 = has_b ? (fb % g.F) * g.S - g.pad_left - row_shift(g, cb_) : 0;
     const float *xa = x + ca * g.Tn, *xb = x + cb_ * g.Tn;
     const int nblk = g.N2 / OLS_CB;
     // Wave-uniform clock of the walk: `ta` / `tb` = time (sample index in its row) of row 0's first sample of the block being
-    // FETCHED; a line is row r of a frame, r * N2 samples later.  Lines are whole 128-byte lines of the signal or lie entirely
-    // outside [0, T) (aligned frames, T % 32 == 0), so validity is one comparison of the row offset with two scalars.
+    // FETCHED; a line is row r of a frame, r * N2 samples later.  Frames start on 128-byte lines of MEMORY (row_shift), so a
+    // line of the stage is one line of the signal; where the row begins or ends inside a line (T % 32 != 0) the loader takes
+    // the samples one by one, everywhere else validity is one comparison of the 16-byte part's offset with two scalars.
     int64_t ta = ia0 - (int64_t)OLS_CB * sf.warm_blocks, tb = ib0 - (int64_t)OLS_CB * sf.warm_blocks;
     auto bound = [](int64_t v) { return (int)(v < -(int64_t)0x40000000 ? -(int64_t)0x40000000 : (v > (int64_t)0x40000000 ? (int64_t)0x40000000 : v)); };
 
     // recursion side: this thread is line `tid` = (frame tid >> 8, row tid & 255)
     const bool mine_b = tid >= 256;
     const int rel_l = (tid & 255) * g.N2;
+    // section taps: a sample lies in the windows of two consecutive frames (they overlap by K - 1 samples); the frame whose LAST
+    // S window samples hold it stores it (frame 0 of a row: its whole window) -- one writer per address
+    const int own_lo = TAPS ? (((mine_b ? fb : fa) % g.F) == 0 ? 0 : OLS_N1 * g.N2 - (int)g.S) : 0;
     double h1[KS + 1], h2[KS + 1];             // h[0]: input history; h[s + 1]: output history of section s (iir_cpu.cpp:125-130)
 #pragma unroll
     for (int s = 0; s <= KS; ++s) { h1[s] = 0.0; h2[s] = 0.0; }
@@ -455,10 +465,17 @@ ols_col_fwd16_sos_kernel(const float *__restrict__ x, cpx *__restrict__ T, const
         for (int i = 0; i < 8; ++i) {
             const bool isb = i >= 4;
             const int r = rel + (i & 3) * rstep;
+            const int lo = isb ? lo_b : lo_a, hi = isb ? hi_b : hi_a;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r >= (isb ? lo_b : lo_a) && r < (isb ? hi_b : hi_a)) {
+            if (r >= lo && r + 4 <= hi) {
                 const float *src = (isb ? pb : pa) + r;
                 v = (g.nt & 1) ? ldg16_stream<float4>(src) : *(const float4 *)src;
+            } else if (r + 4 > lo && r < hi) {               // the row begins or ends inside this 16-byte part
+                const float *src = (isb ? pb : pa) + r;
+                if (r >= lo) v.x = src[0];
+                if (r + 1 >= lo && r + 1 < hi) v.y = src[1];
+                if (r + 2 >= lo && r + 2 < hi) v.z = src[2];
+                if (r + 3 < hi) v.w = src[3];
             }
             P[i] = v;
         }
@@ -472,7 +489,12 @@ ols_col_fwd16_sos_kernel(const float *__restrict__ x, cpx *__restrict__ T, const
         for (int i = 0; i < 8; ++i) *(float4 *)&S[(lrow + 64 * i) * SOSF_LS + 4 * lpart] = P[i];
         // the block being filtered is the one fetched last: its clock is one block behind ta / tb
         const int64_t tcur = (mine_b ? tb : ta) - OLS_CB;
-        const bool live = (!mine_b || has_b) && rel_l >= bound(-tcur) && rel_l < bound(g.Tn - tcur);
+        // samples [first, last) of this thread's line lie inside the row.  In front of the row the recursion sees zeros from
+        // zero state and returns zeros by itself; behind its end the filter's tail is cut (the reference filters T samples and
+        // the FIR pads afterwards)
+        const int last = (!mine_b || has_b) ? min(max(bound(g.Tn - tcur) - rel_l, 0), OLS_CB) : 0;
+        int first = 0;
+        if (TAPS) first = max(min(max(bound(-tcur) - rel_l, 0), OLS_CB), min(max(own_lo - (rel_l + OLS_CB * blk), 0), OLS_CB));
         if (blk + 1 < nblk) fetch();                       // in flight while this block is filtered and transformed
         __syncthreads();
         // The recursion is a long stream of independent float64 operations, the transform a short chain of LDS round trips and
@@ -487,6 +509,7 @@ ols_col_fwd16_sos_kernel(const float *__restrict__ x, cpx *__restrict__ T, const
                 const float4 w4 = *(const float4 *)&S[tid * SOSF_LS + SOSF_CH * j + 4 * i];
                 u[4 * i] = w4.x; u[4 * i + 1] = w4.y; u[4 * i + 2] = w4.z; u[4 * i + 3] = w4.w;
             }
+            const int lastj = last - SOSF_CH * j, firstj = first - SOSF_CH * j;
 #pragma unroll
             for (int n = 0; n < SOSF_CH; ++n) {
                 double v = (double)u[n];
@@ -501,14 +524,21 @@ ols_col_fwd16_sos_kernel(const float *__restrict__ x, cpx *__restrict__ T, const
                     h2[s] = h1[s]; h1[s] = v;
                     v = yn;
                     if (TAPS) {
-                        if (live && blk >= 0)
+                        if (blk >= 0 && n >= firstj && n < lastj)
                             sf.sections[((int64_t)s * (g.nframes / g.F) + (mine_b ? cb_ : ca)) * g.Tn + tcur + rel_l + SOSF_CH * j + n] =
                                 UNIT ? yn * sf.co[s][0] : yn;
                     }
                 }
                 h2[KS] = h1[KS]; h1[KS] = v;
                 if (UNIT) v *= sf.co[KS - 1][0];
-                u[n] = live ? (float)v : 0.0f;
+                u[n] = n < lastj ? (float)v : 0.0f;
+            }
+            // Two real frames ride one complex transform: a non-finite sample of one would come out in BOTH.  A state that
+            // has gone non-finite stays so (flag + fix-up below): from here on this line enters the transform as zeros -- the
+            // frame's own output is replaced by NaN afterwards, its partner's stays what it is.
+            if (!(__builtin_fabs(h1[KS]) <= 1.7976931348623157e308)) {
+#pragma unroll
+                for (int n = 0; n < SOSF_CH; ++n) u[n] = 0.0f;
             }
             if (blk >= 0) {
 #pragma unroll
@@ -532,6 +562,68 @@ ols_col_fwd16_sos_kernel(const float *__restrict__ x, cpx *__restrict__ T, const
         for (int k = 0; k < 16; ++k) { *(cpx *)(Tb + off) = v[0][DFT16_AT(k)]; off += ostep; }
         __syncthreads();                                      // exchange read: the stage may be refilled
     }
+    // Non-finite values never leave a recursion (iir_cpu.cpp:132-147: once in the state, every later output of the row carries
+    // them) -- but a row of this walk starts again from zero state, so a bad sample would "heal" one row later.  The state a
+    // thread ends with tells whether its row (warm-up included) met one: one flag per frame, and olsnative_forward's fix-up pass
+    // turns everything behind the first flagged frame of a signal row into NaN like the staged pair of launches does.
+    {
+        int *flag = (int *)smem;                              // the stage is free (last barrier above)
+        if (tid < 2) flag[tid] = 0;
+        __syncthreads();
+        const double e1 = h1[KS], e2 = h2[KS];
+        if (!(__builtin_fabs(e1) <= 1.7976931348623157e308 && __builtin_fabs(e2) <= 1.7976931348623157e308)) flag[mine_b ? 1 : 0] = 1;
+        __syncthreads();
+        if (tid == 0) g.nf_flag[fa] = flag[0];
+        if (tid == 1 && has_b) g.nf_flag[fb] = flag[1];
+    }
+}
+
+// Fix-up behind pass C of the cascade-in-pass-A pipeline (see the flags above).  Grid (chunks, C, 1 + sections): every
+// workgroup first reads its signal row's F flags and leaves when none is set -- the common case, a few microseconds for the whole
+// launch.  z = 0: the output row becomes NaN from the first sample of the first flagged frame: that frame's window holds the bad
+// sample and every later frame's window lies behind it -- what the staged pair of launches returns (the cascade's output stays
+// non-finite to the end of the row, and every block of the convolution that reaches it is non-finite as a whole).  The
+// flagged frames entered the transform as zeros from the bad sample on, so the frame that shares a transform with one (even a
+// frame of the neighbouring signal row) keeps its own finite output.  z = s + 1 (section taps, parity tests): section s is exact up to its first non-finite sample, which
+// lies in the flagged frame's window or its warm-up; everything behind that sample becomes NaN (iir_cpu.cpp:132-147).
+__global__ void __launch_bounds__(256)
+ols_sos_nonfinite_fix_kernel(float *__restrict__ y, double *__restrict__ sections, OlsGeom g, int warm_blocks)
+{
+    __shared__ int s_first;
+    __shared__ long long s_n;
+    const int tid = threadIdx.x;
+    const int64_t c = blockIdx.y;
+    if (tid == 0) { s_first = 0x7fffffff; s_n = 0x7fffffffffffffffll; }
+    __syncthreads();
+    for (int64_t f = tid; f < g.F; f += 256)
+        if (g.nf_flag[c * g.F + f]) atomicMin(&s_first, (int)f);
+    __syncthreads();
+    const int64_t first = s_first;
+    if (first == 0x7fffffff) return;
+    const int sh = row_shift(g, c);
+    const float nanf_ = __builtin_nanf("");
+    if (blockIdx.z == 0) {
+        // the statistic of an epilogue saw the flagged frames' stand-in samples: a NaN partial wins both reductions (epilogue.h)
+        if (blockIdx.x == 0 && tid == 0 && g.ep_stat >= 0) g.ep_partial[(c * g.F + first) * (g.N2 / OLS_CB)] = __builtin_nan("");
+        const int64_t t0 = max((int64_t)0, first * g.S - g.out_shift - sh);
+        const int64_t len = g.Tout - t0, per = (len + gridDim.x - 1) / gridDim.x;
+        const int64_t lo = t0 + per * blockIdx.x, hi = min(g.Tout, lo + per);
+        for (int64_t t = lo + tid; t < hi; t += 256) y[c * g.Tout + t] = nanf_;
+        return;
+    }
+    if (!sections || blockIdx.x != 0) return;
+    double *row = sections + ((int64_t)(blockIdx.z - 1) * (g.nframes / g.F) + c) * g.Tn;
+    const int64_t start = max((int64_t)0, first * g.S - g.pad_left - sh - (int64_t)OLS_CB * warm_blocks);
+    for (int64_t t0 = start; t0 < g.Tn; t0 += 4096) {         // first non-finite sample of this section, 4096 samples at a time
+        for (int64_t t = t0 + tid; t < min(g.Tn, t0 + 4096); t += 256)
+            if (!(__builtin_fabs(row[t]) <= 1.7976931348623157e308)) { atomicMin(&s_n, (long long)t); break; }
+        __syncthreads();
+        if (s_n != 0x7fffffffffffffffll) break;
+    }
+    const int64_t n = s_n;
+    if (n == 0x7fffffffffffffffll) return;
+    const double nan_ = __builtin_nan("");
+    for (int64_t t = n + 1 + tid; t < g.Tn; t += 256) row[t] = nan_;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1750,7 +1842,7 @@ bool olsnative_sos_supported(int64_t Ksos, int64_t warm, int64_t K, int64_t Tn, 
     if (envi("TFX_OLS_SOS", 1) == 0) return false;
     if (Ksos < 1 || Ksos > SOSF_MAXK || warm < 0 || warm > envi("TFX_OLS_SOS_MAXWARM", 4096)) return false;
     const int64_t L = Tn + pl + pr;
-    if (L < K || Tn % 32 != 0 || (L - K + 1) % 32 != 0 || envi("TFX_OLS_ALIGN", 1) == 0) return false;
+    if (L < K || envi("TFX_OLS_ALIGN", 1) == 0) return false;
     int64_t N = (int64_t)1 << (force == 2 ? 21 : 20);       // force: 1 = the 2^20-point block, 2 = the 2^21-point block, whatever the row length
     if (force) { if (N < 2 * (K + 32)) return false; }
     else {
@@ -1768,12 +1860,14 @@ bool olsnative_sos_supported(int64_t Ksos, int64_t warm, int64_t K, int64_t Tn, 
 void olsnative_geometry(int64_t K, int64_t Tn, int64_t pl, int64_t pr, int64_t N, int64_t *S_out, int64_t *F_out)
 {
     const int64_t L = Tn + pl + pr, Tout = L - K + 1;
-    const bool align = (Tn % 32 == 0) && (Tout % 32 == 0) && envi("TFX_OLS_ALIGN", 1) != 0;
+    (void)Tout;
+    const bool align = envi("TFX_OLS_ALIGN", 1) != 0;
     const int64_t lead = align ? (32 - (pl % 32)) % 32 : 0;
     int64_t S = N - (K + lead) + 1;
     if (align && S > 64) S -= S % 32;
     if (S_out) *S_out = S;
-    if (F_out) *F_out = ceil_div(Tout, S);
+    // rows that are not whole 128-byte lines shift their frame grid by up to 31 samples (row_shift): one more frame at most
+    if (F_out) *F_out = ceil_div(Tout + ((align && (Tn % 32 != 0)) ? 31 : 0), S);
 }
 
 void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const float *kf_host, int64_t K,
@@ -1795,9 +1889,15 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     // of 32: every 32-column segment the column passes read or write is then exactly one cache
     // line (misaligned segments straddle two lines: +8 % time on the forward pass, +26 % on the
     // inverse pass, measured)
+    // Rows that are not whole lines (Tn % 32 != 0, or x starting inside a line) keep this: row c's frame grid is moved left by
+    // sh(c) samples (row_shift) so that its frames start on lines of MEMORY; the column passes address the same way, only the
+    // first and the last line of a row are partial.
     int64_t lead = 0;
-    const bool align = (Tn % 32 == 0) && (g.Tout % 32 == 0) && envi("TFX_OLS_ALIGN", 1) != 0;
+    const bool align = envi("TFX_OLS_ALIGN", 1) != 0;
     if (align) lead = (32 - (pl % 32)) % 32;
+    g.sh_base = (int)(((uintptr_t)x >> 2) & 31);
+    g.sh_on = (align && (Tn % 32 != 0 || g.sh_base != 0)) ? 1 : 0;
+    g.nf_flag = nullptr;
     g.pad_left = pl + lead;
     g.S = N - (K + lead) + 1;
     if (align && g.S > 64) g.S -= g.S % 32;
@@ -1831,7 +1931,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     if (plan_err) std::rethrow_exception(plan_err);
     if (plan->ready && plan->ready_stream != stream) TFX_HIP(hipStreamWaitEvent(stream, plan->ready, 0));   // spectrum computed on another stream
     tr.mark("plan (spectrum, tables)");
-    g.F = ceil_div(g.Tout + g.out_shift, g.S);
+    g.F = ceil_div(g.Tout + g.out_shift + (g.sh_on ? 31 : 0), g.S);
     g.nframes = C * g.F; g.N2 = plan->N2;
     g.P2 = g.N2 + (int)envi("TFX_OLS_PITCH_PAD", 0);
     g.nt = (int)envi("TFX_OLS_NT", 3);
@@ -1900,6 +2000,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     if (sosf) {
         TFX_CHECK((g.N2 == 4096 || g.N2 == 8192) && align && !hist && sosf->K >= 1 && sosf->K <= SOSF_MAXK && sosf->warm >= 0,
                   "olsnative_forward: the cascade cannot run inside the column pass here (olsnative_sos_supported)");
+        g.nf_flag = (int *)scratch("olsn_nf_flag", (size_t)g.nframes * sizeof(int), stream);
         sos_unit = envi("TFX_OLS_SOS_UNIT_B0", 1) != 0 && sos_unit_rows(sosf->sos, sosf->K, sosk.co);
         for (int64_t s = 0; s < sosf->K && !sos_unit; ++s) {
             const double *co = sosf->sos + 6 * s;                 // b0 b1 b2 a0 a1 a2; a0 is not used (iir_cpu.cpp:86)
@@ -2021,6 +2122,12 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
             TFX_HIP(hipEventRecord(ev_join[i], lane_stream[i]));
             TFX_HIP(hipStreamWaitEvent(user_stream, ev_join[i], 0));
         }
+    }
+    if (sosf) {                           // non-finite values stay in a recursion: see ols_sos_nonfinite_fix_kernel
+        const unsigned chunks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, g.Tout >> 16));
+        hipLaunchKernelGGL(ols_sos_nonfinite_fix_kernel, dim3(chunks, (unsigned)C, (unsigned)(1 + (sosf->sections ? sosf->K : 0))), dim3(256), 0,
+                           user_stream, y, sosf->sections, g, sosk.warm_blocks);
+        TFX_HIP(hipGetLastError());
     }
     if (g.ep_stat >= 0)                   // after the join: all partials are in
         stat_finish(g.ep_partial, ep->per_row ? C : 1, (ep->per_row ? g.F : g.nframes) * (g.N2 / OLS_CB), g.ep_stat,

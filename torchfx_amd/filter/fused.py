@@ -97,8 +97,11 @@ class CascadeFIR(nn.Module):
     column pass (``tfx_sos_fft_conv_forward``) instead of as a pass over the signal of its own.  Stateless like the
     ``FusedSOSCascade`` the reference builds per materialisation (``wave.py:221-233``: its state is dropped with it).
 
-    Rows the kernel does not serve (another dtype, a length that is not a multiple of 32, a misaligned view, a host tensor)
-    run the two steps staged -- same arithmetic, two launches."""
+    Rows of any length and any float alignment are served (a row that is not a whole number of 128-byte lines moves its
+    frame grid, ``row_shift`` in ``csrc/olsnative.hip``); non-finite samples poison the rest of their row exactly as in the
+    staged pair.  What still takes the staged pair of launches -- same arithmetic, two launches -- is listed by
+    :meth:`route`, which ``Wave.explain()`` prints: another dtype, a host tensor, or a batch below
+    ``MIN_PAIRS`` frame pairs (there the two launches are the *faster* plan)."""
 
     MIN_PAIRS = 256          # frame pairs below which the staged pair of launches is the faster plan (profiles/r05_experiments.txt section 11)
 
@@ -106,6 +109,7 @@ class CascadeFIR(nn.Module):
         super().__init__()
         self._table, self.fir = table, fir
         self._planner_built = True
+        self.last_route: tuple[str, str] | None = None
 
     @property
     def _sos(self) -> Tensor:
@@ -115,27 +119,49 @@ class CascadeFIR(nn.Module):
     def fs(self) -> int | None:
         return self._table.fs
 
+    def route(self, x: Tensor, return_sections: bool = False) -> tuple[str, str, dict | None]:
+        """``("fused" | "staged", why, plan_info)`` for this tensor -- the decision :meth:`forward` takes, without running it."""
+        from torchfx_amd import torchfx_ext
+
+        k = int(self.fir.kernel.numel())
+        if x.ndim not in (1, 2, 3):
+            return "staged", f"{x.ndim}-d input", None
+        if not x.is_cuda:
+            return "staged", "host tensor (the fused step is a device kernel)", None
+        if x.dtype != torch.float32:
+            return "staged", f"{x.dtype} signal (the fused step reads float32 rows)", None
+        rows = x.reshape(-1, x.shape[-1])                     # a view where possible; the op makes strided rows contiguous itself
+        info = torchfx_ext.sos_fft_conv_plan_info(int(rows.shape[-1]), self._table.sos, k, (k - 1, 0))
+        if info is None:
+            return "staged", "geometry not served (tfx_sos_fft_conv_supported)", None
+        pairs = (int(rows.shape[0]) * info["F"] + 1) // 2
+        if not return_sections and pairs < self.MIN_PAIRS:
+            return "staged", (f"{pairs} frame pairs < {self.MIN_PAIRS}: the recursion pass needs hundreds of pairs in flight, "
+                              "two launches are faster here"), info
+        return "fused", f"recursion inside pass A, {1 << (info['N'].bit_length() - 1)}-point blocks, {pairs} frame pairs", info
+
+    def extra_repr(self) -> str:
+        r = self.last_route
+        return f"sections={self._table.sections}, taps={int(self.fir.kernel.numel())}" + (f", route={r[0]} ({r[1]})" if r else "")
+
     @torch.no_grad()
     def forward(self, x: Tensor, epilogue=None, return_sections: bool = False):
         from torchfx_amd import torchfx_ext
 
         if x.ndim not in (1, 2, 3):
             raise ValueError("Input must be of shape [T], [C, T], or [B, C, T]")
-        taps = self.fir.kernel.reshape(-1)
-        k = int(taps.numel())
-        rows = x.reshape(-1, x.shape[-1])
-        info = None
-        if x.is_cuda and x.dtype == torch.float32 and rows.is_contiguous() and rows.data_ptr() % 16 == 0:
-            info = torchfx_ext.sos_fft_conv_plan_info(int(rows.shape[-1]), self._table.sos, k, (k - 1, 0))
-        # the recursion pass runs one workgroup per frame PAIR for a whole frame: it needs a few hundred pairs in flight (64 ch x 600 s:
-        # 480); a small batch is faster as two launches (cascade kernel, then the plain pipeline) -- unless sections are asked for
-        if info is not None and (return_sections or int(rows.shape[0]) * info["F"] >= 2 * self.MIN_PAIRS):
+        path, why, _ = self.route(x, return_sections)
+        self.last_route = (path, why)
+        if path == "fused":
+            taps = self.fir.kernel.reshape(-1)
+            k = int(taps.numel())
+            rows = x.reshape(-1, x.shape[-1])
             out = torchfx_ext.sos_fft_conv_forward(rows, self._table.sos, taps, (k - 1, 0), return_sections=return_sections,
                                                    epilogue=epilogue)
             if return_sections:
                 return out[0].reshape(x.shape), out[1]
             return out.reshape(x.shape)
         if return_sections:
-            raise RuntimeError("CascadeFIR: section taps come from the fused pass only (float32 rows of a multiple of 32 samples)")
+            raise RuntimeError(f"CascadeFIR: section taps come from the fused pass only ({why})")
         y = CascadeStream(self._table)(x)                  # fresh state, like the FusedSOSCascade of one materialisation
         return self.fir(y, epilogue) if epilogue is not None else self.fir(y)

@@ -247,6 +247,8 @@ def _instantiate(cached: list) -> list:
             c._planner_built = True
             if hasattr(m, "fold_refused"):
                 c.fold_refused = m.fold_refused
+            if hasattr(m, "recursive_refused"):
+                c.recursive_refused = m.recursive_refused
             return c
         if isinstance(m, Epilogued) and getattr(m.producer, "_planner_built", False):
             return Epilogued(fresh(m.producer), m.gain, m.norm)
@@ -486,9 +488,10 @@ class Wave:
         materialisation -- ``wave.py:221-233``) followed by an FFT-mode FIR runs as ONE overlap-save pipeline
         with the float64 recursion inside the forward column pass (``filter.fused.CascadeFIR``): the reference's
         arithmetic, one pass over the signal less.  Only where the kernel serves the geometry
-        (``torchfx_ext.sos_fft_conv_supported``: float32 rows of a multiple of 32 samples, <= 8 sections whose memory
-        fades within a 4096-sample row, taps long enough for the 2^20-point block); a lone IIR step, a user-held
-        ``FusedSOSCascade`` (stateful across waves) and direct-mode FIRs stay staged."""
+        (``torchfx_ext.sos_fft_conv_supported``: float32 rows of any length, <= 8 sections whose memory fades within a
+        4096-sample row, taps long enough for the 2^20-point block); a lone IIR step, a user-held ``FusedSOSCascade``
+        (stateful across waves) and direct-mode FIRs stay staged.  A cascade that stays staged carries the reason
+        (``recursive_refused``), which :meth:`explain` prints."""
         from torchfx_amd import torchfx_ext
         from torchfx_amd.filter.fused import CascadeFIR, FusedSOSCascade
 
@@ -506,9 +509,47 @@ class Wave:
                     out.append(CascadeFIR(m._stream.table, nxt))
                     i += 2
                     continue
+                m.recursive_refused = Wave._recursive_refusal(m._sos, k, length)
             out.append(m)
             i += 1
         return out
+
+    @staticmethod
+    def _recursive_refusal(sos: Tensor, taps: int, length: int) -> str:
+        """Why ``tfx_sos_fft_conv_supported`` said no (host-only queries, the same ones the library asks itself)."""
+        from torchfx_amd import torchfx_ext
+
+        if int(sos.shape[0]) > 8:
+            return f"{int(sos.shape[0])} sections > 8"
+        warm = torchfx_ext.sos_fft_conv_warmup(sos)
+        if warm < 0 or warm > 4096:
+            return f"the cascade's memory ({warm} samples to 2^-40) is longer than a 4096-sample row of the transform"
+        try:
+            info = torchfx_ext.ols_plan_info(taps, length, (taps - 1, 0), torch.float32)
+            return f"{taps} taps on rows of {length} samples run the {info['path']} path, not the 2^20 / 2^21-point three-pass pipeline"
+        except RuntimeError as e:
+            return str(e)
+
+    def explain(self) -> list[str]:
+        """One line per step of :meth:`plan` for THIS tensor: the step, the route it will take (``CascadeFIR``: the fused
+        recursion-in-pass-A pipeline or the staged pair of launches) and why."""
+        from torchfx_amd.effect import Epilogued
+        from torchfx_amd.filter.fused import CascadeFIR, FusedSOSCascade
+
+        lines = []
+        for m in self.plan():
+            inner = m.producer if isinstance(m, Epilogued) else m
+            line = type(m).__name__ + (f"[{type(inner).__name__}]" if inner is not m else "")
+            if isinstance(inner, CascadeFIR):
+                path, why, _ = inner.route(self._ys)
+                line += f": {path} -- {why}"
+            elif isinstance(inner, FusedSOSCascade):
+                if getattr(inner, "recursive_refused", None):
+                    line += f": staged -- {inner.recursive_refused}"
+                elif getattr(inner, "fold_refused", None) is not None:
+                    line += f": staged -- spectral fold refused (error estimate {inner.fold_refused:.1e})"
+            lines.append(line)
+        return lines
 
     def _materialize(self) -> None:
         if not self._pipeline:
