@@ -27,6 +27,7 @@
 #ifndef TORCHFX_HIP_H
 #define TORCHFX_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -379,6 +380,21 @@ const char *tfx_prof_collect(void);
 
 /* Drop all cached plans / device workspaces (tests, memory pressure). */
 int tfx_clear_caches(void);
+
+/* Workspace under the caller's control.  The overlap-save pipelines keep device workspaces between calls (the default chain
+ * step: three lanes x up to 3.75 GB); by default they come from hipMalloc / hipFree.  A host that runs its own device allocator
+ * installs it here -- the torch module (csrc/ext/torchfx_ext.cpp) routes the workspaces through PyTorch's caching allocator, so
+ * torch.cuda.memory_allocated(), its free-cached-blocks-and-retry and its OutOfMemoryError cover them (the reference allocates
+ * every temporary as a torch tensor: src/torchfx/filter/_fftconv.py:119-140).
+ *   alloc_fn(bytes, device, stream, ctx) -> device pointer, or NULL when it cannot (the pipeline then asks for a smaller slab:
+ *       fewer frame pairs per launch, down to 8; below that the call fails with "out of device memory")
+ *   free_fn(ptr, device, ctx)               called after a device synchronise
+ * Both NULL restores hipMalloc / hipFree.  Buffers held at the time of the call keep the allocator they came from.
+ * tfx_workspace_bytes(): bytes of workspace held right now (all streams and devices); tfx_clear_caches() releases them. */
+typedef void *(*tfx_alloc_fn)(size_t bytes, int device, void *stream, void *ctx);
+typedef void (*tfx_free_fn)(void *ptr, int device, void *ctx);
+int tfx_set_workspace_allocator(tfx_alloc_fn alloc_fn, tfx_free_fn free_fn, void *ctx);
+int64_t tfx_workspace_bytes(void);
 
 #ifdef __cplusplus
 }

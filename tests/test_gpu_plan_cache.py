@@ -76,3 +76,46 @@ def test_first_use_inside_a_capture_is_refused_and_a_warm_filter_captures():
     torch.cuda.synchronize()
     y2 = E.fft_conv_forward(x, cold, (299, 0))                      # ... and the library is fine afterwards
     assert torch.isfinite(y2).all()
+
+
+def test_workspaces_live_in_torchs_allocator_and_shrink_under_pressure():
+    """tfx_set_workspace_allocator: the overlap-save workspaces come from PyTorch's caching allocator -- counted
+    by torch.cuda.memory_allocated, released by clear_caches + empty_cache -- and with most of the device taken by torch
+    tensors the chain step either runs on smaller slabs (same numbers) or raises torch's OutOfMemoryError, never a raw HIP one."""
+    import numpy as np
+    from tests.gpu_common import DEV, ext, rnd
+    E = ext()
+    E.clear_caches()
+    torch.cuda.empty_cache()
+    from torchfx_amd import filter as F
+    f1 = F.LoButterworth(2000, order=6, fs=48000)
+    f2 = F.ParametricEQ(frequency=1000, q=2.0, gain=3.0, fs=48000)
+    f1.compute_coefficients(); f2.compute_coefficients()
+    sos = torch.cat([f1._sos, f2._sos])
+    K = 20001
+    k = np.random.default_rng(0).standard_normal(K) * np.exp(-np.arange(K) / 3000.0)
+    kf = torch.from_numpy((k / np.abs(k).sum()).astype(np.float32)[::-1].copy())
+    x = torch.from_numpy(rnd((24, 6 << 20), 3)).to(DEV)             # 24 x 7 frames of 2^20 points = 84 pairs
+    base = torch.cuda.memory_allocated()
+    assert E.workspace_bytes() == 0
+    y_ref = E.sos_fft_conv_forward(x, sos, kf, (K - 1, 0), force_block=1)
+    held = E.workspace_bytes()
+    assert held >= 84 * (1 << 23) // 3                                # three lanes of 28 pairs x 8 MB
+    assert torch.cuda.memory_allocated() - base >= held               # ... counted by torch (plus y)
+    E.clear_caches()
+    ybytes = y_ref.numel() * 4
+    assert E.workspace_bytes() == 0 and torch.cuda.memory_allocated() - base - ybytes < held // 4
+    torch.cuda.empty_cache()
+    # take all of the device with torch tensors but the output and ~400 MB: the slabs must shrink (84 pairs need 700 MB)
+    free, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(max(0, free - ybytes - (400 << 20)), dtype=torch.uint8, device=DEV)
+    try:
+        y = E.sos_fft_conv_forward(x, sos, kf, (K - 1, 0), force_block=1)
+        assert E.workspace_bytes() < held
+        assert torch.equal(y, y_ref)                                  # the slab size never changes a sample
+    except torch.OutOfMemoryError:
+        pass                                                          # torch's own error type: acceptable, a raw HIP error is not
+    finally:
+        del hog
+        E.clear_caches()
+        torch.cuda.empty_cache()

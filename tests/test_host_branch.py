@@ -21,8 +21,13 @@ def test_cfg1_literally(golden):
     """BASELINE.json configs[0]: single LoButterworth order-4, 1 ch x 1 s @ 48 kHz float32 on the CPU path."""
     g = golden("iir_cfg1")
     y, sx, sy = _mod().sos_forward(torch.from_numpy(g["x"]), None, torch.from_numpy(g["sos"]), None, None)
-    assert y.dtype == torch.float32 and np.array_equal(y.numpy(), g["y"])
+    # float64 out whatever x is (iir_cpu.cpp: y = empty_like(x_f64)); the reference's Python downcasts (_ops.py:149-176)
+    assert y.dtype == torch.float64 and np.array_equal(y.to(torch.float32).numpy(), g["y"])
     assert _err(sx, g["state_x"]) <= 2e-10 and _err(sy, g["state_y"]) <= 2e-10
+    # the coefficients come from `sos` (2nd argument) on host tensors, like binding.cpp:52-66; `sos_cpu` when it is absent
+    wrong = torch.zeros_like(torch.from_numpy(g["sos"]))
+    y2, _, _ = _mod().sos_forward(torch.from_numpy(g["x"]), torch.from_numpy(g["sos"]), wrong, None, None)
+    assert torch.equal(y2, y)
 
 
 def test_cfg2_section_by_section(golden):
@@ -34,7 +39,7 @@ def test_cfg2_section_by_section(golden):
         cur, _, _ = m.sos_forward(cur, None, sos[k:k + 1], None, None)
         assert _err(cur, g["y_sections"][k]) <= 2e-11 * max(1.0, float(np.abs(g["y_sections"][k]).max())), k
     y, sx, sy = m.sos_forward(torch.from_numpy(g["x"]), None, sos, None, None)
-    assert np.array_equal(y.numpy(), g["y"])
+    assert np.array_equal(y.to(torch.float32).numpy(), g["y"])
     assert _err(sx, g["state_x"]) <= 2e-10 and _err(sy, g["state_y"]) <= 2e-10
 
 

@@ -67,6 +67,8 @@ SIGNATURES = {
     "tfx_prof_enable": (_int, [_int]),
     "tfx_prof_collect": (ctypes.c_char_p, []),
     "tfx_clear_caches": (_int, []),
+    "tfx_set_workspace_allocator": (_int, [_vp, _vp, _vp]),
+    "tfx_workspace_bytes": (_i64, []),
 }
 
 

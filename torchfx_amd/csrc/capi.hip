@@ -5,6 +5,7 @@
 #include "epilogue.h"
 #include "../../include/torchfx_hip.h"
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -68,13 +69,13 @@ int64_t fftconv_block_size(int64_t K, int64_t L);
 namespace {
 struct EnvTable {
     std::mutex mu;
-    std::map<const void *, std::pair<bool, int64_t>> by_ptr;      // literal address -> (set, value)
-    std::map<std::string, std::pair<bool, int64_t>> by_name;
-    bool dynamic = false;
+    std::map<std::string, std::pair<bool, int64_t>> by_name;      // keyed by the knob's TEXT: any pointer may ask
+    std::atomic<bool> dynamic{false};                             // read by every lookup, written by env_reload
+    std::atomic<uint64_t> generation{1};                          // bumped by env_reload: the per-thread shortcuts below expire
     EnvTable()
     {
         const char *e = getenv("TFX_ENV_DYNAMIC");
-        dynamic = e && *e && *e != '0';
+        dynamic.store(e && *e && *e != '0', std::memory_order_relaxed);
     }
 };
 EnvTable &env_table()
@@ -87,31 +88,45 @@ EnvTable &env_table()
 int64_t env_i64(const char *name, int64_t dflt)
 {
     EnvTable &t = env_table();
-    if (t.dynamic) {
+    if (t.dynamic.load(std::memory_order_relaxed)) {
         const char *e = getenv(name);
         return (e && *e) ? atoll(e) : dflt;
     }
-    std::lock_guard<std::mutex> lk(t.mu);
-    auto it = t.by_ptr.find((const void *)name);
-    if (it == t.by_ptr.end()) {
+    // A per-thread shortcut keyed by the pointer sits in front of the shared table (a dispatch asks for about ten knobs; no lock
+    // in steady state).  An entry is trusted only while the text behind the pointer is still the knob it was stored for, so a
+    // reused buffer cannot alias another knob, and only within the generation it was read in.
+    struct Local {
+        uint64_t gen = 0;
+        std::map<const void *, std::pair<std::string, std::pair<bool, int64_t>>> by_ptr;
+    };
+    thread_local Local loc;
+    const uint64_t gen = t.generation.load(std::memory_order_acquire);
+    if (loc.gen != gen) { loc.by_ptr.clear(); loc.gen = gen; }
+    auto it = loc.by_ptr.find((const void *)name);
+    if (it != loc.by_ptr.end() && it->second.first == name)
+        return it->second.second.first ? it->second.second.second : dflt;
+    std::pair<bool, int64_t> v;
+    {
+        std::lock_guard<std::mutex> lk(t.mu);
         auto in = t.by_name.find(name);
         if (in == t.by_name.end()) {
             const char *e = getenv(name);
             in = t.by_name.emplace(name, std::make_pair(e && *e, (e && *e) ? (int64_t)atoll(e) : (int64_t)0)).first;
         }
-        it = t.by_ptr.emplace((const void *)name, in->second).first;
+        v = in->second;
     }
-    return it->second.first ? it->second.second : dflt;
+    loc.by_ptr[(const void *)name] = std::make_pair(std::string(name), v);
+    return v.first ? v.second : dflt;
 }
 
 void env_reload()
 {
     EnvTable &t = env_table();
     std::lock_guard<std::mutex> lk(t.mu);
-    t.by_ptr.clear();
     t.by_name.clear();
     const char *e = getenv("TFX_ENV_DYNAMIC");
-    t.dynamic = e && *e && *e != '0';
+    t.dynamic.store(e && *e && *e != '0', std::memory_order_relaxed);
+    t.generation.fetch_add(1, std::memory_order_release);
 }
 
 // ---- errors ------------------------------------------------------------------------------------
@@ -170,38 +185,77 @@ void prof_end(hipStream_t s)
 }
 
 // ---- scratch -------------------------------------------------------------------------------------
+// Buffers come from hipMalloc unless the host installed its own allocator (tfx_set_workspace_allocator: the torch module routes
+// them through PyTorch's caching allocator, so torch.cuda.memory_allocated, its out-of-memory retry and its error type see them).
 struct Scratch {
     void *p = nullptr;
     size_t bytes = 0;
+    bool hooked = false;                 // allocated by the installed hook (freed through it, even if the hook was replaced since)
+    tfx_free_fn free_fn = nullptr;
+    void *ctx = nullptr;
+    int dev = 0;
 };
 static std::mutex g_scr_mu;
 static std::map<std::string, Scratch> g_scr;
-void *scratch(const char *tag, size_t bytes, hipStream_t stream)
+static tfx_alloc_fn g_alloc_fn = nullptr;
+static tfx_free_fn g_free_fn = nullptr;
+static void *g_alloc_ctx = nullptr;
+
+static void scratch_release(Scratch &s)
+{
+    if (!s.p) return;
+    (void)hipDeviceSynchronize();        // the old buffer may still be in use by queued work: drain before freeing
+    if (s.hooked) s.free_fn(s.p, s.dev, s.ctx);
+    else (void)hipFree(s.p);
+    s.p = nullptr;
+    s.bytes = 0;
+}
+
+void *scratch_try(const char *tag, size_t bytes, hipStream_t stream)
 {
     std::lock_guard<std::mutex> lk(g_scr_mu);
     char key[96];
-    snprintf(key, sizeof(key), "%s@%p#%d", tag, (void *)stream, current_device());
+    const int dev = current_device();
+    snprintf(key, sizeof(key), "%s@%p#%d", tag, (void *)stream, dev);
     Scratch &s = g_scr[key];
-    if (s.bytes < bytes) {
-        if (s.p) {
-            // the old buffer may still be in use by queued work: drain before freeing
-            (void)hipDeviceSynchronize();
-            (void)hipFree(s.p);
-            s.p = nullptr;
-            s.bytes = 0;
-        }
-        TFX_HIP(hipMalloc(&s.p, bytes));
-        s.bytes = bytes;
+    if (s.bytes >= bytes) return s.p;
+    scratch_release(s);
+    if (g_alloc_fn) {
+        void *q = g_alloc_fn(bytes, dev, (void *)stream, g_alloc_ctx);
+        if (!q) return nullptr;
+        s.p = q; s.hooked = true; s.free_fn = g_free_fn; s.ctx = g_alloc_ctx;
+    } else {
+        void *q = nullptr;
+        if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        s.p = q; s.hooked = false;
     }
+    s.bytes = bytes; s.dev = dev;
     return s.p;
+}
+void *scratch(const char *tag, size_t bytes, hipStream_t stream)
+{
+    void *q = scratch_try(tag, bytes, stream);
+    TFX_CHECK(q || bytes == 0, "out of device memory: a %zu-byte workspace (%s) could not be allocated%s", bytes, tag,
+              g_alloc_fn ? " by the installed workspace allocator" : " by hipMalloc");
+    return q;
+}
+size_t scratch_bytes()
+{
+    std::lock_guard<std::mutex> lk(g_scr_mu);
+    size_t n = 0;
+    for (auto &kv : g_scr) n += kv.second.bytes;
+    return n;
 }
 void scratch_clear()
 {
     std::lock_guard<std::mutex> lk(g_scr_mu);
-    (void)hipDeviceSynchronize();
-    for (auto &kv : g_scr)
-        if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto &kv : g_scr) scratch_release(kv.second);
     g_scr.clear();
+}
+void scratch_set_allocator(tfx_alloc_fn a, tfx_free_fn f, void *ctx)
+{
+    std::lock_guard<std::mutex> lk(g_scr_mu);
+    g_alloc_fn = a; g_free_fn = f; g_alloc_ctx = ctx;
 }
 
 // ---- elementwise kernels ----------------------------------------------------------------------------
@@ -581,6 +635,16 @@ const char *tfx_prof_collect(void)
     out += "}";
     return out.c_str();
 }
+
+int tfx_set_workspace_allocator(tfx_alloc_fn alloc_fn, tfx_free_fn free_fn, void *ctx)
+{
+    TFX_API_BEGIN
+    TFX_CHECK((alloc_fn == nullptr) == (free_fn == nullptr), "tfx_set_workspace_allocator: give both functions or neither");
+    scratch_set_allocator(alloc_fn, free_fn, ctx);       // buffers already held keep the allocator they came from
+    TFX_API_END
+}
+
+int64_t tfx_workspace_bytes(void) { return (int64_t)scratch_bytes(); }
 
 int tfx_clear_caches(void)
 {

@@ -59,16 +59,19 @@ struct ProfScope {
 // on the SAME stream (stream order makes the reuse safe); calls on different streams never share a
 // buffer.  Host-side enqueueing is serialised by the API lock (capi.hip), so two threads can drive
 // two streams concurrently.
-void *scratch(const char *tag, size_t bytes, hipStream_t stream);
+void *scratch(const char *tag, size_t bytes, hipStream_t stream);        // throws when the allocation fails
+void *scratch_try(const char *tag, size_t bytes, hipStream_t stream);    // null when it fails (callers that can do with less)
+size_t scratch_bytes();                                                  // bytes held right now, all tags / streams / devices
 void scratch_clear();
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- tuning knobs from the environment (TFX_*) --------------------------------------------------
 // Read ONCE per process and name (capi.hip): a dispatch asks for about ten of them and a short-row call lasts 8-30 us.
-// `name` must be a string literal (the table is keyed by its address first, by its text on a miss).  Development and
-// tests change knobs inside one process: TFX_ENV_DYNAMIC=1 (read when the library is first used) makes every lookup a
-// fresh getenv, and tfx_env_reload() drops the table.
+// The table is keyed by the knob's text (a per-thread, pointer-keyed shortcut in front of it is checked against the text, so
+// any pointer may ask).  A knob changed after its first read is NOT seen -- development and tests that flip knobs inside one
+// process set TFX_ENV_DYNAMIC=1 (read when the library is first used: every lookup becomes a fresh getenv) or call
+// tfx_env_reload() / torchfx_ext.env_reload(), which drops the table.
 int64_t env_i64(const char *name, int64_t dflt);
 void env_reload();
 

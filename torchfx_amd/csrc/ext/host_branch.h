@@ -84,7 +84,7 @@ inline std::tuple<Tensor, Tensor, Tensor> sos_forward(const Tensor &x_in, const 
         pybind11::gil_scoped_release nogil;
         df1_rows(x.data_ptr<double>(), y.data_ptr<double>(), C, T, co.data(), K, sx.data_ptr<double>(), sy.data_ptr<double>());
     }
-    return {y.to(x_in.scalar_type()), sx, sy};
+    return {y, sx, sy};          // float64 whatever x is, like iir_cpu.cpp (y = empty_like(x_f64)); the caller downcasts (_ops.py:149-176)
 }
 
 // biquad_forward on host tensors (binding.cpp:30-50 -> biquad_forward_cpu, iir_cpu.cpp:10-62): states [C, 2]
@@ -105,7 +105,7 @@ inline std::tuple<Tensor, Tensor, Tensor> biquad_forward(const Tensor &x_in, con
         pybind11::gil_scoped_release nogil;
         df1_rows(x.data_ptr<double>(), y.data_ptr<double>(), C, T, co, 1, sx.data_ptr<double>(), sy.data_ptr<double>());
     }
-    return {y.to(x_in.scalar_type()), sx, sy};
+    return {y, sx, sy};          // float64 whatever x is, like iir_cpu.cpp (y = empty_like(x_f64)); the caller downcasts (_ops.py:149-176)
 }
 
 // delay_line_forward on host tensors (binding.cpp:68-81 -> delay_cpu.cpp:17-66): y[n] = x[n] + mix * decay * x[n - delay];

@@ -17,10 +17,14 @@
 #include <torch/extension.h>
 #include <torch/library.h>
 
+#include <c10/hip/HIPCachingAllocator.h>
 #include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 
+#include <cstdlib>
+#include <exception>
 #include <optional>
+#include <string>
 #include <tuple>
 #include <vector>
 
@@ -32,8 +36,46 @@ namespace {
 using at::Tensor;
 using OptTensor = std::optional<Tensor>;
 
+// ---- workspaces through PyTorch's caching allocator (tfx_set_workspace_allocator, include/torchfx_hip.h) -------------------------
+// The overlap-save pipelines keep multi-GB workspaces between calls.  Allocated here they show up in torch.cuda.memory_allocated(),
+// an allocation under memory pressure first frees torch's cached blocks and retries, and when it still fails the library asks
+// for a smaller slab; only if even 8 frame pairs do not fit does the op fail -- with torch's own OutOfMemoryError (kept in
+// `pending_oom` by the hook, rethrown by check_rc), not a raw hipErrorOutOfMemory.  TORCHFX_AMD_WORKSPACE=hip keeps hipMalloc.
+thread_local std::exception_ptr pending_oom;
+
+void *torch_ws_alloc(size_t bytes, int device, void *stream, void *)
+{
+    try {
+        c10::hip::HIPGuard guard((c10::DeviceIndex)device);
+        return c10::hip::HIPCachingAllocator::raw_alloc_with_stream(bytes, (hipStream_t)stream);
+    } catch (...) {
+        pending_oom = std::current_exception();
+        return nullptr;
+    }
+}
+
+void torch_ws_free(void *ptr, int device, void *)
+{
+    try {
+        c10::hip::HIPGuard guard((c10::DeviceIndex)device);
+        c10::hip::HIPCachingAllocator::raw_delete(ptr);
+    } catch (...) {            // interpreter shutdown: the allocator may be gone
+    }
+}
+
+struct WorkspaceHook {
+    WorkspaceHook()
+    {
+        const char *e = std::getenv("TORCHFX_AMD_WORKSPACE");
+        if (!(e && std::string(e) == "hip")) tfx_set_workspace_allocator(torch_ws_alloc, torch_ws_free, nullptr);
+    }
+} workspace_hook;
+
 void check_rc(int rc, const char *what)
 {
+    std::exception_ptr oom;
+    std::swap(oom, pending_oom);           // an allocation that failed on the way to a smaller slab is not an error of a call that succeeded
+    if (rc != 0 && oom) std::rethrow_exception(oom);
     TORCH_CHECK(rc == 0, what, ": ", tfx_last_error());
 }
 
@@ -674,8 +716,9 @@ PYBIND11_MODULE(torchfx_ext, m)
           py::arg("a1"), py::arg("a2"), py::arg("state_x"), py::arg("state_y"));
     m.def("sos_forward",
           [](const Tensor &x, const OptTensor &sos, const Tensor &sos_cpu, const OptTensor &state_x, const OptTensor &state_y) {
-              (void)sos;      // device copy of the coefficients: the reference's sync-avoidance argument, unused here
-              if (!x.is_cuda()) return host::sos_forward(x, sos_cpu, state_x, state_y);             // binding.cpp:52-66
+              // host tensors: binding.cpp:52-66 hands `sos` (the 2nd argument) to sos_forward_cpu; `sos_cpu` only when it is absent
+              if (!x.is_cuda()) return host::sos_forward(x, (sos.has_value() && sos->defined() && !sos->is_cuda()) ? *sos : sos_cpu, state_x, state_y);
+              // device tensors: `sos` is the reference's device copy of the coefficients (its sync-avoidance argument), unused here
               return sos_op(x, sos_cpu, state_x, state_y, std::nullopt, -1);
           },
           "SOS cascade forward pass (x, sos, sos_cpu, state_x, state_y) -> (y, new_state_x, new_state_y)", py::arg("x"),

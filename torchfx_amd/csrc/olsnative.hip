@@ -488,7 +488,12 @@ ols_col_fwd16_sos_kernel(const float *__restrict__ x, cpx *__restrict__ T, const
 #pragma unroll
         for (int i = 0; i < 8; ++i) *(float4 *)&S[(lrow + 64 * i) * SOSF_LS + 4 * lpart] = P[i];
         // the block being filtered is the one fetched last: its clock is one block behind ta / tb
-        const int64_t tcur = (mine_b ? tb : ta) - OLS_CB;
+        int64_t tcur = (mine_b ? tb : ta) - OLS_CB;
+        {   // wave-uniform (a wavefront lies in one frame): keep it in scalar registers
+            const unsigned lo32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uint64_t)tcur);
+            const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uint64_t)tcur >> 32));
+            tcur = (int64_t)(((uint64_t)hi32 << 32) | lo32);
+        }
         // samples [first, last) of this thread's line lie inside the row.  In front of the row the recursion sees zeros from
         // zero state and returns zeros by itself; behind its end the filter's tail is cut (the reference filters T samples and
         // the FIR pads afterwards)
@@ -536,14 +541,17 @@ ols_col_fwd16_sos_kernel(const float *__restrict__ x, cpx *__restrict__ T, const
             // Two real frames ride one complex transform: a non-finite sample of one would come out in BOTH.  A state that
             // has gone non-finite stays so (flag + fix-up below): from here on this line enters the transform as zeros -- the
             // frame's own output is replaced by NaN afterwards, its partner's stays what it is.
-            if (!(__builtin_fabs(h1[KS]) <= 1.7976931348623157e308)) {
-#pragma unroll
-                for (int n = 0; n < SOSF_CH; ++n) u[n] = 0.0f;
-            }
+            // (the stretch is overwritten in the stage, not in the registers: sixteen samples kept live to the end of the stretch
+            // cost three spilled registers at the 128 this kernel has)
             if (blk >= 0) {
 #pragma unroll
                 for (int i = 0; i < SOSF_CH / 4; ++i)
                     *(float4 *)&S[tid * SOSF_LS + SOSF_CH * j + 4 * i] = make_float4(u[4 * i], u[4 * i + 1], u[4 * i + 2], u[4 * i + 3]);
+                if (!(__builtin_fabs(h1[KS]) <= 1.7976931348623157e308)) {
+#pragma unroll
+                    for (int i = 0; i < SOSF_CH / 4; ++i)
+                        *(float4 *)&S[tid * SOSF_LS + SOSF_CH * j + 4 * i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
         }
         if (sf.prio) __builtin_amdgcn_s_setprio(3);
@@ -1979,8 +1987,23 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
         if (slab > per_lane) slab = std::max<int64_t>(per_lane, 1);
     }
     if (slab > npairs) slab = npairs;
-    cpx *T = (cpx *)scratch("olsn_T", (size_t)slab * (size_t)OLS_N1 * (size_t)g.P2 * sizeof(cpx), stream);
-    tr.mark("workspace lane 0");
+    // Workspaces of all lanes, from the installed allocator (tfx_set_workspace_allocator: PyTorch's caching allocator under the
+    // torch module) or hipMalloc.  When memory is short the slab is halved -- fewer frame pairs per launch, same results --
+    // down to 8 pairs; below that the call fails with "out of device memory".
+    static const char *lane_tags[8] = {"olsn_T", "olsn_T2", "olsn_T3", "olsn_T4", "olsn_T5", "olsn_T6", "olsn_T7", "olsn_T8"};
+    cpx *Tlane[8] = {};
+    for (;;) {
+        const int want = (npairs <= slab) ? 1 : nlanes;
+        const size_t bytes = (size_t)slab * (size_t)OLS_N1 * (size_t)g.P2 * sizeof(cpx);
+        int got = 0;
+        for (; got < want; ++got)
+            if (!(Tlane[got] = (cpx *)scratch_try(lane_tags[got], bytes, stream))) break;
+        if (got == want) break;
+        if (slab <= 8) { (void)scratch(lane_tags[got], bytes, stream); break; }          // throws with the allocator's name in the message
+        slab = std::max<int64_t>(8, slab / 2);
+    }
+    cpx *T = Tlane[0];
+    tr.mark("workspaces");
     const size_t shm_col = OLS_SHM_COL;
     const size_t shm_row = (size_t)(g.N2 * 5) * sizeof(cpx);
     const int probe = (int)envi("TFX_OLS_PROBE", 0);           // development only (tools/ols_knobs.py)
@@ -2019,13 +2042,8 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     hipStream_t *lane_stream = ln_.stream;
     hipEvent_t &ev_fork = ln_.fork;
     hipEvent_t *ev_join = ln_.join;
-    cpx *Tlane[MAXL] = {T, T, T, T, T, T, T, T};
     hipStream_t user_stream = stream;
     if (nlanes > 1) {
-        static const char *tags[MAXL] = {"olsn_T", "olsn_T2", "olsn_T3", "olsn_T4", "olsn_T5", "olsn_T6", "olsn_T7", "olsn_T8"};
-        for (int i = 1; i < nlanes; ++i)
-            Tlane[i] = (cpx *)scratch(tags[i], (size_t)slab * (size_t)OLS_N1 * (size_t)g.P2 * sizeof(cpx), user_stream);
-        tr.mark("  lane workspaces");
         ols_make_lanes(dev, nlanes);
         tr.mark("  lane streams / events");
         std::lock_guard<std::mutex> fl(lane_mu);

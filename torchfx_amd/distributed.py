@@ -60,7 +60,6 @@ def gather_rows(y_local: Tensor, n_rows: int, dst: int = 0, group=None, out: Ten
     transfer rides that pair's own xGMI link."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     sizes = [shard_bounds(n_rows, world, r) for r in range(world)]
-    T = y_local.shape[1]
     lo, hi = sizes[rank]
 
     def peer(r: int) -> int:
@@ -69,16 +68,26 @@ def gather_rows(y_local: Tensor, n_rows: int, dst: int = 0, group=None, out: Ten
     # development set-up where several ranks share one GPU) stages device rows through host memory
     nccl = dist.get_backend(group) == "nccl"
     staged = y_local.is_cuda and not nccl
-    # ONE small all-reduce opens every gather, and every rank enters it: (1) the arguments are validated collectively -- a rank
-    # whose block has the wrong shape makes ALL ranks raise instead of leaving the others blocked in the transfer (advisor,
-    # round 4); (2) on RCCL the first communication of a group creates its communicator and needs every rank, also those
-    # whose block is empty (n_rows < world) and who sit the point-to-point batch out.  A few bytes beside a gather of GBs.
-    bad = 0 if y_local.shape[0] == hi - lo else 1
-    flag = torch.tensor([bad, T, -T], dtype=torch.int64, device=y_local.device if nccl else "cpu")
+    # ONE small all-reduce opens every gather, and every rank enters it: (1) EVERY local check -- the block's rank and shape, the
+    # root's `out` buffer -- is made before it and folded into the reduced flag, so a wrong argument on one rank makes ALL ranks
+    # raise instead of leaving the others blocked in the transfer (advisor, rounds 4 and 5); (2) on RCCL the first communication
+    # of a group creates its communicator and needs every rank, also those whose block is empty (n_rows < world) and who sit the
+    # point-to-point batch out.  A few bytes beside a gather of GBs (on RCCL reading the flag is one device-to-host sync).
+    why = None
+    if y_local.dim() != 2:
+        why = f"rank {rank} holds a {y_local.dim()}-d tensor, [rows, T] expected"
+    elif y_local.shape[0] != hi - lo:
+        why = (f"rank {rank} holds {tuple(y_local.shape)}; its block of {n_rows} rows over {world} ranks has {hi - lo} rows")
+    T = int(y_local.shape[1]) if y_local.dim() == 2 else -1
+    if why is None and rank == dst and out is not None and (
+            tuple(out.shape) != (n_rows, T) or out.dtype != y_local.dtype or out.device != y_local.device or not out.is_contiguous()):
+        why = f"out must be a contiguous [{n_rows}, {T}] {y_local.dtype} tensor on {y_local.device}"
+    flag = torch.tensor([0 if why is None else 1, T, -T], dtype=torch.int64, device=y_local.device if nccl else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-    if int(flag[0]) != 0 or int(flag[1]) != -int(flag[2]):
-        raise ValueError(f"gather_rows: rank {rank} holds {tuple(y_local.shape)}; its block of {n_rows} rows over {world} ranks has "
-                         f"{hi - lo} rows and all ranks must agree on the row length (some rank disagrees: every rank raises)")
+    bad, tmax, tmin = (int(v) for v in flag.tolist())              # one transfer of the three values
+    if bad != 0 or tmax != -tmin:
+        raise ValueError("gather_rows: " + (why or f"rank {rank} holds {tuple(y_local.shape)}") +
+                         " -- some rank's arguments are wrong or the ranks disagree on the row length: every rank raises")
     if rank != dst:
         if hi > lo:
             wire = y_local.contiguous()
@@ -88,8 +97,6 @@ def gather_rows(y_local: Tensor, n_rows: int, dst: int = 0, group=None, out: Ten
         return None
     if out is None:
         out = torch.empty((n_rows, T), dtype=y_local.dtype, device=y_local.device)
-    elif tuple(out.shape) != (n_rows, T) or out.dtype != y_local.dtype or out.device != y_local.device or not out.is_contiguous():
-        raise ValueError(f"out must be a contiguous [{n_rows}, {T}] {y_local.dtype} tensor on {y_local.device}")
     out[lo:hi].copy_(y_local)
     ops, landing = [], {}
     for r, (rlo, rhi) in enumerate(sizes):

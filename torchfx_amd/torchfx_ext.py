@@ -33,7 +33,7 @@ from torchfx_amd import native
 
 __all__ = [
     "biquad_forward", "sos_forward", "sos_bank_forward", "sos_bank_sum_forward", "delay_line_forward",
-    "fir_direct_forward", "fft_conv_forward", "sos_fft_conv_forward", "sos_fft_conv_supported", "sos_fft_conv_warmup", "sos_fft_conv_plan_info", "fir_stream_forward", "chunk_forward", "chunk_supported", "normalize_apply", "Epilogue", "sum_forward", "gain_forward", "quantile_abs", "stat_forward", "normalize_forward",
+    "fir_direct_forward", "fft_conv_forward", "sos_fft_conv_forward", "sos_fft_conv_supported", "sos_fft_conv_warmup", "sos_fft_conv_plan_info", "workspace_bytes", "clear_caches", "env_reload", "fir_stream_forward", "chunk_forward", "chunk_supported", "normalize_apply", "Epilogue", "sum_forward", "gain_forward", "quantile_abs", "stat_forward", "normalize_forward",
     "deinterleave_forward", "interleave_forward", "sos_plan_info", "ols_plan_info", "prewarm",
 ]
 
@@ -186,7 +186,20 @@ def sos_fft_conv_plan_info(T: int, sos, taps: int, padding: tuple[int, int] = (0
                                              ctypes.c_int64(s.shape[0]), ctypes.c_int64(int(taps)), ctypes.c_int64(int(padding[0])),
                                              ctypes.c_int64(int(padding[1])), ctypes.c_int(int(force_block)), ctypes.byref(n),
                                              ctypes.byref(h), ctypes.byref(f), ctypes.byref(w))
-    return {"N": n.value, "S": h.value, "F": f.value, "warmup": w.value} if ok else None
+    return {"N": n.value, "S": h.value, "F": f.value, "warmup": w.value, "workspace_bytes_held": workspace_bytes()} if ok else None
+
+
+def clear_caches() -> None:
+    """Drop every cached plan and hand all device workspaces back to their allocator (``tfx_clear_caches``): PyTorch's caching
+    allocator under this module, so ``torch.cuda.empty_cache()`` afterwards returns them to the driver."""
+    L.check(L.load().tfx_clear_caches())
+
+
+def workspace_bytes() -> int:
+    """Bytes of device workspace the library holds right now (overlap-save slabs, statistic partials ...; all streams and
+    devices).  Under the torch module they come from PyTorch's caching allocator (``tfx_set_workspace_allocator``): they are
+    part of ``torch.cuda.memory_allocated()`` and :func:`clear_caches` hands them back to it."""
+    return int(L.load().tfx_workspace_bytes())
 
 
 def sos_fft_conv_warmup(sos) -> int:
@@ -305,6 +318,12 @@ def sos_plan_info(sos) -> dict:
                                   ctypes.byref(prec), ctypes.byref(warm), ctypes.byref(eb)))
     return {"auto_precision": "f32" if prec.value == L.PREC_F32 else "f64",
             "warmup": warm.value, "f32_error_bound": eb.value}
+
+
+def env_reload() -> None:
+    """The library reads every ``TFX_*`` knob ONCE per process; after changing one in ``os.environ`` call this (``tfx_env_reload``)
+    -- or start the process with ``TFX_ENV_DYNAMIC=1`` to make every lookup a fresh ``getenv``."""
+    L.check(L.load().tfx_env_reload())
 
 
 def prewarm(device=None) -> None:
