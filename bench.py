@@ -478,8 +478,8 @@ def cfg5_on_one_gpu(dev, sync, lib, total_channels: int = 512, seconds: float = 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="chain",
                     choices=["chain", "sos", "fir", "fir_fft", "fftconv", "chain_iir_kernel", "chain_fold", "chain_reference_staging"])
     ap.add_argument("--channels", type=int, default=64, help="channels PER GPU (weak scaling)")

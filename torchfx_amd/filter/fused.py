@@ -110,6 +110,7 @@ class CascadeFIR(nn.Module):
         self._table, self.fir = table, fir
         self._planner_built = True
         self.last_route: tuple[str, str] | None = None
+        self._routes: dict = {}          # (shape, dtype, device type, sections asked) -> route(): the geometry query is host work per call otherwise
 
     @property
     def _sos(self) -> Tensor:
@@ -121,6 +122,15 @@ class CascadeFIR(nn.Module):
 
     def route(self, x: Tensor, return_sections: bool = False) -> tuple[str, str, dict | None]:
         """``("fused" | "staged", why, plan_info)`` for this tensor -- the decision :meth:`forward` takes, without running it."""
+        key = (tuple(x.shape), x.dtype, x.device.type, bool(return_sections), self.MIN_PAIRS, self.fir.kernel._version)
+        hit = self._routes.get(key)
+        if hit is None:
+            if len(self._routes) > 64:
+                self._routes.clear()
+            hit = self._routes[key] = self._route(x, return_sections)
+        return hit
+
+    def _route(self, x: Tensor, return_sections: bool) -> tuple[str, str, dict | None]:
         from torchfx_amd import torchfx_ext
 
         k = int(self.fir.kernel.numel())
