@@ -300,7 +300,9 @@ def test_lds_ols_plan_info_paths():
     assert e.ols_plan_info(8193, 44100, (8192, 0))["path"] == "rocfft"
     i = e.ols_plan_info(2049, 2_880_000, (2048, 0), torch.float64)
     assert (i["path"], i["N"]) == ("lds", 8192) and abs(i["bytes_per_sample"] - (8 * 8192 / i["S"] + 8)) < 1e-9
-    assert e.ols_plan_info(4097, 2_880_000, (4096, 0), torch.float64)["path"] == "rocfft"
+    i = e.ols_plan_info(4097, 2_880_000, (4096, 0), torch.float64)                      # float64 beyond 4096 taps: three passes in float64 (round 6)
+    assert (i["path"], i["N"]) == ("passes", 1 << 20) and abs(i["bytes_per_sample"] - (40 * (1 << 20) / i["S"] + 8)) < 1e-9
+    assert e.ols_plan_info(4097, 500_000, (4096, 0), torch.float64)["path"] == "rocfft" # ... on rows of at least one 2^20-point block
     i = e.ols_plan_info(1024, 2_880_000, (1023, 0))                      # aligned rows: one lead tap, a hop of whole cache lines
     assert i["N"] == 8192 and i["S"] == 7168 and i["F"] == 402 and abs(i["bytes_per_sample"] - (4 * 8192 / 7168 + 4)) < 1e-9
     i = e.ols_plan_info(512, 2_880_000, (511, 0))
@@ -322,3 +324,53 @@ def test_lds_ols_many_rows_full_config(K, block):
     for c in (0, 31, 63):
         xc = x[c].cpu().numpy()
         close(y[c:c + 1], _f64_corr(xc[None], k[::-1].copy(), K - 1, 0).astype(np.float32), 2e-6, f"row {c}")
+
+
+# ---- float64 beyond 4096 taps: the three-pass pipeline in float64 (olsnative64.hip) ----------------------------
+@pytest.mark.parametrize("C,T,K,off", [(1, 1 << 20, 4097, 0), (3, 2_500_003, 66559, 0), (2, 1_100_000, 20000, 5), (1, 3_300_017, 140_000, 0),
+                                       (5, (1 << 20) + 12345, 9001, 3)])
+def test_float64_three_pass_vs_float64_reference(C, T, K, off, monkeypatch):
+    """The reference keeps a float64 signal float64 through FIR.forward (fir.py:526-579 -> _fftconv.py:70-141).  Above the
+    one-launch kernels' 4096 taps the float64 three-pass pipeline runs (2^20-point blocks, any row length, any float64
+    alignment, odd frame counts): against a float64 FFT convolution at 1e-11 and against the rocFFT path it replaces."""
+    info = ext().ols_plan_info(K, T, (K - 1, 0), torch.float64)
+    assert info["path"] == "passes" and info["N"] == 1 << 20 and info["bytes_per_sample"] < 60
+    x = rnd((C, T), 31 + C, np.float64)
+    k = np.random.default_rng(K).standard_normal(K) * np.exp(-np.arange(K) / (K / 6.0))
+    kf = (k / np.abs(k).sum())[::-1].copy()
+    buf = torch.zeros(C * T + 32, dtype=torch.float64, device=DEV)
+    xv = buf[off: off + C * T].view(C, T)
+    xv.copy_(torch.from_numpy(x))
+    y = ext().fft_conv_forward(xv, torch.from_numpy(kf), (K - 1, 0))
+    assert y.dtype == torch.float64 and tuple(y.shape) == (C, T)
+    close(y, _f64_corr(x, kf, K - 1, 0), TOL_CONV_F64, f"float64 three passes C={C} T={T} K={K}")
+    for pad in ((K - 1 + 7, 3), (0, 0), (K // 2, K // 2)):
+        close(ext().fft_conv_forward(xv, torch.from_numpy(kf), pad), _f64_corr(x, kf, *pad), TOL_CONV_F64, f"pad={pad}")
+    monkeypatch.setenv("TFX_OLS_NATIVE64", "0")
+    ext().env_reload()
+    try:
+        assert ext().ols_plan_info(K, T, (K - 1, 0), torch.float64)["path"] == "rocfft"
+        y2 = ext().fft_conv_forward(xv, torch.from_numpy(kf), (K - 1, 0))
+    finally:
+        monkeypatch.delenv("TFX_OLS_NATIVE64")
+        ext().env_reload()
+    close(y, y2.cpu().numpy(), TOL_CONV_F64, "three passes vs rocFFT (float64)")
+
+
+def test_float64_fir_module_keeps_float64_on_long_taps():
+    """`FIR.forward` on a float64 wave with a 20 000-tap kernel: float64 out, the float64 pipeline underneath, epilogue as passes."""
+    from torchfx_amd import filter as F
+    K, T = 20000, (1 << 20) + 4321
+    k = np.random.default_rng(1).standard_normal(K) * np.exp(-np.arange(K) / 3000.0)
+    k /= np.abs(k).sum()
+    x = rnd((2, T), 77, np.float64)
+    fir = F.FIR(k)
+    y = fir(dev(x))
+    assert y.dtype == torch.float64
+    k32 = k.astype(np.float32).astype(np.float64)                # the module keeps its taps in float32 (fir.py:516), the signal stays float64
+    close(y, _f64_corr(x, k32[::-1].copy(), K - 1, 0), TOL_CONV_F64, "FIR module, float64")
+    ep = ext().Epilogue(gain=0.5, clamp=True, stat="absmax", per_row=True)
+    y2 = ext().fft_conv_forward(dev(x), torch.from_numpy(k32[::-1].copy()), (K - 1, 0), epilogue=ep)
+    exp = torch.clamp(y * 0.5, -1.0, 1.0)
+    assert torch.equal(y2, exp)
+    close(ep.stat_value, exp.abs().amax(dim=1).cpu().numpy(), 1e-12, "statistic")

@@ -46,6 +46,10 @@ void normalize_apply_forward(const void *x, void *y, int dtype, int64_t C, int64
 void fftconv_clear();
 void olsnative_clear();
 bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out);
+void olsnative_geometry(int64_t K, int64_t Tn, int64_t pl, int64_t pr, int64_t N, int64_t *S_out, int64_t *F_out);
+void olsnative64_clear();
+bool olsnative64_supported(int64_t K, int64_t L, bool has_hist);
+void olsnative64_geometry(int64_t K, int64_t Tn, int64_t pl, int64_t pr, int64_t *S_out, int64_t *F_out);
 void olslds_clear();
 void olsnative_prewarm();
 bool olslds_supported(int64_t K, int dtype, int64_t L, int64_t *N_out);
@@ -485,18 +489,18 @@ static void ols_plan(int64_t K, int64_t T, int64_t pad_left, int64_t pad_right, 
     const int64_t L = T + pad_left + pad_right;
     TFX_CHECK(K >= 1 && L >= K, "ols_plan_info: kernel size %lld larger than the padded signal %lld", (long long)K, (long long)L);
     TFX_CHECK(dtype == TFX_F32 || dtype == TFX_F64, "ols_plan_info: bad dtype %d", dtype);
-    int64_t n = 0, hop = 0;
+    int64_t n = 0, hop = 0, frames = 0;
     int p = 0;
     if (olslds_supported(K, dtype, L, &n)) {
         int64_t lead = 0;
         olslds_geometry(K, T, pad_left, pad_right, dtype == TFX_F32 ? 4 : 8, n, &lead, &hop);
         p = 2;
     } else if (dtype == TFX_F32 && olsnative_supported(K, L, &n)) {
-        const int64_t tout = L - K + 1;
-        const bool align = (T % 32 == 0) && (tout % 32 == 0);
-        const int64_t lead = align ? (32 - (pad_left % 32)) % 32 : 0;
-        hop = n - (K + lead) + 1;
-        if (align && hop > 64) hop -= hop % 32;
+        olsnative_geometry(K, T, pad_left, pad_right, n, &hop, &frames);
+        p = 1;
+    } else if (dtype == TFX_F64 && olsnative64_supported(K, L, false)) {
+        n = (int64_t)1 << 20;
+        olsnative64_geometry(K, T, pad_left, pad_right, &hop, &frames);
         p = 1;
     } else {
         n = fftconv_block_size(K, L);
@@ -504,7 +508,7 @@ static void ols_plan(int64_t K, int64_t T, int64_t pad_left, int64_t pad_right, 
     }
     if (N) *N = n;
     if (S) *S = hop;
-    if (F) *F = ceil_div(L - K + 1, hop);
+    if (F) *F = frames > 0 ? frames : ceil_div(L - K + 1, hop);
     if (path) *path = p;
 }
 
@@ -653,6 +657,7 @@ int tfx_clear_caches(void)
     fir_clear();
     fftconv_clear();
     olsnative_clear();
+    olsnative64_clear();
     olslds_clear();
     scratch_clear();
     TFX_API_END

@@ -34,6 +34,9 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
                        const SosFuseHost *sosf = nullptr);
 void olsnative_wait_warm();
 void olsnative_geometry(int64_t K, int64_t Tn, int64_t pl, int64_t pr, int64_t N, int64_t *S_out, int64_t *F_out);
+bool olsnative64_supported(int64_t K, int64_t L, bool has_hist);                          // olsnative64.hip
+void olsnative64_forward(const double *x, double *y, int64_t C, int64_t Tn, const double *kf_host, int64_t K, int64_t pl, int64_t pr,
+                         hipStream_t stream);
 bool olsnative_sos_supported(int64_t Ksos, int64_t warm, int64_t K, int64_t Tn, int64_t pl, int64_t pr, int force, int64_t *N_out);
 void sos_plan_info(const double *sos_host, int64_t K, int *precision, int64_t *warmup, double *err_bound);
 int64_t sos_warmup_bits(const double *sos_host, int64_t K, int bits);
@@ -345,6 +348,12 @@ void fft_conv_forward(const void *x, void *y, int dtype, int64_t C, int64_t T, c
         // the LDS-resident path applies the epilogue in its last pass (the store of the inverse column FFT)
         olsnative_forward((const float *)x, (float *)y, C, T, (const float *)kernel_host, K, pad_left, pad_right, Nn, stream,
                           (const float *)hist, H, (ep && ep->any()) ? ep : nullptr);
+        return;
+    }
+    if (dtype == TFX_F64 && olsnative64_supported(K, L, hist != nullptr)) {
+        // float64 beyond the one-launch kernels' 4096 taps: the three-pass pipeline in float64 (olsnative64.hip)
+        olsnative64_forward((const double *)x, (double *)y, C, T, (const double *)kernel_host, K, pad_left, pad_right, stream);
+        if (ep && ep->any()) epilogue_as_passes(y, dtype, C, L - K + 1, *ep, stream);
         return;
     }
     if (dtype == TFX_F32)

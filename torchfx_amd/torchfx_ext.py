@@ -346,6 +346,6 @@ def ols_plan_info(K: int, T: int, padding: tuple[int, int] = (0, 0), dtype: torc
     L.check(lib.tfx_ols_plan_info2(int(K), int(T), int(padding[0]), int(padding[1]), code, ctypes.byref(n),
                                    ctypes.byref(s_), ctypes.byref(f), ctypes.byref(path)))
     esz = 8 if dtype == torch.float64 else 4
-    bps = {2: esz * n.value / s_.value + esz, 1: 20.0 * n.value / s_.value + 4.0, 0: 95.0 * esz / 4}[path.value]
+    bps = {2: esz * n.value / s_.value + esz, 1: (20.0 * n.value / s_.value + 4.0) * esz / 4, 0: 95.0 * esz / 4}[path.value]
     return {"N": n.value, "S": s_.value, "F": f.value, "native": path.value != 0,
             "path": ("rocfft", "passes", "lds")[path.value], "bytes_per_sample": bps}
