@@ -374,3 +374,41 @@ def test_float64_fir_module_keeps_float64_on_long_taps():
     exp = torch.clamp(y * 0.5, -1.0, 1.0)
     assert torch.equal(y2, exp)
     close(ep.stat_value, exp.abs().amax(dim=1).cpu().numpy(), 1e-12, "statistic")
+
+
+# ---- rows are independent signals: a non-finite sample never reaches another row (round 6) ------------------------------------
+@pytest.mark.parametrize("dtype,K,T", [(np.float32, 1024, 3 * 7168 - 500), (np.float32, 300, 5 * 3584 + 17), (np.float32, 6000, 3 * 10385 - 9),
+                                       (np.float32, 20000, 2_600_000), (np.float32, 66559, 2_900_000), (np.float64, 2000, 3 * 6193 - 3),
+                                       (np.float64, 20000, 2_600_000)],
+                         ids=["lds8192", "lds4096", "lds16k", "passes-2^18", "passes-2^20", "lds8192-f64", "passes-f64"])
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")], ids=["nan", "inf"])
+def test_non_finite_sample_stays_in_its_row(dtype, K, T, bad):
+    """Two frames ride one complex transform.  When a row has an odd number of frames, the first frame of row c shares its
+    transform with the last frame of row c - 1: a NaN / Inf in row c must not come out in row c - 1 (the reference convolves
+    every row on its own, _fftconv.py:119-140).  Checked on every paired path: the rows before and after stay finite and equal to
+    a clean run (to rounding: the real part of a complex product rounds differently when the imaginary operand changes), the
+    poisoned row is non-finite around the sample and equal to the clean run where it is finite."""
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    info = ext().ols_plan_info(K, T, (K - 1, 0), tdt)
+    assert info["path"] in ("lds", "passes")
+    if info["F"] % 2 == 0:
+        pytest.skip(f"even frame count {info['F']}: no pair straddles two rows at this geometry")
+    x = rnd((3, T), 5, dtype)
+    k = np.random.default_rng(K).standard_normal(K) * np.exp(-np.arange(K) / (K / 5.0))
+    kf = torch.from_numpy((k / np.abs(k).sum()).astype(dtype)[::-1].copy())
+    clean = ext().fft_conv_forward(dev(x), kf, (K - 1, 0)).cpu().numpy()
+    xb = x.copy()
+    xb[1, 37] = bad                                              # inside row 1's FIRST frame = the partner of row 0's last frame
+    y = ext().fft_conv_forward(dev(xb), kf, (K - 1, 0)).cpu().numpy()
+    tol = 2e-6 if dtype == np.float32 else 1e-13
+    assert np.isfinite(y[0]).all(), "the non-finite sample of row 1 leaked into row 0 through the shared transform"
+    close(y[0], clean[0], tol, "row 0 against the clean run")
+    close(y[2], clean[2], tol, "row 2 against the clean run")
+    assert not np.isfinite(y[1, 37:37 + K]).any(), "the samples the bad one reaches must be non-finite"
+    fin = np.isfinite(y[1])
+    assert fin[info["S"] + info["N"]:].all()
+    close(y[1][fin], clean[1][fin], tol, "row 1 where it is finite")
+    ep = ext().Epilogue(gain=1.0, stat="absmax", per_row=True)
+    ext().fft_conv_forward(dev(xb), kf, (K - 1, 0), epilogue=ep)
+    st = ep.stat_value.cpu().numpy()
+    assert np.isnan(st[1]) and np.isfinite(st[0]) and np.isfinite(st[2])

@@ -54,6 +54,8 @@ struct OlsGeom {
                        // moves left by sh(c) = (sh_base + c * Tn) % 32 samples, so every frame still starts on a 128-byte line of
                        // memory; block output i of frame f is then y[f * S + i - sh(c)]  (sh_base = element offset of x in its line)
     int *nf_flag;      // cascade in pass A: [nframes], 1 = the recursion of this frame met a non-finite value (every slot written)
+    int *nf_pair;      // plain pass A: [C] zeroed per call, or null: row c's first frame shares its transform with row c - 1's last and
+                       // held a non-finite sample (only when a row has an odd number of frames)
     int nt;            // nontemporal hints (TFX_OLS_NT, default 3): 1 = signal loads of pass A, 2 = signal stores of pass C -- the signal
                        // is read once and written once; chain step 7.98 -> 7.87 ms.  (The same hint on the workspace loads of
                        // passes B and C, their last use, changes nothing.)
@@ -234,6 +236,19 @@ ols_col_fwd16_kernel(const float *__restrict__ x, cpx *__restrict__ T, const cpx
                 v[i][t] = make_float2(re, im);
             }
     }
+    if (has_b && ca != cb_ && g.nf_pair) {
+        // A pair that straddles two signal rows (the last frame of row ca, the first of row cb): frame b's non-finite samples
+        // enter as zeros and row cb is flagged -- ols_straddle_fix_kernel makes that frame's output NaN, which it would have
+        // been, while row ca keeps its own (rows are independent signals; inside a row a shared transform only widens the
+        // non-finite stretch by a block).  Wave-uniform, at most one pair per row: the other workgroups never get here.
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < NBF; ++i)
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                if (!(__builtin_fabsf(v[i][t].y) <= 3.4028234663852886e38f)) { v[i][t].y = 0.0f; bad = true; }
+        if (bad) g.nf_pair[cb_] = 1;
+    }
     __syncthreads();
     if (PROBE == 0 || PROBE == 4) col_stages16<false, NBF, PROBE == 0>(v, lds, tw256, col, q);
     cpx *Tp = T + pair * ((int64_t)OLS_N1 * g.P2);
@@ -345,6 +360,16 @@ ols_col_inv16_kernel(const cpx *__restrict__ T, float *__restrict__ y, const cpx
             if (has_b) g.ep_partial[fb * ncb + cb] = rb;
         }
     }
+}
+
+// see the straddling-pair branch of ols_col_fwd16_kernel: frame 0 of a flagged row becomes NaN (grid: chunks x C)
+__global__ void __launch_bounds__(256) ols_straddle_fix_kernel(float *__restrict__ y, OlsGeom g)
+{
+    const int64_t c = blockIdx.y;
+    if (!g.nf_pair[c]) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && g.ep_stat >= 0) g.ep_partial[(c * g.F) * (g.N2 / OLS_CB)] = __builtin_nan("");
+    const int64_t hi = min(g.Tout, g.S - g.out_shift - row_shift(g, c));
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < hi; t += (int64_t)gridDim.x * 256) y[c * g.Tout + t] = __builtin_nanf("");
 }
 
 // ---------------------------------------------------------------------------------------------

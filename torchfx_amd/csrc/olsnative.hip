@@ -548,6 +548,7 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     g.sh_base = (int)(((uintptr_t)x >> 2) & 31);
     g.sh_on = (align && (Tn % 32 != 0 || g.sh_base != 0)) ? 1 : 0;
     g.nf_flag = nullptr;
+    g.nf_pair = nullptr;
     g.pad_left = pl + lead;
     g.S = N - (K + lead) + 1;
     if (align && g.S > 64) g.S -= g.S % 32;
@@ -586,6 +587,10 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     g.P2 = g.N2 + (int)envi("TFX_OLS_PITCH_PAD", 0);
     g.nt = (int)envi("TFX_OLS_NT", 3);
     const int64_t npairs = ceil_div(g.nframes, 2);
+    if (!sosf && C > 1 && (g.F & 1)) {     // some pair straddles two signal rows: see ols_col_fwd16_kernel
+        g.nf_pair = (int *)scratch("olsn_nf_pair", (size_t)C * sizeof(int), stream);
+        TFX_HIP(hipMemsetAsync(g.nf_pair, 0, (size_t)C * sizeof(int), stream));
+    }
     if (g.ep_stat >= 0)                   // every (frame, column block) slot is written by exactly one workgroup
         g.ep_partial = (double *)scratch("olsn_ep_partial", (size_t)(g.nframes * (g.N2 / OLS_CB)) * sizeof(double), stream);
     // Slab = the frame pairs one A / B / C launch triple covers; slabs rotate over `nlanes` internal streams, each with its own
@@ -788,6 +793,11 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
         const unsigned chunks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, g.Tout >> 16));
         hipLaunchKernelGGL(ols_sos_nonfinite_fix_kernel, dim3(chunks, (unsigned)C, (unsigned)(1 + (sosf->sections ? sosf->K : 0))), dim3(256), 0,
                            user_stream, y, sosf->sections, g, sosk.warm_blocks);
+        TFX_HIP(hipGetLastError());
+    }
+    if (g.nf_pair) {
+        hipLaunchKernelGGL(ols_straddle_fix_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(64, g.S >> 12)), (unsigned)C), dim3(256), 0,
+                           user_stream, y, g);
         TFX_HIP(hipGetLastError());
     }
     if (g.ep_stat >= 0)                   // after the join: all partials are in

@@ -42,6 +42,7 @@ constexpr int64_t NPTS = (int64_t)N1 * N2;
 struct Geom {
     int64_t Tn, Tout, F, S, pad_left, nframes;
     int sh_on, sh_base;                              // rows that are not whole 128-byte lines: see row_shift (olsnative.hip)
+    int *nf_pair;                                    // [C] zeroed per call, or null: see the straddling-pair branch of ols_col_fwd16_kernel (ols_kernels.h)
 };
 __device__ __forceinline__ int row_shift(const Geom &g, int64_t c) { return g.sh_on ? (int)(((int64_t)g.sh_base + c * g.Tn) & 15) : 0; }
 
@@ -98,6 +99,13 @@ ols64_col_fwd_kernel(const double *__restrict__ x, cpd *__restrict__ T, const cp
             v[t] = mk<double>((ia >= 0 && ia < g.Tn) ? xa[ia] : 0.0, (has_b && ib >= 0 && ib < g.Tn) ? xb[ib] : 0.0);
         }
     }
+    if (has_b && ca != cb_ && g.nf_pair) {           // a pair that straddles two signal rows: row cb's non-finite samples must not reach row ca
+        bool bad = false;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            if (!(__builtin_fabs(v[t].y) <= 1.7976931348623157e308)) { v[t].y = 0.0; bad = true; }
+        if (bad) g.nf_pair[cb_] = 1;
+    }
     __syncthreads();
     col_fft256<false>(v, lds, tw256, col, j);
     cpd *Tp = T + pair * NPTS;
@@ -137,6 +145,14 @@ ols64_col_inv_kernel(const cpd *__restrict__ T, double *__restrict__ y, const cp
             if (has_b && ob >= 0 && ob < g.Tout) __builtin_nontemporal_store(o.y, yb + ob);
         }
     }
+}
+
+__global__ void __launch_bounds__(256) ols64_straddle_fix_kernel(double *__restrict__ y, Geom g)
+{
+    const int64_t c = blockIdx.y;
+    if (!g.nf_pair[c]) return;
+    const int64_t hi = min(g.Tout, g.S - row_shift(g, c));          // frame 0 of row c
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < hi; t += (int64_t)gridDim.x * 256) y[c * g.Tout + t] = __builtin_nan("");
 }
 
 // Row pass: one workgroup per row k1 of a frame pair; thread j holds T[k1][j + 256 t].
@@ -272,6 +288,11 @@ void olsnative64_forward(const double *x, double *y, int64_t C, int64_t Tn, cons
     g.sh_on = (Tn % 16 != 0 || g.sh_base != 0) ? 1 : 0;
     g.F = ceil_div(g.Tout + (g.sh_on ? 15 : 0), g.S);
     g.nframes = C * g.F;
+    g.nf_pair = nullptr;
+    if (C > 1 && (g.F & 1)) {
+        g.nf_pair = (int *)scratch("olsn64_nf_pair", (size_t)C * sizeof(int), stream);
+        TFX_HIP(hipMemsetAsync(g.nf_pair, 0, (size_t)C * sizeof(int), stream));
+    }
     const Plan plan = get_plan(kf_host, K, lead, stream);
     const int dev = current_device();
     constexpr size_t shm_col = (size_t)(N1 * CB + 256) * sizeof(cpd);
@@ -314,6 +335,10 @@ void olsnative64_forward(const double *x, double *y, int64_t C, int64_t Tn, cons
             hipLaunchKernelGGL(ols64_col_inv_kernel, dim3((unsigned)(np * ncb)), dim3(256), shm_col, stream, T, y, plan.tw256, g, 2 * p0);
             TFX_HIP(hipGetLastError());
         }
+    }
+    if (g.nf_pair) {
+        hipLaunchKernelGGL(ols64_straddle_fix_kernel, dim3(64, (unsigned)C), dim3(256), 0, stream, y, g);
+        TFX_HIP(hipGetLastError());
     }
 }
 
