@@ -399,7 +399,7 @@ __device__ __forceinline__ void transform_pair16k_r4(cx<float> (&v)[64], cx<floa
     const v2f *twB = (const v2f *)twB_, *twA = (const v2f *)twA_;
     v2f u[4][16];
     {
-        const v2f w1 = w16kg[j], w2 = w16kg[256 + j], w3 = w16kg[512 + j];
+        const v2f w1 = w16kg[j], w2 = w16kg[512 + j], w3 = w16kg[1024 + j];
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             v2f a0 = __builtin_bit_cast(v2f, v[t]), a1 = __builtin_bit_cast(v2f, v[t + 16]);
@@ -426,7 +426,7 @@ __device__ __forceinline__ void transform_pair16k_r4(cx<float> (&v)[64], cx<floa
         pk::fft4096_pk<true>(u[r], (v2f *)lds, twB, twA, j, Wc, Wr);
     }
     {
-        const v2f w1 = w16kg[j], w2 = w16kg[256 + j], w3 = w16kg[512 + j];
+        const v2f w1 = w16kg[j], w2 = w16kg[512 + j], w3 = w16kg[1024 + j];
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             v2f a0 = u[0][t];
@@ -462,6 +462,149 @@ ols_lds16k_r4_kernel(const float *__restrict__ x, float *__restrict__ y, const v
     sanitize_partner<float, 64>(v, g, p);
     transform_pair16k_r4(v, lds, twB, twA, Hq, w16kg, j);
     store_pair<float, 16384, 64>(v, y, g, p, j, smem);
+}
+
+// ---- 16 384 points in a 512-thread workgroup (round 6): the radix-4 construction with HALF the registers per thread --------------
+// ols_lds16k_r4_kernel holds 64 complex values per thread (198 VGPRs: two workgroups = 8 wavefronts per CU).  Here thread j of 512
+// holds z[j + 512 t], t < 32 -- the footprint of the 8192-point kernel, so 16 wavefronts per CU fit -- and the two halves of the
+// workgroup run two of the four 4096-point transforms AT THE SAME TIME, each through its own exchange buffer:
+//   radix-4 step in registers (n, n + 4096 q are t0 + 8 q of one thread), times W16384^(n r) = W16384^(j r) W256^(8 r t0)
+//   -> u_r[j + 512 t0];  half h transforms r = 2 h and 2 h + 1 and needs u_r[jj + 256 t'] (jj = j & 255): the even t' of half 0 and
+//   the odd t' of half 1 are its own, the others sit in thread j ^ 256 -- one exchange of 16 values per thread through the (still
+//   free) transform buffers, and the mirror image on the way back.  Spectrum and tables: those of the 256-thread radix-4 kernel.
+__device__ __forceinline__ void transform_pair16k_w8(cx<float> (&v)[32], v2f *lbuf, const cx<float> *twB_, const cx<float> *twA_,
+                                                     const v4f *__restrict__ Hq, const v2f *__restrict__ w16kg, int j)
+{
+    const v2f Wc = {0.92387953251128675613f, 0.38268343236508977173f}, Wr = {0.70710678118654752440f, 0.70710678118654752440f};
+    const v2f *twB = (const v2f *)twB_, *twA = (const v2f *)twA_;
+    const int jj = j & 255;
+    const int half = __builtin_amdgcn_readfirstlane(j >> 8);          // wave-uniform: wavefronts 0-3 / 4-7
+    v2f *lds = lbuf + half * (LDS_N + LDS_N / 16);                     // this half's 4096-point exchange buffer
+    v2f *X = lbuf;                                                     // both buffers as one [16][512] exchange (8192 of 8704 slots)
+    v2f u[4][8];
+    {
+        const v2f w1 = w16kg[j], w2 = w16kg[512 + j], w3 = w16kg[1024 + j];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            v2f a0 = __builtin_bit_cast(v2f, v[t]), a1 = __builtin_bit_cast(v2f, v[t + 8]);
+            v2f a2 = __builtin_bit_cast(v2f, v[t + 16]), a3 = __builtin_bit_cast(v2f, v[t + 24]);
+            pk::pk_dft4<false, false>(a0, a1, a2, a3);
+            u[0][t] = a0;                                              // W256^(8 r t) = twB[16 (4 r) + 2 t]
+            u[1][t] = pk::pk_cmul<false>(a1, t ? pk::pk_cmul<false>(w1, twB[16 * 4 + 2 * t]) : w1);
+            u[2][t] = pk::pk_cmul<false>(a2, t ? pk::pk_cmul<false>(w2, twB[16 * 8 + 2 * t]) : w2);
+            u[3][t] = pk::pk_cmul<false>(a3, t ? pk::pk_cmul<false>(w3, twB[16 * 12 + 2 * t]) : w3);
+        }
+    }
+    v2f A[16], B[16];
+    if (half == 0) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { X[t * 512 + j] = u[2][t]; X[(8 + t) * 512 + j] = u[3][t]; }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { X[t * 512 + j] = u[0][t]; X[(8 + t) * 512 + j] = u[1][t]; }
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            A[2 * t] = u[0][t]; A[2 * t + 1] = X[t * 512 + (j ^ 256)];
+            B[2 * t] = u[1][t]; B[2 * t + 1] = X[(8 + t) * 512 + (j ^ 256)];
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            A[2 * t] = X[t * 512 + (j ^ 256)]; A[2 * t + 1] = u[2][t];
+            B[2 * t] = X[(8 + t) * 512 + (j ^ 256)]; B[2 * t + 1] = u[3][t];
+        }
+    }
+    __syncthreads();
+    const v4f *Hh = Hq + (size_t)(16 * half) * 256;                    // spectrum quarters r = 2 h (A) and 2 h + 1 (B)
+    pk::fft4096_pk<false>(A, lds, twB, twA, jj, Wc, Wr);
+    {
+        v4f q[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) q[m] = Hh[m * 256 + jj];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            A[2 * m] = pk::pk_cmul<false>(A[2 * m], v2f{q[m].x, q[m].y});
+            A[2 * m + 1] = pk::pk_cmul<false>(A[2 * m + 1], v2f{q[m].z, q[m].w});
+        }
+    }
+    pk::fft4096_pk<true>(A, lds, twB, twA, jj, Wc, Wr);
+    pk::fft4096_pk<false>(B, lds, twB, twA, jj, Wc, Wr);
+    {
+        v4f q[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) q[m] = Hh[(8 + m) * 256 + jj];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            B[2 * m] = pk::pk_cmul<false>(B[2 * m], v2f{q[m].x, q[m].y});
+            B[2 * m + 1] = pk::pk_cmul<false>(B[2 * m + 1], v2f{q[m].z, q[m].w});
+        }
+    }
+    pk::fft4096_pk<true>(B, lds, twB, twA, jj, Wc, Wr);              // ends with a barrier: both buffers are free
+    // back: half 0 keeps the even t' of its two sub-sequences and hands the odd ones to thread j + 256, half 1 the other way round
+    if (half == 0) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { X[t * 512 + j] = A[2 * t + 1]; X[(8 + t) * 512 + j] = B[2 * t + 1]; }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { X[t * 512 + j] = A[2 * t]; X[(8 + t) * 512 + j] = B[2 * t]; }
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            u[0][t] = A[2 * t]; u[1][t] = B[2 * t];
+            u[2][t] = X[t * 512 + (j ^ 256)]; u[3][t] = X[(8 + t) * 512 + (j ^ 256)];
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            u[0][t] = X[t * 512 + (j ^ 256)]; u[1][t] = X[(8 + t) * 512 + (j ^ 256)];
+            u[2][t] = A[2 * t + 1]; u[3][t] = B[2 * t + 1];
+        }
+    }
+    {
+        const v2f w1 = w16kg[j], w2 = w16kg[512 + j], w3 = w16kg[1024 + j];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            v2f a0 = u[0][t];
+            v2f a1 = pk::pk_cmul<true>(u[1][t], t ? pk::pk_cmul<false>(w1, twB[16 * 4 + 2 * t]) : w1);
+            v2f a2 = pk::pk_cmul<true>(u[2][t], t ? pk::pk_cmul<false>(w2, twB[16 * 8 + 2 * t]) : w2);
+            v2f a3 = pk::pk_cmul<true>(u[3][t], t ? pk::pk_cmul<false>(w3, twB[16 * 12 + 2 * t]) : w3);
+            pk::pk_dft4<true, false>(a0, a1, a2, a3);
+            v[t] = __builtin_bit_cast(cx<float>, a0);
+            v[t + 8] = __builtin_bit_cast(cx<float>, a1);
+            v[t + 16] = __builtin_bit_cast(cx<float>, a2);
+            v[t + 24] = __builtin_bit_cast(cx<float>, a3);
+        }
+    }
+}
+
+constexpr size_t lds16k_w8_bytes() { return (size_t)(2 * (LDS_N + LDS_N / 16) + 512) * sizeof(cx<float>); }
+
+__global__ void __launch_bounds__(512, 4)         // 4 wavefronts per SIMD = two workgroups per CU (LDS: 2 x 73.7 KB)
+ols_lds16k_w8_kernel(const float *__restrict__ x, float *__restrict__ y, const v4f *__restrict__ Hq, const cx<float> *__restrict__ tw256g,
+                     const cx<float> *__restrict__ t4log, const v2f *__restrict__ w16kg, Geom<float> g, int64_t npairs, int64_t per_xcd)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cx<float> *lbuf = (cx<float> *)smem;                              // two [4096 + 256] exchange buffers
+    cx<float> *twB = lbuf + 2 * (LDS_N + LDS_N / 16);
+    cx<float> *twA = twB + 256;
+    const int j = threadIdx.x;
+    if (j < 256) { twB[j] = tw256g[((j >> 4) * (j & 15)) & 255]; twA[j] = t4log[j]; }
+    const int64_t pair = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= per_xcd || pair >= npairs) return;
+    __syncthreads();
+    cx<float> v[32];
+    const PairAt<float> p(pair, g);
+    fetch_pair<float, 16384, 32>(v, x, g, p, j);
+    sanitize_partner<float, 32>(v, g, p);
+    transform_pair16k_w8(v, (v2f *)lbuf, twB, twA, Hq, w16kg, j);
+    store_pair<float, 16384, 32>(v, y, g, p, j, smem);
 }
 
 // ---- second block size: 16 384 points, one 1024-thread workgroup per pair of frames (float32; 2048 < K <= 8192) ----------
@@ -642,7 +785,7 @@ template <typename R> static Plan get_plan(const R *kf, int64_t K, int64_t lead,
                 for (int i = 0; i < 256; ++i) hs.push_back(W(i, 8192));
             if (kind == 3)
                 for (int r = 1; r < 4; ++r)
-                    for (int i = 0; i < 256; ++i) hs.push_back(W(r * i, 16384));
+                    for (int i = 0; i < 512; ++i) hs.push_back(W(r * i, 16384));      // [r - 1][i]: the 256-thread kernel reads i < 256, the 512-thread one all
             p.Hs = upload<R>(hs);
             p.owner = std::shared_ptr<void>(p.Hs, [](void *q) { (void)hipFree(q); });
             p.tw256 = (char *)p.Hs + (size_t)N * sizeof(cx<R>);
@@ -765,7 +908,13 @@ static void olslds_typed(const R *x, R *y, int64_t C, int64_t Tn, const R *kf_ho
     static bool ready[4][TFX_MAX_DEVICES] = {};            // per kernel kind of this instantiation
     bool done = false;
     if constexpr (sizeof(R) == 4) {
-        if (kind == 3) {
+        if (kind == 3 && envi("TFX_OLS_LDS16K_W8", 1) != 0) {
+            static bool ready_w8[TFX_MAX_DEVICES] = {};
+            launch(ols_lds16k_w8_kernel, ready_w8[dev], "ols_lds16k_w8_kernel", lds16k_w8_bytes(), per_xcd * 8, 512,
+                   (const float *)x, (float *)y, (const v4f *)plan.Hs, (const cx<float> *)plan.tw256, (const cx<float> *)plan.t4lo,
+                   (const v2f *)plan.w8k, g, npairs, per_xcd);
+            done = true;
+        } else if (kind == 3) {
             launch(ols_lds16k_r4_kernel, ready[3][dev], "ols_lds16k_r4_kernel", lds_bytes<float>(), per_xcd * 8, 256,
                    (const float *)x, (float *)y, (const v4f *)plan.Hs, (const cx<float> *)plan.tw256, (const cx<float> *)plan.t4lo,
                    (const v2f *)plan.w8k, g, npairs, per_xcd);
