@@ -797,6 +797,10 @@ def main() -> None:
         if args.workload == "chain" and "ols_col_fwd16_sos_kernel" in kernels:
             # the default plan IS the reference's arithmetic: float64 recursion (inside the forward column pass), float32 overlap-save
             roof["step_frac_reference_arithmetic"] = roof["step_frac"]
+            roof["reference_arithmetic_means"] = ("float64 DF1 recursion, one rounding to float32, float32 FFT convolution -- the reference's "
+                                                  "operations, not its bits: a row of the transform restarts from a warm-up (state true to 2^-40), "
+                                                  "FMA contraction and the unit-b0 form reassociate the numerator; parity bars: every section "
+                                                  "2e-11 in float64, the float32 cascade output 1 ulp, the chain 1e-5 (tests/gpu_common.py)")
         if variants and "ms_per_step" in variants.get("chain_fold", {}):
             roof["step_frac_spectral_fold"] = variants["chain_fold"]["frac_of_8TBps_at_8B_per_sample"]
         if variants and "ms_per_step" in variants.get("chain_iir_kernel", {}):
