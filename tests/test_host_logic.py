@@ -538,6 +538,40 @@ def test_cascade_fir_module_staged_fallback(oracle_backend, golden):
     assert m._sos.shape == (4, 6) and m.fs == 48000
 
 
+def test_plan_explains_its_routes():
+    """`Wave.explain()` / `CascadeFIR.route()` (VERDICT r5 #10): which route a tensor takes and why -- host-only queries."""
+    from scipy.signal import firwin
+    ir = np.random.default_rng(0).standard_normal(65536) * np.exp(-np.arange(65536) / 8000.0)
+    members = (F.LoButterworth(2000, order=6, fs=48000), F.ParametricEQ(frequency=1000, q=2.0, gain=3.0, fs=48000),
+               F.FIR(firwin(1024, 5000, fs=48000)), F.FIR(ir / np.abs(ir).sum()))
+
+    def wave(x):
+        w = fx.Wave.__new__(fx.Wave)
+        w._ys, w.fs, w._device, w.metadata, w._pipeline = x, 48000, "meta", {}, list(members)
+        w.fuse_fir, w.fuse_spectral, w.fuse_gain, w.fuse_epilogue, w.fuse_recursive = True, False, False, True, True
+        return w
+    lines = wave(torch.empty((64, 28_800_001), dtype=torch.float32, device="meta")).explain()
+    assert len(lines) == 1 and lines[0].startswith("CascadeFIR: staged -- host tensor")        # a meta tensor is not a device tensor
+    step = wave(torch.empty((64, 28_800_001), dtype=torch.float32, device="meta")).plan()[0]
+
+    class FakeCuda:                                       # what route() reads of a tensor
+        def __init__(self, shape, dtype=torch.float32):
+            self.shape, self.dtype, self.ndim, self.is_cuda = shape, dtype, len(shape), True
+            self.device = torch.device("cuda", 0)
+
+        def reshape(self, *a):
+            return FakeCuda((int(np.prod(self.shape[:-1])), self.shape[-1]), self.dtype)
+    path, why, info = step.route(FakeCuda((64, 28_800_001)))
+    assert path == "fused" and "2097152-point blocks" in why and "480 frame pairs" in why and info["N"] == 1 << 21
+    path, why, _ = step.route(FakeCuda((2, 28_800_001)))
+    assert path == "staged" and "15 frame pairs < 256" in why
+    assert step.route(FakeCuda((2, 28_800_001)), return_sections=True)[0] == "fused"                # section taps come from the fused pass
+    path, why, _ = step.route(FakeCuda((64, 28_800_001), torch.float64))
+    assert path == "staged" and "float64" in why
+    short = wave(torch.empty((64, 1_440_000), dtype=torch.float32, device="meta")).explain()
+    assert short[0].startswith("FusedSOSCascade: staged -- ") and "2^20" in short[0] and short[1] == "FIR"
+
+
 def _gain_chain(wave):
     from scipy.signal import firwin
     irg = np.random.default_rng(2).standard_normal(2049) * np.exp(-np.arange(2049) / 300.0)
