@@ -78,6 +78,34 @@ def test_first_use_inside_a_capture_is_refused_and_a_warm_filter_captures():
     assert torch.isfinite(y2).all()
 
 
+def test_a_workspace_that_must_grow_inside_a_capture_is_refused():
+    """A warm filter captures as long as its workspaces exist for the shapes captured; a capture that would have to ALLOCATE one
+    (here: more rows than the warm-up call had) is refused with a clear message -- under PyTorch's allocator the block would
+    belong to the graph's private pool and die with the graph while the library still holds it."""
+    import numpy as np
+    E = ext()
+    K = 9001
+    k = np.random.default_rng(3).standard_normal(K) * np.exp(-np.arange(K) / 1500.0)
+    kf = torch.from_numpy((k / np.abs(k).sum()).astype(np.float32)[::-1].copy())
+    x = dev(rnd((6, 300_000), 8))
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        y_ref = E.fft_conv_forward(x[:1], kf, (K - 1, 0)).clone()   # warm: spectrum + a one-row workspace on this stream
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            y = E.fft_conv_forward(x[:1], kf, (K - 1, 0))
+        g.replay()
+        s.synchronize()
+        assert torch.equal(y, y_ref)
+        g2 = torch.cuda.CUDAGraph()
+        with pytest.raises(RuntimeError, match="inside a stream capture"):
+            with torch.cuda.graph(g2, stream=s):
+                E.fft_conv_forward(x, kf, (K - 1, 0))              # six rows: the workspace would have to grow
+    torch.cuda.synchronize()
+    assert torch.isfinite(E.fft_conv_forward(x, kf, (K - 1, 0))).all()
+
+
 def test_workspaces_live_in_torchs_allocator_and_shrink_under_pressure():
     """tfx_set_workspace_allocator: the overlap-save workspaces come from PyTorch's caching allocator -- counted
     by torch.cuda.memory_allocated, released by clear_caches + empty_cache -- and with most of the device taken by torch

@@ -223,6 +223,14 @@ void *scratch_try(const char *tag, size_t bytes, hipStream_t stream)
     snprintf(key, sizeof(key), "%s@%p#%d", tag, (void *)stream, dev);
     Scratch &s = g_scr[key];
     if (s.bytes >= bytes) return s.p;
+    {
+        // a workspace that has to grow would be allocated (and the old one freed behind a device synchronise) in the middle of a
+        // stream capture: under PyTorch's allocator the new block would belong to the graph's private pool and die with it
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        TFX_CHECK(!(hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone),
+                  "workspace '%s' (%zu bytes) would be allocated inside a stream capture -- run the op once on this stream with these "
+                  "shapes before capturing", tag, bytes);
+    }
     scratch_release(s);
     if (g_alloc_fn) {
         void *q = g_alloc_fn(bytes, dev, (void *)stream, g_alloc_ctx);

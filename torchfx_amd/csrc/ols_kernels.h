@@ -362,14 +362,15 @@ ols_col_inv16_kernel(const cpx *__restrict__ T, float *__restrict__ y, const cpx
     }
 }
 
-// see the straddling-pair branch of ols_col_fwd16_kernel: frame 0 of a flagged row becomes NaN (grid: chunks x C)
+// see the straddling-pair branch of ols_col_fwd16_kernel: frame 0 of a flagged row becomes NaN (grid: C x chunks -- rows on x, the
+// dimension without a 65 535 limit)
 __global__ void __launch_bounds__(256) ols_straddle_fix_kernel(float *__restrict__ y, OlsGeom g)
 {
-    const int64_t c = blockIdx.y;
+    const int64_t c = blockIdx.x;
     if (!g.nf_pair[c]) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && g.ep_stat >= 0) g.ep_partial[(c * g.F) * (g.N2 / OLS_CB)] = __builtin_nan("");
+    if (blockIdx.y == 0 && threadIdx.x == 0 && g.ep_stat >= 0) g.ep_partial[(c * g.F) * (g.N2 / OLS_CB)] = __builtin_nan("");
     const int64_t hi = min(g.Tout, g.S - g.out_shift - row_shift(g, c));
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < hi; t += (int64_t)gridDim.x * 256) y[c * g.Tout + t] = __builtin_nanf("");
+    for (int64_t t = (int64_t)blockIdx.y * 256 + threadIdx.x; t < hi; t += (int64_t)gridDim.y * 256) y[c * g.Tout + t] = __builtin_nanf("");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -575,7 +576,7 @@ ols_col_fwd16_sos_kernel(const float *__restrict__ x, cpx *__restrict__ T, const
     }
 }
 
-// Fix-up behind pass C of the cascade-in-pass-A pipeline (see the flags above).  Grid (chunks, C, 1 + sections): every
+// Fix-up behind pass C of the cascade-in-pass-A pipeline (see the flags above).  Grid (C, chunks, 1 + sections): every
 // workgroup first reads its signal row's F flags and leaves when none is set -- the common case, a few microseconds for the whole
 // launch.  z = 0: the output row becomes NaN from the first sample of the first flagged frame: that frame's window holds the bad
 // sample and every later frame's window lies behind it -- what the staged pair of launches returns (the cascade's output stays
@@ -589,7 +590,7 @@ ols_sos_nonfinite_fix_kernel(float *__restrict__ y, double *__restrict__ section
     __shared__ int s_first;
     __shared__ long long s_n;
     const int tid = threadIdx.x;
-    const int64_t c = blockIdx.y;
+    const int64_t c = blockIdx.x;
     if (tid == 0) { s_first = 0x7fffffff; s_n = 0x7fffffffffffffffll; }
     __syncthreads();
     for (int64_t f = tid; f < g.F; f += 256)
@@ -601,14 +602,14 @@ ols_sos_nonfinite_fix_kernel(float *__restrict__ y, double *__restrict__ section
     const float nanf_ = __builtin_nanf("");
     if (blockIdx.z == 0) {
         // the statistic of an epilogue saw the flagged frames' stand-in samples: a NaN partial wins both reductions (epilogue.h)
-        if (blockIdx.x == 0 && tid == 0 && g.ep_stat >= 0) g.ep_partial[(c * g.F + first) * (g.N2 / OLS_CB)] = __builtin_nan("");
+        if (blockIdx.y == 0 && tid == 0 && g.ep_stat >= 0) g.ep_partial[(c * g.F + first) * (g.N2 / OLS_CB)] = __builtin_nan("");
         const int64_t t0 = max((int64_t)0, first * g.S - g.out_shift - sh);
-        const int64_t len = g.Tout - t0, per = (len + gridDim.x - 1) / gridDim.x;
-        const int64_t lo = t0 + per * blockIdx.x, hi = min(g.Tout, lo + per);
+        const int64_t len = g.Tout - t0, per = (len + gridDim.y - 1) / gridDim.y;
+        const int64_t lo = t0 + per * blockIdx.y, hi = min(g.Tout, lo + per);
         for (int64_t t = lo + tid; t < hi; t += 256) y[c * g.Tout + t] = nanf_;
         return;
     }
-    if (!sections || blockIdx.x != 0) return;
+    if (!sections || blockIdx.y != 0) return;
     double *row = sections + ((int64_t)(blockIdx.z - 1) * (g.nframes / g.F) + c) * g.Tn;
     const int64_t start = max((int64_t)0, first * g.S - g.pad_left - sh - (int64_t)OLS_CB * warm_blocks);
     for (int64_t t0 = start; t0 < g.Tn; t0 += 4096) {         // first non-finite sample of this section, 4096 samples at a time

@@ -55,8 +55,6 @@ template <typename R> struct Geom {
     R ep_gain;
     int ep_scale, ep_clamp, ep_stat;
     double *ep_partial;   // [nframes]: one partial per frame
-    int *nf_flag;         // [C] or null: row c's first frame shares its transform with the last frame of row c - 1 and held a non-finite
-                          // sample (see sanitize_partner); null when no pair straddles two rows
     int nt;               // TFX_OLS_LDS_NT (default 2): 2 = the output is stored with the nontemporal hint (written once: 2-3 % on every
                           // block size; the same hint on the signal loads, whose overlap the XCD's L2 serves, changes nothing)
 };
@@ -117,27 +115,25 @@ __device__ __forceinline__ void fetch_pair(cx<R> (&v)[VPT], const R *__restrict_
 // Two frames share one complex transform, so a non-finite sample of one comes out in both.  Inside a signal row that only widens
 // the non-finite stretch by a block (the reference's blocks are other sizes anyway, _fftconv.py:119-122) -- but a pair that
 // STRADDLES two rows would carry row c's NaN into the tail of row c - 1, and rows are independent signals.  Such pairs (at most
-// one per row, only when a row has an odd number of frames) check frame b on the way in: non-finite samples enter as zeros and
-// the row is flagged; olslds_straddle_fix_kernel then makes that frame's output NaN, which is what it would have been.
+// one per row, only when a row has an odd number of frames) check frame b on the way in: non-finite samples enter the transform
+// as zeros, and the workgroup -- it owns the pair from load to store -- writes NaN as frame b's output (poison_partner), which is
+// what it would have been.  Returns whether frame b has to be poisoned (workgroup-uniform).
 template <typename R, int VPT>
-__device__ __forceinline__ void sanitize_partner(cx<R> (&v)[VPT], const Geom<R> &g, const PairAt<R> &p)
+__device__ __forceinline__ bool sanitize_partner(cx<R> (&v)[VPT], const PairAt<R> &p)
 {
-    if (!(p.has_b && p.ca != p.cb && g.nf_flag)) return;       // wave-uniform
-    bool bad = false;
+    if (!(p.has_b && p.ca != p.cb)) return false;              // workgroup-uniform: the barrier below is reached by all or none
+    int bad = 0;
 #pragma unroll
     for (int t = 0; t < VPT; ++t)
-        if (!(__builtin_fabs((double)v[t].y) <= 1.7976931348623157e308)) { v[t].y = (R)0; bad = true; }
-    if (bad) g.nf_flag[p.cb] = 1;
+        if (!(__builtin_fabs((double)v[t].y) <= 1.7976931348623157e308)) { v[t].y = (R)0; bad = 1; }
+    return __syncthreads_or(bad) != 0;
 }
-
-template <typename R>
-__global__ void __launch_bounds__(256) olslds_straddle_fix_kernel(R *__restrict__ y, Geom<R> g)
+template <typename R, int VPT>
+__device__ __forceinline__ void poison_partner(cx<R> (&v)[VPT], bool nan_b)
 {
-    const int64_t c = blockIdx.y;
-    if (!g.nf_flag[c]) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && g.ep_stat >= 0) g.ep_partial[c * g.F] = __builtin_nan("");      // wins both reductions (epilogue.h)
-    const int64_t hi = g.S < g.Tout ? g.S : g.Tout;             // frame 0 of row c
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < hi; t += (int64_t)gridDim.x * 256) y[c * g.Tout + t] = (R)__builtin_nan("");
+    if (!nan_b) return;
+#pragma unroll
+    for (int t = 0; t < VPT; ++t) v[t].y = (R)__builtin_nan("");
 }
 
 // the valid part of the block, n < S: real part -> frame a's hop, imaginary part -> frame b's
@@ -265,8 +261,9 @@ ols_lds4096_kernel(const R *__restrict__ x, R *__restrict__ y, const cx<R> *__re
     cx<R> v[16];
     const PairAt<R> p(pair, g);
     fetch_pair<R>(v, x, g, p, j);
-    sanitize_partner<R, 16>(v, g, p);
+    const bool nan_b = sanitize_partner<R, 16>(v, p);
     transform_pair<R>(v, lds, twB, twA, Hs, j);
+    poison_partner<R, 16>(v, nan_b);
     store_pair<R>(v, y, g, p, j, smem);
 }
 
@@ -377,11 +374,12 @@ ols_lds8192_kernel(const R *__restrict__ x, R *__restrict__ y, const cx<R> *__re
     cx<R> v[32];
     const PairAt<R> p(pair, g);
     fetch_pair<R, LDS8K, 32>(v, x, g, p, j);
-    sanitize_partner<R, 32>(v, g, p);
+    const bool nan_b = sanitize_partner<R, 32>(v, p);
     if constexpr (sizeof(R) == 4)
         transform_pair8k(v, lds, twB, twA, (const v4f *)Hs, __builtin_bit_cast(v2f, wj), j);
     else
         transform_pair8k_plain<R>(v, lds, twB, twA, Hs, wj, j);
+    poison_partner<R, 32>(v, nan_b);
     store_pair<R, LDS8K, 32>(v, y, g, p, j, smem);
 }
 
@@ -459,8 +457,9 @@ ols_lds16k_r4_kernel(const float *__restrict__ x, float *__restrict__ y, const v
     cx<float> v[64];
     const PairAt<float> p(pair, g);
     fetch_pair<float, 16384, 64>(v, x, g, p, j);
-    sanitize_partner<float, 64>(v, g, p);
+    const bool nan_b = sanitize_partner<float, 64>(v, p);
     transform_pair16k_r4(v, lds, twB, twA, Hq, w16kg, j);
+    poison_partner<float, 64>(v, nan_b);
     store_pair<float, 16384, 64>(v, y, g, p, j, smem);
 }
 
@@ -602,8 +601,9 @@ ols_lds16k_w8_kernel(const float *__restrict__ x, float *__restrict__ y, const v
     cx<float> v[32];
     const PairAt<float> p(pair, g);
     fetch_pair<float, 16384, 32>(v, x, g, p, j);
-    sanitize_partner<float, 32>(v, g, p);
+    const bool nan_b = sanitize_partner<float, 32>(v, p);
     transform_pair16k_w8(v, (v2f *)lbuf, twB, twA, Hq, w16kg, j);
+    poison_partner<float, 32>(v, nan_b);
     store_pair<float, 16384, 32>(v, y, g, p, j, smem);
 }
 
@@ -658,8 +658,9 @@ ols_lds16k_kernel(const float *__restrict__ x, float *__restrict__ y, const v4f 
         cx<float> v[16];
         const PairAt<float> p(pair, g);
         fetch_pair<float, LDS16K>(v, x, g, p, j);
-        sanitize_partner<float, 16>(v, g, p);
+        const bool nan_b = sanitize_partner<float, 16>(v, p);
         transform_pair16k(v, L, tb, Hq, j);
+        poison_partner<float, 16>(v, nan_b);
         store_pair<float, LDS16K>(v, y, g, p, j, smem);
         __syncthreads();                         // the statistic's scratch is the transform buffer
     }
@@ -886,11 +887,6 @@ static void olslds_typed(const R *x, R *y, int64_t C, int64_t Tn, const R *kf_ho
     const int kind = N == LDS_N ? 0 : N == LDS8K ? 1 : use_r4 ? 3 : 2;
     const Plan plan = get_plan<R>(kf_host, K, lead, (int)N, kind, stream);      // holds its buffer until this function has enqueued its launch
     const int64_t npairs = ceil_div(g.nframes, 2);
-    g.nf_flag = nullptr;
-    if (C > 1 && (g.F & 1)) {                             // some pair straddles two rows: see sanitize_partner
-        g.nf_flag = (int *)scratch("olslds_nf_flag", (size_t)C * sizeof(int), stream);
-        TFX_HIP(hipMemsetAsync(g.nf_flag, 0, (size_t)C * sizeof(int), stream));
-    }
     if (g.ep_stat >= 0) g.ep_partial = (double *)scratch("olslds_ep_partial", (size_t)g.nframes * sizeof(double), stream);
     const int dev = current_device();
     const int64_t per_xcd = ceil_div(npairs, 8);
@@ -938,11 +934,6 @@ static void olslds_typed(const R *x, R *y, int64_t C, int64_t Tn, const R *kf_ho
     else if (!done)
         launch(ols_lds4096_kernel<R>, ready[0][dev], "ols_lds4096_kernel", lds_bytes<R>(), per_xcd * 8, 256,
                x, y, (const cx<R> *)plan.Hs, (const cx<R> *)plan.tw256, (const cx<R> *)plan.t4lo, g, npairs, per_xcd);
-    if (g.nf_flag) {
-        hipLaunchKernelGGL(olslds_straddle_fix_kernel<R>, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(64, g.S >> 10)), (unsigned)C), dim3(256), 0,
-                           stream, y, g);
-        TFX_HIP(hipGetLastError());
-    }
     if (g.ep_stat >= 0)
         stat_finish(g.ep_partial, ep->per_row ? C : 1, ep->per_row ? g.F : g.nframes, g.ep_stat, ep->stat_out, stream);
 }

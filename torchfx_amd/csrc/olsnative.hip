@@ -791,12 +791,12 @@ void olsnative_forward(const float *x, float *y, int64_t C, int64_t Tn, const fl
     }
     if (sosf) {                           // non-finite values stay in a recursion: see ols_sos_nonfinite_fix_kernel
         const unsigned chunks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, g.Tout >> 16));
-        hipLaunchKernelGGL(ols_sos_nonfinite_fix_kernel, dim3(chunks, (unsigned)C, (unsigned)(1 + (sosf->sections ? sosf->K : 0))), dim3(256), 0,
+        hipLaunchKernelGGL(ols_sos_nonfinite_fix_kernel, dim3((unsigned)C, chunks, (unsigned)(1 + (sosf->sections ? sosf->K : 0))), dim3(256), 0,
                            user_stream, y, sosf->sections, g, sosk.warm_blocks);
         TFX_HIP(hipGetLastError());
     }
     if (g.nf_pair) {
-        hipLaunchKernelGGL(ols_straddle_fix_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(64, g.S >> 12)), (unsigned)C), dim3(256), 0,
+        hipLaunchKernelGGL(ols_straddle_fix_kernel, dim3((unsigned)C, (unsigned)std::max<int64_t>(1, std::min<int64_t>(64, g.S >> 12))), dim3(256), 0,
                            user_stream, y, g);
         TFX_HIP(hipGetLastError());
     }

@@ -149,10 +149,10 @@ ols64_col_inv_kernel(const cpd *__restrict__ T, double *__restrict__ y, const cp
 
 __global__ void __launch_bounds__(256) ols64_straddle_fix_kernel(double *__restrict__ y, Geom g)
 {
-    const int64_t c = blockIdx.y;
+    const int64_t c = blockIdx.x;                                    // rows on x: no 65 535 limit
     if (!g.nf_pair[c]) return;
     const int64_t hi = min(g.Tout, g.S - row_shift(g, c));          // frame 0 of row c
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < hi; t += (int64_t)gridDim.x * 256) y[c * g.Tout + t] = __builtin_nan("");
+    for (int64_t t = (int64_t)blockIdx.y * 256 + threadIdx.x; t < hi; t += (int64_t)gridDim.y * 256) y[c * g.Tout + t] = __builtin_nan("");
 }
 
 // Row pass: one workgroup per row k1 of a frame pair; thread j holds T[k1][j + 256 t].
@@ -337,7 +337,7 @@ void olsnative64_forward(const double *x, double *y, int64_t C, int64_t Tn, cons
         }
     }
     if (g.nf_pair) {
-        hipLaunchKernelGGL(ols64_straddle_fix_kernel, dim3(64, (unsigned)C), dim3(256), 0, stream, y, g);
+        hipLaunchKernelGGL(ols64_straddle_fix_kernel, dim3((unsigned)C, 64), dim3(256), 0, stream, y, g);
         TFX_HIP(hipGetLastError());
     }
 }
