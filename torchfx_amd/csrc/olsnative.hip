@@ -459,10 +459,19 @@ bool olsnative_supported(int64_t K, int64_t L, int64_t *N_out)
     if (lg == 16 || lg == 18 || lg == 20 || lg == 21) N = (int64_t)1 << lg;
     else if (lg != 0) return false;
     else if (K < envi("TFX_OLS_NATIVE_MIN_K", 16)) return false;   // a handful of taps: use the direct kernel / rocFFT
-    else if (4 * K <= (1 << 16)) N = 1 << 16;
-    // rows shorter than 4 M samples: 2^18 points -- but from ~24 K taps the 2^20-point block wins there too once a row holds two
-    // of them (64 x 2.88 M: 65 536 taps 1.01-1.07 -> 0.86 ms, 32 768 taps 0.92 -> 0.85; at 20 000 taps equal; r05 experiments section 11)
-    else if (2 * K <= (1 << 18) && L < 4 * ((int64_t)1 << 20)) N = (K > envi("TFX_OLS_N20_MINK", 24576) && L >= ((int64_t)1 << 21)) ? ((int64_t)1 << 20) : (1 << 18);
+    else if (4 * K <= (1 << 16)) {
+        // 8193 ... 16 384 taps (below that the one-launch kernels serve): 2^16 points waste 12-25 % of a block on the overlap.  Rows of
+        // 4 M samples and more take the 2^20-point block (16 x 28.8 M: 16 384 taps 2.20 -> 1.93 ms, 12 288: 2.07 -> 1.93, 8193: 1.98
+        // -> 1.91), rows of 2 M and more the 2^18-point one from 9000 taps (64 x 2.88 M: 16 384 taps 0.936 -> 0.832, 12 288: 0.880 ->
+        // 0.831, 9000: 0.850 -> 0.827); shorter rows are a handful of workgroups either way (profiles/r06_experiments.txt section 9)
+        N = 1 << 16;
+        if (K > 8192 && L >= 4 * ((int64_t)1 << 20)) N = (int64_t)1 << 20;
+        else if (K >= envi("TFX_OLS_N18_MINK", 9000) && L >= ((int64_t)1 << 21)) N = 1 << 18;
+    }
+    // rows shorter than 4 M samples: 2^18 points -- but from ~22 K taps the 2^20-point block wins there too once a row holds two
+    // of them (64 x 2.88 M: 65 536 taps 1.01-1.07 -> 0.86 ms, 32 768 taps 0.92 -> 0.85, 23 000 taps 0.897 -> 0.852; at 22 000 taps
+    // 0.820 against 0.855; r05 experiments section 11, r06 section 9)
+    else if (2 * K <= (1 << 18) && L < 4 * ((int64_t)1 << 20)) N = (K > envi("TFX_OLS_N20_MINK", 22528) && L >= ((int64_t)1 << 21)) ? ((int64_t)1 << 20) : (1 << 18);
     else if (2 * K <= (1 << 20)) {
         N = (int64_t)1 << 20;                            // long signals: 4x fewer blocks, less overlap
         // 2^21 = 256 x 8192 on signals of at least four such blocks: half the overlap again (TFX_OLS_N21: 0 never)
