@@ -18,6 +18,32 @@
 #include <hip/hip_runtime_api.h>
 #endif
 
+/* A host that runs its own device allocator hands it to the library (tfx_set_workspace_allocator): every overlap-save workspace then
+ * comes from -- and goes back to -- these two functions.  Here: the HIP runtime's own calls behind a byte counter. */
+static long long ws_live = 0, ws_calls = 0;
+static void *ws_alloc(size_t bytes, int device, void *stream, void *ctx)
+{
+    void *p = NULL;
+    (void)device; (void)stream; (void)ctx;
+    ++ws_calls;
+#ifdef WITH_HIP
+    if (hipMalloc(&p, bytes) != hipSuccess) return NULL;       /* NULL = "cannot": the pipeline asks again for a smaller slab */
+    ws_live += (long long)bytes;
+#else
+    (void)bytes;
+#endif
+    return p;
+}
+static void ws_free(void *ptr, int device, void *ctx)
+{
+    (void)device; (void)ctx;
+#ifdef WITH_HIP
+    (void)hipFree(ptr);
+#else
+    (void)ptr;
+#endif
+}
+
 /* 2nd-order Butterworth low-pass at fc/fs = 1/12 and a peaking section, [K, 6] rows b0 b1 b2 1 a1 a2 */
 static const double SOS[2][6] = {
     {0.0495329964, 0.0990659928, 0.0495329964, 1.0, -1.2796324250, 0.4777644106},
@@ -48,6 +74,13 @@ int main(int argc, char **argv)
                (long long)fn, (long long)fs, (long long)ff, (long long)fw,
                tfx_sos_fft_conv_supported(28800001, &SOS[0][0], 2, 66559, 66558, 0, 0));
     }
+    /* workspaces under the host's control: install the pair above (host-only call; nothing is allocated before a kernel needs it) */
+    if (tfx_set_workspace_allocator(ws_alloc, ws_free, NULL) != 0 || tfx_set_workspace_allocator(ws_alloc, NULL, NULL) == 0) {
+        fprintf(stderr, "tfx_set_workspace_allocator: %s\n", tfx_last_error());
+        return 1;
+    }
+    printf("workspace allocator installed; held now %lld bytes (%lld calls, %lld bytes through the host's allocator so far)\n",
+           (long long)tfx_workspace_bytes(), ws_calls, ws_live);
     /* error path: a null coefficient pointer is an error code, not a crash */
     if (tfx_sos_plan_info(NULL, 2, &precision, &warm, &bound) == 0) {
         fprintf(stderr, "expected an error for a null SOS pointer\n");
@@ -88,6 +121,10 @@ int main(int argc, char **argv)
             printf("fused cascade|identity FIR vs cascade: max difference %.3g\n", worst);
             hipFree(dz); free(taps); free(hz);
         }
+        /* the pipeline's workspaces came through ws_alloc; tfx_clear_caches hands them back through ws_free */
+        printf("workspaces through the host's allocator: %lld calls, %lld bytes; held %lld\n", ws_calls, ws_live, (long long)tfx_workspace_bytes());
+        tfx_clear_caches();
+        printf("after tfx_clear_caches: held %lld\n", (long long)tfx_workspace_bytes());
         hipFree(dx); hipFree(dy); free(hx); free(hy);
     }
 #else

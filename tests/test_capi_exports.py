@@ -158,6 +158,7 @@ def test_plain_c_host_builds_and_runs_without_a_gpu(tmp_path):
     exe = _build_c_host(tmp_path)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert "tfx_version" in out and "overlap-save plan: N 1048576" in out
+    assert "workspace allocator installed; held now 0 bytes (0 calls" in out
     assert "fused cascade|FIR plan: served 1 block 2097152" in out and "28800001-sample rows served 1" in out      # any row length since round 6 (row_shift)
     assert "null pointer ->" in out            # error code + message instead of a crash
 

@@ -289,3 +289,6 @@ def test_plain_c_host_filters_on_the_device(tmp_path):
     # ... and tfx_sos_fft_conv_forward from C: the cascade inside the overlap-save pipeline with an identity FIR == the cascade kernel
     worst = float(out.split("fused cascade|identity FIR vs cascade: max difference")[1].split()[0])
     assert worst <= 2e-6, out
+    # the workspaces of that step came from the allocator the C host installed (tfx_set_workspace_allocator) and went back to it
+    calls, nbytes = (int(v) for v in out.split("workspaces through the host's allocator:")[1].replace(",", " ").replace(";", " ").split()[0:3:2])
+    assert calls >= 1 and nbytes >= 8 << 20 and "after tfx_clear_caches: held 0" in out, out
